@@ -1,0 +1,453 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, which never travels to the
+GPU box).  Usage:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Outputs (all small, committed):
+    tiny_llama/{config.json,tokenizer.model,...}  tiny Llama dir the reference can load
+    g_meta.json        state_dict key -> shape/dtype of the reference model (fp32 & bf16)
+    g1_encoder*.npz    scene encoder          
+    g2_lm_*.npz        visual-token LM        (G2)
+    g3_nav_*.npz       navigation mode        (G3) + g4 loss/grads (G4)
+    g5_*.npz           object grounding, 3dqa (G5)
+    g6_prompts.json    prompt strings         (G6)
+    g7_graph.npz       graph_utils            (G7)
+    g8_adamw.npz       clip + AdamW on bf16   (G8)
+
+Three shims, all outside the reference tree (the third -- fp32 RoPE
+frequencies, see build_reference -- undoes a transformers 4.28 -> 5.15 drift): the bert-large-uncased
+config lookup is answered locally, and the LM is a from-config tiny Llama with a
+locally trained SentencePiece tokenizer.  Weights are NOT the reference's random
+init: they come from navillm_amd.params.synth_state_dict (seeded, per-name), are loaded
+into the reference module with load_state_dict(strict=True), and are regenerated from
+the seed by the tests -- so fixtures hold inputs + expected outputs only.
+"""
+import os, sys, json, types, logging, random, io
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+from transformers import PretrainedConfig, BertConfig, LlamaConfig  # noqa: E402
+from navillm_amd import config as nvcfg  # noqa: E402
+from navillm_amd.params import param_specs, synth_state_dict  # noqa: E402
+
+TINY_DIR = os.path.join(HERE, "tiny_llama")
+_ENC = {}
+
+
+def _install_bert_shim():
+    orig = PretrainedConfig.from_pretrained.__func__
+
+    def shim(cls, name, *a, **k):
+        if name == "bert-large-uncased":
+            return BertConfig(hidden_size=_ENC["h"], num_hidden_layers=24,
+                              num_attention_heads=_ENC["heads"], intermediate_size=_ENC["ff"])
+        return orig(cls, name, *a, **k)
+    PretrainedConfig.from_pretrained = classmethod(shim)
+
+
+def make_tiny_llama_dir(cfg):
+    import sentencepiece as spm
+    os.makedirs(TINY_DIR, exist_ok=True)
+    random.seed(0)
+    words = ("navigate following the instruction history which contains visual information of your "
+             "previous decisions candidate several directions you can go to at current position is stop "
+             "compare and infer progress then select correct direction from candidates target location output "
+             "walk past table turn left right door kitchen stairs bedroom hallway exit enter wait near sofa "
+             "chair window go straight up down answer question what color object exist select").split()
+    corpus = os.path.join("/tmp", "nv_corpus.txt")
+    with open(corpus, "w") as f:
+        for _ in range(3000):
+            f.write(" ".join(random.choices(words, k=random.randint(5, 20))) + "\n")
+        for _ in range(50):
+            f.write("### Instruction: Navigate following the instruction. ### History: (0) (1) (2) (3) (4) "
+                    "### Candidate: (0) stop (1) (2) (5) (6) (7) (8) (9) ### Output: ### Answer: ### Question:\n")
+    spm.SentencePieceTrainer.train(
+        input=corpus, model_prefix=os.path.join(TINY_DIR, "tokenizer"), vocab_size=cfg.base_vocab_size,
+        model_type="bpe", character_coverage=1.0, unk_id=0, bos_id=1, eos_id=2, pad_id=-1,
+        minloglevel=2)
+    os.remove(os.path.join(TINY_DIR, "tokenizer.vocab"))
+    hf = LlamaConfig(vocab_size=cfg.base_vocab_size, hidden_size=cfg.hidden_size,
+                     intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_layers,
+                     num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_heads,
+                     rms_norm_eps=cfg.rms_norm_eps, max_position_embeddings=2048)
+    hf._attn_implementation = "eager"
+    hf.save_pretrained(TINY_DIR)
+
+
+def build_reference(cfg, seed):
+    """Reference NavModel holding synth_state_dict(cfg, seed)."""
+    import models.nav_model as nm
+    _ENC.update(h=cfg.enc_hidden_size, heads=cfg.enc_num_heads, ff=cfg.enc_intermediate_size)
+    args = types.SimpleNamespace(
+        precision=cfg.precision, pretrained_model_name_or_path=TINY_DIR,
+        image_feat_size=cfg.image_feat_size, angle_feat_size=cfg.angle_feat_size,
+        obj_feat_size=cfg.obj_feat_size, resume_from_checkpoint=None, from_scratch=True,
+        enable_og=cfg.enable_og, fuse_obj=cfg.fuse_obj, feat_dropout=cfg.feat_dropout)
+    model = nm.NavModel(args, logging.getLogger("golden"), types.SimpleNamespace(num_pano_layers=cfg.num_pano_layers))
+    model.lang_model.config._attn_implementation = "eager"
+    ref_sd = model.state_dict()
+    mine = synth_state_dict(cfg, seed)
+    assert set(ref_sd) == set(mine), (sorted(set(ref_sd) ^ set(mine)))
+    for k in ref_sd:
+        assert tuple(ref_sd[k].shape) == tuple(mine[k].shape) and ref_sd[k].dtype == mine[k].dtype, \
+            (k, ref_sd[k].shape, ref_sd[k].dtype, mine[k].shape, mine[k].dtype)
+    model.load_state_dict(mine, strict=True)
+    # Version-drift shim (third one): the reference pins transformers 4.28, whose
+    # LlamaRotaryEmbedding caches cos/sin computed in fp32 at construction; `.to(bf16)`
+    # (modified_lm.py:47) then rounds the TABLES.  The installed 5.15 instead keeps
+    # `inv_freq` as a buffer, so the same `.to(bf16)` rounds the FREQUENCIES (a different,
+    # position-dependent error).  Restore fp32 inv_freq so the fixture has the pinned
+    # behaviour: cos/sin = lm_dtype(cos(fp32 angle)).
+    rot = model.lang_model.model.rotary_emb
+    hd = cfg.head_dim
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))
+    rot.inv_freq = torch.nn.Buffer(inv, persistent=False)
+    rot.original_inv_freq = torch.nn.Buffer(inv.clone(), persistent=False)
+    model.eval()
+    return model
+
+
+def npf(t):
+    """tensor -> numpy (bf16 widened to fp32, exact)."""
+    if isinstance(t, torch.Tensor):
+        t = t.detach()
+        if t.dtype == torch.bfloat16:
+            t = t.float()
+        return t.cpu().numpy()
+    return np.asarray(t)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: npf(v) for k, v in arrs.items()})
+    print(f"  wrote {name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+# ------------------------------------------------------------------ synthetic inputs
+def pano_inputs(cfg, g, B, N, with_obj=False, O=5):
+    lens = torch.tensor([N, N - 2, N - 1][:B] + [N] * max(0, B - 3))
+    x = torch.randn(B, N, cfg.image_feat_size, generator=g)
+    loc = torch.randn(B, N, 7, generator=g)
+    nav = torch.zeros(B, N, dtype=torch.long)
+    cand_k = [3, 2, 4][:B] + [3] * max(0, B - 3)
+    for b in range(B):
+        nav[b, :cand_k[b]] = 1
+        x[b, lens[b]:] = 0
+        loc[b, lens[b]:] = 0
+    d = dict(view_img_fts=x, view_lens=lens, loc_fts=loc, nav_types=nav)
+    if with_obj:
+        ol = torch.tensor([O, O - 3, 1][:B] + [O] * max(0, B - 3))
+        of = torch.randn(B, O, cfg.obj_feat_size, generator=g)
+        olf = torch.randn(B, O, 7, generator=g)
+        for b in range(B):
+            of[b, ol[b]:] = 0
+            olf[b, ol[b]:] = 0
+        d.update(obj_img_fts=of, obj_lens=ol, obj_loc_fts=olf)
+    return d, cand_k
+
+
+def nav_inputs(cfg, g, pano_embeds, pano_masks, cand_k, hist_t):
+    """A toy topological map per sample: slot 0 = stop, some visited nodes, frontier nodes;
+    candidates of the current panorama point at a subset of the frontier (+ one visited)."""
+    B, N, d = pano_embeds.shape
+    vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
+    pm = torch.cat([torch.ones_like(pano_masks[:, :1]), pano_masks], 1)
+    vp_pos = torch.randn(B, N + 1, 14, generator=g)
+    gv, gvis, gstep, cand_vp = [], [], [], []
+    for b in range(B):
+        K = cand_k[b]
+        visited = [f"v{b}_{i}" for i in range(1 + b)]
+        frontier = [f"f{b}_{i}" for i in range(K + 1 - (1 if b == 1 else 0))]
+        vpids = [None] + visited + frontier
+        gv.append(vpids)
+        gvis.append([0] + [1] * len(visited) + [0] * len(frontier))
+        gstep.append([0] + list(range(1, len(visited) + 1)) + [0] * len(frontier))
+        cands = frontier[:K - 1] + [visited[0]] if b != 2 else frontier[:K]
+        cand_vp.append([None] + cands)
+    G = max(len(v) for v in gv)
+    gmask = torch.zeros(B, G, dtype=torch.bool)
+    gvm = torch.zeros(B, G, dtype=torch.bool)
+    gst = torch.zeros(B, G, dtype=torch.long)
+    gimg = torch.randn(B, G, d, generator=g)
+    gpos = torch.randn(B, G, 7, generator=g)
+    for b in range(B):
+        n = len(gv[b])
+        gmask[b, :n] = True
+        gvm[b, :n] = torch.tensor(gvis[b]).bool()
+        gst[b, :n] = torch.tensor(gstep[b])
+        gimg[b, 0] = 0
+        gimg[b, n:] = 0
+        gpos[b, n:] = 0
+    hist_vis = [[torch.randn(d, generator=g) for _ in range(hist_t[b])] for b in range(B)]
+    return dict(
+        gmap_vpids=gv, gmap_img_embeds=gimg, gmap_step_ids=gst, gmap_pos_fts=gpos,
+        gmap_visited_masks=gvm, gmap_masks=gmask,
+        gmap_pair_dists=torch.zeros(B, G, G),
+        vp_img_embeds=vp_img, pano_masks=pm, vp_pos_fts=vp_pos,
+        vp_nav_masks=torch.ones(B, N + 1, dtype=torch.bool), vp_cand_vpids=cand_vp,
+        hist_vis=hist_vis, history=[["<hist>"] * hist_t[b] for b in range(B)],
+        data_type=["r2r"] * B,
+    )
+
+
+INSTR = ["walk past the table and turn left at the door then wait near the sofa",
+         "go straight down the hallway and enter the bedroom",
+         "exit the kitchen turn right and go up the stairs then stop near the window chair"]
+
+
+def gen_precision(prec, seed=11):
+    from tasks.agents.r2r import R2RAgent
+    from tasks.agents.reverie import REVERIEAgent
+    cfg = nvcfg.tiny(precision=prec)
+    tag = "bf16" if cfg.lm_is_bf16 else "fp32"
+    print(f"[{tag}] building reference model")
+    model = build_reference(cfg, seed)
+    lm = model.lang_model
+    assert lm.cand_token_id == [cfg.cand_token_id] and lm.hist_token_id == [cfg.hist_token_id]
+    assert lm.obj_token_id == [cfg.obj_token_id] and lm.cls_token_id == list(cfg.cls_token_ids)
+    assert lm.tokenizer.pad_token_id == cfg.pad_token_id and len(lm.tokenizer) == cfg.vocab_size
+    g = torch.Generator().manual_seed(1234)
+    B, N = 3, 8
+
+    # ---- G1 encoder (fp32 regardless of precision -> only emitted once)
+    if tag == "fp32":
+        pin, cand_k = pano_inputs(cfg, g, B, N, with_obj=True)
+        with torch.no_grad():
+            out = model("panorama", dict(pin))
+            out_nopose = model.img_embeddings.forward_panorama_per_step(pin["view_img_fts"], pin["view_lens"])
+        save("g1_encoder.npz", **pin, pano_embeds=out["pano_embeds"], pano_masks=out["pano_masks"],
+             obj_embeds=out["obj_embeds"], obj_masks=out["obj_masks"],
+             nopose_pano_embeds=out_nopose["pano_embeds"])
+        # fuse_obj variant needs its own model (extra obj_linear params)
+        cfg_f = nvcfg.tiny(precision=prec, fuse_obj=True)
+        mf = build_reference(cfg_f, seed)
+        with torch.no_grad():
+            outf = mf("panorama", dict(pin))
+        save("g1_encoder_fuseobj.npz", **pin, pano_embeds=outf["pano_embeds"], pano_masks=outf["pano_masks"],
+             obj_embeds=outf["obj_embeds"])
+        del mf
+
+    # ---- G2 LM: left-padded ids with <cand>/<hist>, labels on the tail
+    g2 = torch.Generator().manual_seed(77)
+    S = 40
+    ids = torch.randint(3, cfg.base_vocab_size, (B, S), generator=g2)
+    am = torch.ones(B, S, dtype=torch.long)
+    pads = [0, 7, 3]
+    ncand, nhist = 0, 0
+    for b in range(B):
+        ids[b, :pads[b]] = cfg.pad_token_id
+        am[b, :pads[b]] = 0
+        for p_ in (12, 15 + b):
+            ids[b, p_] = cfg.hist_token_id
+            nhist += 1
+        for p_ in (20, 22, 25 + b):
+            ids[b, p_] = cfg.cand_token_id
+            ncand += 1
+        ids[b, S - 9] = cfg.cls_token_ids[0]
+    cand_vis = torch.randn(ncand, cfg.hidden_size, generator=g2)
+    hist_vis = torch.randn(nhist, cfg.hidden_size, generator=g2)
+    labels = ids.clone()
+    labels[:, :S - 8] = -100
+    with torch.no_grad():
+        o = lm(input_ids=ids, attention_mask=am, labels=labels, cand_vis=cand_vis, hist_vis=hist_vis)
+    save(f"g2_lm_{tag}.npz", input_ids=ids, attention_mask=am, labels=labels, cand_vis=cand_vis,
+         hist_vis=hist_vis, hidden_states=o.hidden_states, logits=o.logits[:, -10:], loss=o.loss)
+
+    # ---- G3/G4 navigation + loss + grads
+    pin, cand_k = pano_inputs(cfg, g, B, N)
+    model.zero_grad()
+    pano = model("panorama", dict(pin))
+    hist_t = [2, 0, 3]
+    nin = nav_inputs(cfg, g, pano["pano_embeds"], pano["pano_masks"], cand_k, hist_t)
+    cand_nums = (nin["gmap_masks"] & ~nin["gmap_visited_masks"]).sum(-1)
+    prompts = [R2RAgent.get_navigation_prompt(None, INSTR[b], hist_t[b], int(cand_nums[b]), lm.cls_token[0])
+               for b in range(B)]
+    nin["prompts"] = prompts
+    nin["instruction"] = INSTR
+    tok = lm.tokenize(prompts)
+    torch.manual_seed(4321)
+    perms = [torch.randperm(int(cand_nums[b]) - 1) for b in range(B)]
+    torch.manual_seed(4321)
+    nout = model("navigation", nin)
+    targets = torch.tensor([1, -100, 2])
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-100, reduction="sum")
+    loss = crit(nout["fuse_logits"], targets) * 1.0 / B / 1
+    loss.backward()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    gnames = ["out_head.0.weight", "out_head.0.bias", "img_embeddings.img_linear.weight",
+              "img_embeddings.mapper.weight", "vp_pos_embeddings.0.weight", "vp_pos_embeddings.1.weight",
+              "gmap_pos_embeddings.0.weight", "gmap_step_embeddings.weight", "token_type_embeddings.weight",
+              "lang_model.model.layers.0.self_attn.q_proj.weight", "lang_model.model.layers.1.mlp.down_proj.weight",
+              "lang_model.model.layers.0.input_layernorm.weight", "lang_model.model.norm.weight",
+              "img_embeddings.pano_encoder.layers.0.self_attn.in_proj_weight",
+              "img_embeddings.pano_encoder.layers.1.linear1.weight", "img_embeddings.layer_norm.weight",
+              "img_embeddings.loc_linear.weight", "img_embeddings.nav_type_embedding.weight"]
+    gsave = {"grad/" + n: grads[n] for n in gnames}
+    # embed_tokens grad is large-ish: keep row norms only
+    gsave["gradnorm/lang_model.model.embed_tokens.weight"] = grads["lang_model.model.embed_tokens.weight"].float().norm(dim=1)
+    gsave["grad_names_with_grad"] = np.array(sorted(grads.keys()))
+    flat = {k: v for k, v in pin.items()}
+    for k in ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_visited_masks", "gmap_masks",
+              "vp_pos_fts"):
+        flat[k] = nin[k]
+    flat["nav_pano_masks"] = nin["pano_masks"]
+    flat["hist_vis_flat"] = torch.stack([v for vis in nin["hist_vis"] for v in vis], 0)
+    meta = dict(gmap_vpids=nin["gmap_vpids"], vp_cand_vpids=nin["vp_cand_vpids"], hist_t=hist_t, prompts=prompts,
+                targets=targets.tolist(), perms=[p.tolist() for p in perms], seed_before_nav=4321)
+    save(f"g3_nav_{tag}.npz", **flat, input_ids=tok["input_ids"], attention_mask=tok["attention_mask"],
+         pano_embeds=pano["pano_embeds"], fuse_logits=nout["fuse_logits"], fuse_embeds=nout["fuse_embeds"],
+         loss=loss, meta=np.array(json.dumps(meta)), **gsave)
+
+    # ---- G5 object grounding + 3dqa training loss
+    g5 = torch.Generator().manual_seed(99)
+    pin_o, _ = pano_inputs(cfg, g5, B, N, with_obj=True)
+    with torch.no_grad():
+        po = model("panorama", dict(pin_o))
+        hist_t5 = [1, 2, 0]
+        hv = [[torch.randn(cfg.hidden_size, generator=g5) for _ in range(hist_t5[b])] for b in range(B)]
+        ocn = po["obj_masks"].sum(1) + 1
+        oprompts = [REVERIEAgent.get_object_grounding_prompt(None, INSTR[b], hist_t5[b], int(ocn[b]), lm.cls_token[0])
+                    for b in range(B)]
+        ob = dict(obj_embeds=po["obj_embeds"], obj_masks=po["obj_masks"], obj_loc_fts=po["obj_loc_fts"],
+                  hist_vis=hv, history=[["<hist>"] * t for t in hist_t5], instruction=INSTR,
+                  data_type=["reverie"] * B, prompts=oprompts)
+        oo = model("object_grounding", ob)
+        otok = lm.tokenize(oprompts)
+    save(f"g5_og_{tag}.npz", **pin_o, input_ids=otok["input_ids"], attention_mask=otok["attention_mask"],
+         hist_vis_flat=torch.stack([v for vis in hv for v in vis], 0), obj_embeds=po["obj_embeds"],
+         obj_logits=oo["obj_logits"], meta=np.array(json.dumps(dict(hist_t=hist_t5, prompts=oprompts))))
+
+    feats = [torch.randn(n, cfg.image_feat_size, generator=g5) for n in (6, 4, 5)]
+    qprompts = ["### Question: what color is the chair ? ### Answer: ",
+                "### Question: what is near the window ? ### Answer: ",
+                "### Question: exist table ? ### Answer: "]
+    # one <cand> per view row (llava.py:13-17 uses a single <cand> with one feature row; the model code
+    # only requires #<cand> == #feature rows, nav_model.py:380-385)
+    qprompts = [" ".join(["<cand>"] * f.shape[0]) + " " + q for f, q in zip(feats, qprompts)]
+    answers = [["left door"], ["sofa"], ["kitchen table stop"]]
+    qb = dict(question=qprompts, prompts=qprompts, answers=answers, features=feats, data_type=["scanqa"] * B)
+    with torch.no_grad():
+        qo = model("3dqa", qb, training=True)
+    all_text = [[p, a[0] + lm.tokenizer.eos_token] for p, a in zip(qprompts, answers)]
+    qtok = lm.tokenize(all_text)
+    save(f"g5_qa_{tag}.npz", features=pad(feats), feat_lens=torch.tensor([f.shape[0] for f in feats]),
+         input_ids=qtok["input_ids"], attention_mask=qtok["attention_mask"], token_type_ids=qtok["token_type_ids"],
+         loss=qo.loss, meta=np.array(json.dumps(dict(prompts=qprompts, answers=answers))))
+    return model, cfg
+
+
+def pad(ts):
+    m = max(t.shape[0] for t in ts)
+    return torch.stack([torch.cat([t, torch.zeros(m - t.shape[0], *t.shape[1:])], 0) for t in ts], 0)
+
+
+def gen_prompts():
+    """G6: byte-exact prompt strings of every agent/mode the synthetic driver uses."""
+    from tasks.agents.r2r import R2RAgent
+    from tasks.agents.reverie import REVERIEAgent
+    from tasks.agents.soon import SOONAgent
+    from tasks.agents.cvdn import CVDNAgent
+    out = {}
+    for cls in (R2RAgent, REVERIEAgent, SOONAgent, CVDNAgent):
+        for (h, c) in ((0, 1), (2, 4), (5, 3)):
+            for mode in ("navigation", "object_grounding", "summarization", "embodied_qa"):
+                fn = getattr(cls, f"get_{mode}_prompt", None)
+                if fn is None:
+                    continue
+                try:
+                    if mode in ("navigation", "object_grounding"):
+                        s = fn(None, "INSTR", h, c, "<cls_1>")
+                    else:
+                        s = fn(None, "INSTR", h, c)
+                except Exception as e:  # agent does not implement it this way
+                    continue
+                out[f"{cls.name}/{mode}/{h}/{c}"] = s
+    with open(os.path.join(HERE, "g6_prompts.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print(f"  wrote g6_prompts.json: {len(out)} prompts")
+
+
+def gen_graph():
+    """G7: models/graph_utils.py on a toy graph."""
+    from models.graph_utils import calculate_vp_rel_pos_fts, get_angle_fts, FloydGraph, GraphMap
+    rng = np.random.RandomState(5)
+    pos = {f"n{i}": rng.randn(3).astype(np.float64) * 3 for i in range(7)}
+    edges = [(0, 1), (1, 2), (2, 3), (1, 4), (4, 5), (5, 6), (3, 6)]
+    fg = FloydGraph()
+    dists_after = []
+    for a, b in edges:
+        d = float(np.linalg.norm(pos[f"n{a}"] - pos[f"n{b}"]))
+        fg.add_edge(f"n{a}", f"n{b}", d)
+    for k in ("n1", "n2", "n4", "n5"):
+        fg.update(k)
+        dists_after.append([[fg.distance(f"n{i}", f"n{j}") for j in range(7)] for i in range(7)])
+    paths = {f"{i}-{j}": fg.path(f"n{i}", f"n{j}") for i in (0, 1, 2) for j in (3, 5, 6) if i != j}
+    rel = np.stack([calculate_vp_rel_pos_fts(pos["n0"], pos[f"n{j}"], base_heading=0.3, base_elevation=-0.1)
+                    for j in range(1, 7)])
+    ang = get_angle_fts(rel[:, 0], rel[:, 1], 4)
+    gm = GraphMap("n0")
+    gm.node_positions = dict(pos)
+    gm.graph = fg
+    pf = gm.get_pos_fts("n1", [None, "n0", "n2", "n3", "n5"], 0.3, -0.1)
+    dd = np.array(dists_after, dtype=np.float64)
+    dd[~np.isfinite(dd)] = -1.0
+    save("g7_graph.npz", positions=np.stack([pos[f"n{i}"] for i in range(7)]), edges=np.array(edges),
+         dists_after=dd, rel=rel, ang=ang, pos_fts=pf, meta=np.array(json.dumps(dict(paths=paths))))
+
+
+def gen_adamw():
+    """G8: 3 steps of clip_grad_norm_(40) + torch.optim.AdamW on bf16 and fp32 tensors."""
+    g = torch.Generator().manual_seed(3)
+    p0 = [torch.randn(300, 64, generator=g).mul(0.05).bfloat16(), torch.randn(1000, generator=g).bfloat16(),
+          torch.randn(77, 33, generator=g).mul(0.1)]
+    params = [torch.nn.Parameter(p.clone()) for p in p0]
+    opt = torch.optim.AdamW(params, lr=1e-3)
+    grads, snaps, norms = [], [], []
+    for step in range(3):
+        gs = [(torch.randn(p.shape, generator=g) * (30.0 if step == 1 else 0.3)).to(p.dtype) for p in params]
+        grads.append(gs)
+        for p, gr in zip(params, gs):
+            p.grad = gr.clone()
+        norms.append(torch.nn.utils.clip_grad_norm_(params, 40.0))
+        opt.step()
+        snaps.append([p.detach().clone() for p in params])
+    arr = {}
+    for i in range(3):
+        arr[f"p0_{i}"] = p0[i]
+        for s in range(3):
+            arr[f"g{s}_{i}"] = grads[s][i]
+            arr[f"p{s + 1}_{i}"] = snaps[s][i]
+    arr["norms"] = torch.stack([n.float() for n in norms])
+    save("g8_adamw.npz", **arr)
+
+
+def main():
+    torch.set_num_threads(8)
+    torch.use_deterministic_algorithms(False)
+    _install_bert_shim()
+    cfg = nvcfg.tiny()
+    make_tiny_llama_dir(cfg)
+    meta = {}
+    for prec in ("fp32", "amp_bf16"):
+        model, c = gen_precision(prec)
+        meta[prec] = {k: [list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()}
+    # also record the key inventory for the configs with fuse_obj / no objects
+    with open(os.path.join(HERE, "g_meta.json"), "w") as f:
+        json.dump(meta, f, indent=0, sort_keys=True)
+    gen_prompts()
+    gen_graph()
+    gen_adamw()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,140 @@
+"""CPU: the oracle (oracle/navillm_oracle.py) against the golden vectors produced by the
+reference itself (tests/golden/make_golden.py). This is what pins the oracle."""
+import json
+import os
+import numpy as np
+import pytest
+import torch
+
+from util import (load_oracle, gold, T, tiny_cfg, tiny_weights, meta_of, hist_lists, nav_batch_from_gold, GOLD)
+
+O = load_oracle()
+
+
+def close(a, b, atol, rtol=0.0, what=""):
+    a = torch.as_tensor(a).float()
+    b = torch.as_tensor(b).float()
+    fin = torch.isfinite(b)
+    assert torch.equal(torch.isfinite(a), fin), f"{what}: inf pattern differs"
+    err = (a[fin] - b[fin]).abs()
+    tol = atol + rtol * b[fin].abs()
+    assert bool((err <= tol).all()), f"{what}: max err {err.max().item():.3e} (tol {atol}+{rtol}*|ref|)"
+
+
+def test_param_inventory_matches_reference_state_dict():
+    from navillm_amd.params import param_specs
+    meta = json.load(open(os.path.join(GOLD, "g_meta.json")))
+    for prec, tag in (("fp32", "fp32"), ("amp_bf16", "bf16")):
+        cfg = tiny_cfg(tag)
+        ref = meta[prec]
+        mine = {n: (list(s), "torch.bfloat16" if (g == "lm" and cfg.lm_is_bf16) else "torch.float32")
+                for n, s, g in param_specs(cfg)}
+        assert set(mine) == set(ref)
+        for k in ref:
+            assert mine[k][0] == ref[k][0] and mine[k][1] == ref[k][1], k
+
+
+def test_g1_scene_encoder():
+    z = gold("g1_encoder.npz")
+    cfg, P = tiny_weights("fp32")
+    with torch.no_grad():
+        out = O.scene_encoder(P, cfg, T(z["view_img_fts"]), T(z["view_lens"]), T(z["loc_fts"]), T(z["nav_types"]),
+                              T(z["obj_img_fts"]), T(z["obj_lens"]), T(z["obj_loc_fts"]))
+        nop = O.scene_encoder(P, cfg, T(z["view_img_fts"]), T(z["view_lens"]))
+    close(out["pano_embeds"], z["pano_embeds"], 2e-5, what="pano_embeds")
+    assert np.array_equal(out["pano_masks"].numpy(), z["pano_masks"])
+    close(out["obj_embeds"], z["obj_embeds"], 2e-5, what="obj_embeds")
+    assert np.array_equal(out["obj_masks"].numpy(), z["obj_masks"])
+    close(nop["pano_embeds"], z["nopose_pano_embeds"], 2e-5, what="nopose")
+
+
+def test_g1_scene_encoder_fuse_obj():
+    z = gold("g1_encoder_fuseobj.npz")
+    cfg, P = tiny_weights("fp32", fuse_obj=True)
+    with torch.no_grad():
+        out = O.scene_encoder(P, cfg, T(z["view_img_fts"]), T(z["view_lens"]), T(z["loc_fts"]), T(z["nav_types"]),
+                              T(z["obj_img_fts"]), T(z["obj_lens"]), T(z["obj_loc_fts"]))
+    close(out["pano_embeds"], z["pano_embeds"], 2e-5, what="pano_embeds(fuse_obj)")
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_g2_visual_token_lm(tag):
+    z = gold(f"g2_lm_{tag}.npz")
+    cfg, P = tiny_weights(tag)
+    ids, am = T(z["input_ids"]), T(z["attention_mask"])
+    with torch.no_grad():
+        loss, logits, Hs = O.lm_forward(P, cfg, ids, am, labels=T(z["labels"]), cand_vis=T(z["cand_vis"]),
+                                        hist_vis=T(z["hist_vis"]))
+    real = am.bool()
+    # bf16: same rounding points as HF -> only accumulate-order noise (1 bf16 ulp of ~|x|<=4)
+    atol = 2e-5 if tag == "fp32" else 3e-2
+    close(Hs[real], T(z["hidden_states"])[real], atol, what="hidden_states")
+    close(logits[:, -10:][real[:, -10:]], T(z["logits"])[real[:, -10:]], atol, what="logits")
+    close(loss, z["loss"], 1e-5 if tag == "fp32" else 2e-2, what="lm loss")
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_g3_g4_navigation_loss_grads(tag):
+    z = gold(f"g3_nav_{tag}.npz")
+    cfg, P = tiny_weights(tag)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    m = meta_of(z)
+    pano = O.scene_encoder(P, cfg, T(z["view_img_fts"]), T(z["view_lens"]), T(z["loc_fts"]), T(z["nav_types"]))
+    close(pano["pano_embeds"], z["pano_embeds"], 2e-5, what="pano_embeds")
+    batch, m = nav_batch_from_gold(z, pano["pano_embeds"])
+    torch.manual_seed(m["seed_before_nav"])
+    out = O.navigation(P, cfg, batch, T(z["input_ids"]), T(z["attention_mask"]))
+    assert [p.tolist() for p in out["perms"]] == m["perms"]
+    close(out["fuse_embeds"], z["fuse_embeds"], 2e-5, what="fuse_embeds")
+    atol = 2e-5 if tag == "fp32" else 1e-2
+    close(out["fuse_logits"], z["fuse_logits"], atol, what="fuse_logits")
+    loss = O.action_loss(out["fuse_logits"], torch.tensor(m["targets"])) / len(m["targets"])
+    close(loss, z["loss"], atol, what="loss")
+    loss.backward()
+    names = [k[5:] for k in z if k.startswith("grad/")]
+    for n in names:
+        gref = T(z["grad/" + n]).float()
+        g = P[n].grad.float()
+        rel = (g - gref).norm() / (gref.norm() + 1e-12)
+        assert rel < (1e-4 if tag == "fp32" else 6e-2), (n, rel.item())
+    with_grad = sorted(k for k, v in P.items() if v.grad is not None and bool((v.grad != 0).any()))
+    ref_with_grad = [str(s) for s in z["grad_names_with_grad"]]
+    # params the reference leaves without grad must also be grad-free here
+    assert set(with_grad) <= set(ref_with_grad)
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_g5_object_grounding_and_qa(tag):
+    z = gold(f"g5_og_{tag}.npz")
+    cfg, P = tiny_weights(tag)
+    m = meta_of(z)
+    with torch.no_grad():
+        po = O.scene_encoder(P, cfg, T(z["view_img_fts"]), T(z["view_lens"]), T(z["loc_fts"]), T(z["nav_types"]),
+                             T(z["obj_img_fts"]), T(z["obj_lens"]), T(z["obj_loc_fts"]))
+        close(po["obj_embeds"], z["obj_embeds"], 2e-5, what="obj_embeds")
+        b = dict(obj_embeds=po["obj_embeds"], obj_masks=po["obj_masks"], obj_loc_fts=po["obj_loc_fts"],
+                 hist_vis=hist_lists(T(z["hist_vis_flat"]), m["hist_t"]))
+        oo = O.object_grounding(P, cfg, b, T(z["input_ids"]), T(z["attention_mask"]))
+    close(oo["obj_logits"], z["obj_logits"], 2e-5 if tag == "fp32" else 1e-2, what="obj_logits")
+
+    q = gold(f"g5_qa_{tag}.npz")
+    feats = [T(q["features"])[i, :int(n)] for i, n in enumerate(q["feat_lens"])]
+    with torch.no_grad():
+        loss = O.qa_3d_loss(P, cfg, feats, T(q["input_ids"]), T(q["attention_mask"]), T(q["token_type_ids"]))
+    close(loss, q["loss"], 1e-5 if tag == "fp32" else 2e-2, what="3dqa loss")
+
+
+def test_g8_clip_adamw():
+    z = gold("g8_adamw.npz")
+    ps = [T(z[f"p0_{i}"]) for i in range(3)]
+    ps = [ps[0].bfloat16(), ps[1].bfloat16(), ps[2]]
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    for s in range(3):
+        gs = [T(z[f"g{s}_{i}"]).to(ps[i].dtype) for i in range(3)]
+        total = O.clip_grad_norm_(gs, 40.0)
+        assert abs(float(total) - float(z["norms"][s])) <= 1e-5 * float(z["norms"][s]) + 1e-6
+        for i in range(3):
+            O.adamw_step_(ps[i], gs[i], ms[i], vs[i], s + 1, lr=1e-3)
+            ref = T(z[f"p{s + 1}_{i}"])
+            assert torch.equal(ps[i].float(), ref.float()), (s, i, (ps[i].float() - ref.float()).abs().max())

@@ -1,0 +1,70 @@
+"""Shared helpers for the parity tests (fixtures -> tensors, oracle import)."""
+import os
+import sys
+import json
+import importlib.util
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from navillm_amd import config as nvcfg  # noqa: E402
+from navillm_amd.params import synth_state_dict  # noqa: E402
+
+GOLDEN_SEED = 11  # tests/golden/make_golden.py: gen_precision(seed=11)
+
+
+def load_oracle():
+    spec = importlib.util.spec_from_file_location("navillm_oracle", os.path.join(ROOT, "oracle", "navillm_oracle.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def gold(name):
+    z = np.load(os.path.join(GOLD, name), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return t.to(dtype) if dtype is not None else t
+
+
+def tiny_cfg(tag, **over):
+    return nvcfg.tiny(precision="fp32" if tag == "fp32" else "amp_bf16", **over)
+
+
+def tiny_weights(tag, **over):
+    cfg = tiny_cfg(tag, **over)
+    return cfg, synth_state_dict(cfg, GOLDEN_SEED)
+
+
+def meta_of(z):
+    return json.loads(str(z["meta"]))
+
+
+def hist_lists(flat, hist_t):
+    out, o = [], 0
+    for t in hist_t:
+        out.append([flat[o + i] for i in range(t)])
+        o += t
+    return out
+
+
+def nav_batch_from_gold(z, pano_embeds):
+    """Rebuild the `model('navigation', batch)` dict of g3_nav_*.npz around `pano_embeds`."""
+    m = meta_of(z)
+    vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
+    return dict(
+        gmap_vpids=m["gmap_vpids"], gmap_img_embeds=T(z["gmap_img_embeds"]), gmap_step_ids=T(z["gmap_step_ids"]),
+        gmap_pos_fts=T(z["gmap_pos_fts"]), gmap_visited_masks=T(z["gmap_visited_masks"]),
+        gmap_masks=T(z["gmap_masks"]), vp_img_embeds=vp_img, pano_masks=T(z["nav_pano_masks"]),
+        vp_pos_fts=T(z["vp_pos_fts"]), vp_cand_vpids=m["vp_cand_vpids"],
+        hist_vis=hist_lists(T(z["hist_vis_flat"]), m["hist_t"]),
+        history=[["<hist>"] * t for t in m["hist_t"]], data_type=["r2r"] * len(m["hist_t"]),
+        prompts=m["prompts"],
+    ), m
