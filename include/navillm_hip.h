@@ -1,0 +1,123 @@
+/*
+ * navillm_hip.h -- C ABI of libnavillm_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (zd11024/NaviLLM) is pure Python: its drop-in boundary is the module protocol
+ * `NavModel.forward(mode, batch)` (models/nav_model.py:96-126), mirrored by navillm_amd/nav_model.py.
+ * Beneath that class every device computation goes through the entry points below; each one names
+ * the reference call it replaces.  Conventions:
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless noted "host"
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous and stream-ordered
+ *   - return 0 on success, <0 on error (NV_ERR_*); nothing throws, nothing allocates:
+ *     scratch is caller-provided, sized by the `*_workspace_bytes` twin
+ *   - bf16 tensors are raw uint16 bit patterns; rounding is round-to-nearest-even
+ *   - re-entrant; no hidden global state
+ */
+#ifndef NAVILLM_HIP_H
+#define NAVILLM_HIP_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NV_OK 0
+#define NV_ERR_ARG (-1)
+#define NV_ERR_SHAPE (-2)
+#define NV_ERR_LAUNCH (-3)
+
+/* ---- bf16 MFMA GEMM family: the Linear layers of HF LlamaDecoderLayer reached from
+ *      models/modified_lm.py:112-116, and lm_head (modified_lm.py:120).
+ *   C[M,N] = sum_k Aop[m,k]*Bop[n,k], fp32 accumulate.
+ *   layout 0 "NT": A[M,K] B[N,K]  (forward  y = x W^T)          K % 64 == 0
+ *   layout 1 "NN": A[M,K] B[K,N]  (dgrad    dx = dy W)           K % 64 == 0
+ *   layout 2 "TN": A[K,M] B[K,N]  (wgrad    dW = dy^T x)         any K
+ *   epilogue 0 store | 1 C = bf16(C + bf16(acc))  (grad accumulation)
+ *            2 C = bf16(R[m,n] + bf16(acc))       (residual add)   | 3 C = bf16(acc + R[n]) (bias)
+ *   tile_cfg 0 auto | 1 128x128 | 2 256x128 | 3 256x256.   lda/ldb multiples of 8, A/B 16-B aligned. */
+int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
+                 int ldb, int ldc, int ldr, int epilogue, int tile_cfg, void* stream);
+
+/* ---- K6: embedding gather + visual-token add, models/modified_lm.py:100-110.
+ *   out[m] = table[ids[m]]  or  bf16(f32(table[ids[m]]) + vis[vis_idx[m]])  when vis_idx[m] >= 0 */
+int nv_embed_vis_bf16(const void* table, const int* ids, const int* vis_idx, const float* vis, void* out, int M, int d,
+                      void* stream);
+/*   backward of the add: dvis[i] = f32(dE[vis_rows[i]]) */
+int nv_vis_grad_f32(const void* dE, const int* vis_rows, float* dvis, int nvis, int d, void* stream);
+/*   embedding-table gradient; tokens grouped by id on the host: segment u = tok[seg_off[u]..seg_off[u+1]) */
+int nv_embed_grad_bf16(const void* dE, const int* uniq, const int* seg_off, const int* tok, void* gtable, int n_uniq, int d,
+                       void* stream);
+
+/* ---- K7c: HF LlamaRMSNorm (fp32 statistics), forward and backward (+fused residual-grad add,
+ *      weight grad accumulated into gw as bf16(gw + bf16(sum))) */
+int nv_rmsnorm_fwd_bf16(const void* x, const void* w, void* y, float* rstd, int M, int d, float eps, void* stream);
+size_t nv_rmsnorm_bwd_workspace_bytes(int d);
+int nv_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const float* rstd, const void* resid_grad, void* dx,
+                        void* gw, void* workspace, int M, int d, void* stream);
+
+/* ---- HF apply_rotary_pos_emb on the q and k parts of packed qkv [M, 3*H*hd] in place; position of
+ *      row m is m % S (arange(S) incl. left padding); tables [maxS, hd] bf16 as HF builds them;
+ *      backward != 0 applies the transpose */
+int nv_rope_bf16(void* qkv, const void* cos_t, const void* sin_t, int M, int S, int H, int hd, int ld, int backward,
+                 void* stream);
+
+/* ---- HF LlamaMLP activation on packed gate|up [M, 2*ff]: h = bf16(bf16(silu(g)) * u) */
+int nv_swiglu_fwd_bf16(const void* gu, void* h, int M, int ff, void* stream);
+int nv_swiglu_bwd_bf16(const void* gu, const void* dh, void* dgu, int M, int ff, void* stream);
+
+int nv_gather_rows_bf16(const void* src, const int* rows, void* out, int n, int d, void* stream);
+int nv_scatter_rows_bf16(const void* src, const int* rows, void* dst, int n, int d, void* stream);
+
+/* ---- K7b: causal + left-pad attention of HF LlamaAttention (head_dim 128), flash style.
+ *   qkv [B*S, 3*H*128] post-RoPE, out [B*S, H*128], lse2 [B,H,S] (log2 domain, +inf for fully
+ *   masked rows), kv_start[b] = number of left-pad positions of sample b. */
+int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, int B, int S, int H, int head_dim,
+                     void* stream);
+size_t nv_attn_bwd_workspace_bytes(int B, int S, int H);
+int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
+                     void* workspace, int B, int S, int H, int head_dim, void* stream);
+
+/* ---- K10: action / object head Linear(d -> N<=128) in the LM dtype, models/nav_model.py:237,445 */
+int nv_head_fwd_bf16(const void* x, const void* W, const void* bias, void* y, int B, int d, int N, void* stream);
+int nv_head_bwd_bf16(const void* dy, const void* x, const void* W, void* dx, void* gW, void* gb, int B, int d, int N,
+                     void* stream);
+
+/* ---- K11: CrossEntropyLoss(ignore_index=-100, reduction='sum') on bf16 logits with -inf slots,
+ *      train.py:229 / tasks/agents/mp3d_agent.py:750. loss_rows[b] fp32; dlogits = bf16(gscale*(p-onehot)) */
+int nv_action_ce_bf16(const void* logits, const long* targets, float* loss_rows, void* dlogits, int B, int G, float gscale,
+                      void* stream);
+/* ---- K9: token CE of models/modified_lm.py:122-137 on materialised logits (special ids = -inf,
+ *      labels already shifted on the host, -100 ignored); logits overwritten by their gradient */
+int nv_lm_ce_bf16(void* logits, const int* labels, float* loss_rows, int M, int V, int ldl, int special0, int nspecial,
+                  float gscale, int write_grad, void* stream);
+
+/* ---- K13: clip_grad_norm_(40) + AdamW on flat parameter buffers, train.py:86-89, tools/optims.py:43-45 */
+int nv_sumsq(const void* g, long n, int is_bf16, float* partial, int* n_partial_host, void* stream);
+int nv_clip_coef(const float* partial, int n_partial, float max_norm, float* out2, void* stream);
+int nv_adamw(void* p, const void* g, void* m, void* v, long n, int is_bf16, float lr, float beta1, float beta2, float eps,
+             float wd, int step, const float* clip_out2, void* stream);
+
+/* ---- fp32 scene encoder + fusion (K1-K5, K12): models/image_embedding.py:51-121,
+ *      models/detr_transformer.py:170-182, models/nav_model.py:146-194 */
+int nv_gemm_f32(int layout, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                int ldc, int accumulate, void* stream);
+int nv_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, int M, int d,
+                         float eps, void* stream);
+size_t nv_layernorm_bwd_workspace_bytes(int d);
+int nv_layernorm_bwd_f32(const float* dy, const float* x, const float* w, const float* mean, const float* rstd, float* dx,
+                         float* gw, float* gb, void* workspace, int M, int d, int accumulate, void* stream);
+int nv_colsum_f32(const float* x, float* out, int M, int d, int ld, int accumulate, void* stream);
+int nv_mha_fwd_f32(const float* qkv, const int* lens, float* out, float* P, int B, int N, int heads, int hd, void* stream);
+int nv_mha_bwd_f32(const float* qkv, const float* P, const float* dout, float* dqkv, int B, int N, int heads, int hd,
+                   void* stream);
+int nv_gelu_fwd_f32(const float* x, float* y, long n, void* stream);
+int nv_gelu_bwd_f32(const float* x, const float* dy, float* dx, long n, void* stream);
+int nv_add_f32(const float* a, const float* b, float* out, long n, int d, int b_bcast, void* stream);
+int nv_rowscale_f32(const float* x, const float* s, float* out, long rows, int d, void* stream);
+int nv_gather_add_f32(const float* src, const int* idx, const float* base, float* out, long rows, int d, void* stream);
+int nv_index_sum_f32(const float* src, const int* idx, float* dst, int n, int R, int d, int accumulate, void* stream);
+int nv_masked_mean_f32(const float* x, const float* mask, float* out, int B, int N, int d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

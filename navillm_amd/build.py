@@ -1,0 +1,47 @@
+"""Build libnavillm_hip.so (gfx950) in-tree with hipcc. `python -m navillm_amd.build`."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libnavillm_hip.so")
+SOURCES = ["gemm_bf16.hip", "lm_rowops.hip", "attention.hip", "enc_f32.hip", "head_loss_optim.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdr = os.path.join(CSRC, "nv_common.h")
+
+    def compile_one(src):
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if force or _stale(o, [s, hdr]):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        return o
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _stale(OUT, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(OUT)

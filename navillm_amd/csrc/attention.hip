@@ -1,0 +1,498 @@
+// Causal + left-pad flash attention, forward and backward, head_dim = 128, bf16 in/out,
+// fp32 softmax (K7b in SURVEY.md §2.2; reference: HF LlamaAttention reached from
+// models/modified_lm.py:112-116, eager path = softmax(QK^T*scale + mask) @ V).
+//
+// Data: packed post-RoPE qkv [B*S, 3*H*128] (q | k | v), out [B*S, H*128], positions s=0..S-1
+// per sample, keys s < kv_start[b] are left padding (masked), causal key <= query.
+//
+// CDNA4 mapping (all three kernels share it):
+//  * v_mfma_f32_16x16x32_bf16 with the operands SWAPPED so the score tile comes out
+//    transposed (keys down the 4 in-lane rows, one query per lane&15): the row max/sum of a
+//    query is then 16 in-lane values + two cross-lane steps, the softmax rescale is a per-lane
+//    scalar, and P^T is already laid out as the next MFMA's B operand (k = keys, in a
+//    permuted order that the V^T operand reproduces) -- no LDS round trip for P.
+//  * K/V (or Q/dO) tiles are DMA'd HBM->LDS with bounds-checked buffer_load...lds into an
+//    XOR-swizzled [rows][128] image that serves both ds_read_b128 (row-major operand) and
+//    ds_read_b64_tr_b16 (transposed operand) conflict-free; double buffered.
+//  * lse is kept in the log2 domain (lse2 = m2 + log2(l)); fully masked rows store +inf so
+//    the backward's exp2(s2 - lse2) is exactly 0 for them.
+#include "nv_common.h"
+
+namespace {
+
+constexpr int HD = 128;
+constexpr int ROWB = HD * 2;  // 256-B LDS rows
+
+__device__ __forceinline__ int key4(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
+
+// DMA `ROWS` rows x 128 bf16 (global row stride ld elements) into an LDS image.
+template <int ROWS, int NT>
+__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rsrc, LDS_PTR(char) lds, int row0, int col0, int ld,
+                                           int tid) {
+    constexpr int ITERS = (ROWS * ROWB) / (NT * 16);
+    static_assert((ROWS * ROWB) % (NT * 16) == 0, "tile/threads mismatch");
+    const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int chunk = it * (NT / 64) + wave;      // 1 KiB = 4 rows
+        const int row = chunk * 4 + (lane >> 4);
+        const int slot = (lane & 15) ^ key4(row);
+        const uint32_t voff = (uint32_t)(((long)(row0 + row) * ld + col0 + slot * 8) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_PTR(void))(lds + chunk * 1024), 16, voff, 0, 0, 0);
+    }
+}
+
+// row-major operand fragment: lane (idx=lane&15, kg=lane>>4) <- tile[r0+idx][kk*32+kg*8 .. +7]
+__device__ __forceinline__ bf16x8 frag_rm(LDS_PTR(char) tile, int r0, int kk, int lane) {
+    const int row = r0 + (lane & 15);
+    const int slot = (kk * 4 + (lane >> 4)) ^ key4(row);
+    return *(LDS_PTR(bf16x8))(tile + row * ROWB + slot * 16);
+}
+
+// transposed operand fragment: lane (idx, kg) <- { tile[rA+kg*4+e][c0+idx] , tile[rB+kg*4+e][c0+idx] } e=0..3
+__device__ __forceinline__ bf16x8 frag_tr(LDS_PTR(char) tile, int rA, int rB, int c0, int lane) {
+    const int t = lane & 15, kg = lane >> 4;
+    const int slot = (c0 >> 3) + ((t & 3) >> 1);
+    const int half = (t & 1) * 8;
+    const int ra = rA + kg * 4 + (t >> 2), rb = rB + kg * 4 + (t >> 2);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + ra * ROWB + ((slot ^ key4(ra)) << 4) + half));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(tile + rb * ROWB + ((slot ^ key4(rb)) << 4) + half));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
+    u32x4 v = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// reduce over the 4 lane groups that share lane&15
+__device__ __forceinline__ float grp_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float grp_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+struct AttnArgs {
+    const bf16_t* qkv; bf16_t* out; float* lse2;        // fwd
+    const bf16_t* dout; const float* dsum; bf16_t* dqkv; // bwd
+    const int* kv_start;
+    int B, S, H, ld;       // ld = 3*H*HD (qkv row stride), out row stride = H*HD
+    float scale2;          // head_dim^-0.5 * log2(e)
+    float scale;           // head_dim^-0.5
+};
+
+// =========================================================================== forward
+// grid (ceil(S/128), B*H), 256 threads: wave w owns queries q0 + w*32 .. +31 (two 16-query tiles)
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
+    constexpr int TILE = 64 * ROWB;  // 16 KiB per K or V tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int S = p.S, ld = p.ld;
+    const int q0 = blockIdx.x * 128;
+    const int kvs = p.kv_start[b];
+    const int qi = lane & 15, g = lane >> 4;
+    const bf16_t* base = p.qkv + (long)b * S * ld;
+    const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, span);
+    const int kcol = p.H * HD + h * HD, vcol = 2 * p.H * HD + h * HD;
+
+    // Q fragments (B operand: j = query, k = head dim), straight from HBM
+    bf16x8 qf[2][4];
+    int qpos[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        qpos[j] = q0 + wave * 32 + j * 16 + qi;
+        const int ql = qpos[j] < S ? qpos[j] : S - 1;
+        const bf16_t* qp = base + (long)ql * ld + h * HD + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[j][kk] = *(const bf16x8*)(qp + kk * 32);
+    }
+
+    f32x4 o[8][2];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o[dt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m2[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+
+    const int q_hi = (q0 + 127 < S - 1) ? q0 + 127 : S - 1;   // last query of this block
+    const int kt_beg = kvs / 64, kt_end = q_hi / 64;           // inclusive key-tile range
+    if (kt_beg <= kt_end) {
+        auto stage = [&](int kt, int buf) {
+            stage_rows<64, 256>(rs, smem + buf * 2 * TILE, kt * 64, kcol, ld, tid);
+            stage_rows<64, 256>(rs, smem + buf * 2 * TILE + TILE, kt * 64, vcol, ld, tid);
+        };
+        stage(kt_beg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt_beg; kt <= kt_end; ++kt) {
+            if (kt < kt_end) stage(kt + 1, cur ^ 1);
+            LDS_PTR(char) sk = smem + cur * 2 * TILE;
+            LDS_PTR(char) sv = sk + TILE;
+            // ---- S^T = K Q^T : 4 key tiles x 2 query tiles
+            f32x4 s[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x8 kf = frag_rm(sk, i * 16, kk, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        s[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[j][kk], s[i][j], 0, 0, 0);
+                }
+            }
+            // ---- mask + online softmax (per query = per lane&15)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 64 + i * 16 + g * 4 + r;
+                        const bool ok = (key <= qpos[j]) && (key >= kvs);
+                        const float v = ok ? s[i][j][r] * p.scale2 : -INFINITY;
+                        s[i][j][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = grp_max(mx);
+                const float mn = fmaxf(m2[j], mx);
+                const float msafe = (mn == -INFINITY) ? 0.f : mn;
+                const float alpha = exp2f(m2[j] - msafe);   // m2=-inf -> 0
+                m2[j] = mn;
+                float rs_ = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = exp2f(s[i][j][r] - msafe);
+                        s[i][j][r] = e;
+                        rs_ += e;
+                    }
+                l[j] = l[j] * alpha + rs_;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) o[dt][j] *= alpha;
+            }
+            // ---- O^T += V^T P^T : k = keys (two 32-key steps), 8 d tiles
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                bf16x8 pf[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) pf[j] = pack_frag(s[2 * a][j], s[2 * a + 1][j]);
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    const bf16x8 vf = frag_tr(sv, a * 32, a * 32 + 16, dt * 16, lane);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        o[dt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[j], o[dt][j], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // ---- finalize
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float lt = grp_sum(l[j]);
+        const bool valid = qpos[j] < S;
+        const float inv = lt > 0.f ? 1.f / lt : 0.f;
+        if (valid) {
+            bf16_t* op = p.out + ((long)b * S + qpos[j]) * (p.H * HD) + h * HD + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                u32x2 w = {pack2bf(o[dt][j][0] * inv, o[dt][j][1] * inv), pack2bf(o[dt][j][2] * inv, o[dt][j][3] * inv)};
+                *(u32x2*)(op + dt * 16) = w;
+            }
+            if (g == 0) p.lse2[((long)b * p.H + h) * S + qpos[j]] = lt > 0.f ? m2[j] + log2f(lt) : INFINITY;
+        }
+    }
+}
+
+// =========================================================================== backward prep
+// dsum[b,h,q] = sum_d dO[q,d] * O[q,d]   (one wave per (row, head))
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
+                                                            float* __restrict__ dsum, int B, int S, int H) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + wave;   // (row, head)
+    if (item >= (long)B * S * H) return;
+    const long row = item / H;
+    const int h = (int)(item % H);
+    const bf16_t* a = dout + row * (H * HD) + h * HD + lane * 2;
+    const bf16_t* o = out + row * (H * HD) + h * HD + lane * 2;
+    const uint32_t av = *(const uint32_t*)a, ov = *(const uint32_t*)o;
+    float v = __uint_as_float(av << 16) * __uint_as_float(ov << 16) +
+              __uint_as_float(av & 0xffff0000u) * __uint_as_float(ov & 0xffff0000u);
+    v = wave_sum(v);
+    if (lane == 0) {
+        const int bb = (int)(row / S), s = (int)(row % S);
+        dsum[((long)bb * H + h) * S + s] = v;
+    }
+}
+
+// =========================================================================== backward dK, dV
+// grid (ceil(S/64), B*H), 256 threads: wave w owns keys k0 + w*16 .. +15; walks query tiles of 32.
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
+    constexpr int TILE = 32 * ROWB;  // 8 KiB per Q or dO tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int S = p.S, ld = p.ld;
+    const int kblk = blockIdx.x * 64;
+    const int kvs = p.kv_start[b];
+    const int ki = lane & 15, g = lane >> 4;
+    const int key = kblk + wave * 16 + ki;
+    const bf16_t* base = p.qkv + (long)b * S * ld;
+    const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(base, span);
+    const int od = p.H * HD;
+    const bf16_t* dobase = p.dout + (long)b * S * od;
+    const __amdgpu_buffer_rsrc_t rdo = make_rsrc(dobase, (uint32_t)(((long)(S - 1) * od + od) * 2));
+    const float* lse2 = p.lse2 + ((long)b * p.H + h) * S;
+    const float* dsum = p.dsum + ((long)b * p.H + h) * S;
+
+    // K and V fragments (B operand: j = key, k = head dim) from HBM
+    bf16x8 kf[4], vf[4];
+    {
+        const int kl = key < S ? key : S - 1;
+        const bf16_t* kp = base + (long)kl * ld + p.H * HD + h * HD + g * 8;
+        const bf16_t* vp = base + (long)kl * ld + 2 * p.H * HD + h * HD + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            kf[kk] = *(const bf16x8*)(kp + kk * 32);
+            vf[kk] = *(const bf16x8*)(vp + kk * 32);
+        }
+    }
+    f32x4 dv[8], dk[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    // queries that can see this key block: q >= kblk (causal), q >= kvs (pad queries have p=0 anyway)
+    const int qt_beg = kblk / 32, qt_end = (S - 1) / 32;
+    auto stage = [&](int qt, int buf) {
+        stage_rows<32, 256>(rq, smem + buf * 2 * TILE, qt * 32, h * HD, ld, tid);
+        stage_rows<32, 256>(rdo, smem + buf * 2 * TILE + TILE, qt * 32, h * HD, od, tid);
+    };
+    stage(qt_beg, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int qt = qt_beg; qt <= qt_end; ++qt) {
+        if (qt < qt_end) stage(qt + 1, cur ^ 1);
+        LDS_PTR(char) sq = smem + cur * 2 * TILE;
+        LDS_PTR(char) sdo = sq + TILE;
+        // ---- S = Q K^T and dP = dO V^T : lane holds key = lane&15, queries qt*32 + j*16 + g*4 + r
+        f32x4 s[2], dp[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { s[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bf16x8 qa = frag_rm(sq, j * 16, kk, lane);
+                const bf16x8 da = frag_rm(sdo, j * 16, kk, lane);
+                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kk], s[j], 0, 0, 0);
+                dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kk], dp[j], 0, 0, 0);
+            }
+        }
+        f32x4 pv[2], ds[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qt * 32 + j * 16 + g * 4 + r;
+                const bool ok = (q < S) && (key <= q) && (key >= kvs) && (key < S);
+                const int qc = q < S ? q : S - 1;
+                const float pe = ok ? exp2f(s[j][r] * p.scale2 - lse2[qc]) : 0.f;
+                pv[j][r] = pe;
+                ds[j][r] = pe * (dp[j][r] - dsum[qc]);
+            }
+        const bf16x8 pfrag = pack_frag(pv[0], pv[1]);
+        const bf16x8 dsfrag = pack_frag(ds[0], ds[1]);
+        // ---- dV^T += dO^T P ; dK^T += Q^T dS   (k = the 32 queries, permuted as pack_frag lays them)
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            const bf16x8 dot_ = frag_tr(sdo, 0, 16, dt * 16, lane);
+            const bf16x8 qt_ = frag_tr(sq, 0, 16, dt * 16, lane);
+            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_, pfrag, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsfrag, dk[dt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (key < S) {
+        bf16_t* kp = p.dqkv + ((long)b * S + key) * ld + p.H * HD + h * HD + g * 4;
+        bf16_t* vp = p.dqkv + ((long)b * S + key) * ld + 2 * p.H * HD + h * HD + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            u32x2 wk = {pack2bf(dk[dt][0] * p.scale, dk[dt][1] * p.scale), pack2bf(dk[dt][2] * p.scale, dk[dt][3] * p.scale)};
+            u32x2 wv = {pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3])};
+            *(u32x2*)(kp + dt * 16) = wk;
+            *(u32x2*)(vp + dt * 16) = wv;
+        }
+    }
+}
+
+// =========================================================================== backward dQ
+// grid (ceil(S/64), B*H), 256 threads: wave w owns queries q0 + w*16 .. +15; walks key tiles of 64.
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
+    constexpr int TILE = 64 * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int S = p.S, ld = p.ld;
+    const int q0 = blockIdx.x * 64;
+    const int kvs = p.kv_start[b];
+    const int qi = lane & 15, g = lane >> 4;
+    const int q = q0 + wave * 16 + qi;
+    const int ql = q < S ? q : S - 1;
+    const bf16_t* base = p.qkv + (long)b * S * ld;
+    const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, span);
+    const int od = p.H * HD;
+    const int kcol = p.H * HD + h * HD, vcol = 2 * p.H * HD + h * HD;
+
+    bf16x8 qf[4], dof[4];
+    {
+        const bf16_t* qp = base + (long)ql * ld + h * HD + g * 8;
+        const bf16_t* dp_ = p.dout + ((long)b * S + ql) * od + h * HD + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            qf[kk] = *(const bf16x8*)(qp + kk * 32);
+            dof[kk] = *(const bf16x8*)(dp_ + kk * 32);
+        }
+    }
+    const float my_lse = p.lse2[((long)b * p.H + h) * S + ql];
+    const float my_ds = p.dsum[((long)b * p.H + h) * S + ql];
+    f32x4 dq[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int q_hi = (q0 + 63 < S - 1) ? q0 + 63 : S - 1;
+    const int kt_beg = kvs / 64, kt_end = q_hi / 64;
+    if (kt_beg <= kt_end) {
+        auto stage = [&](int kt, int buf) {
+            stage_rows<64, 256>(rs, smem + buf * 2 * TILE, kt * 64, kcol, ld, tid);
+            stage_rows<64, 256>(rs, smem + buf * 2 * TILE + TILE, kt * 64, vcol, ld, tid);
+        };
+        stage(kt_beg, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt_beg; kt <= kt_end; ++kt) {
+            if (kt < kt_end) stage(kt + 1, cur ^ 1);
+            LDS_PTR(char) sk = smem + cur * 2 * TILE;
+            LDS_PTR(char) sv = sk + TILE;
+            f32x4 s[4], dp[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x8 ka = frag_rm(sk, i * 16, kk, lane);
+                    const bf16x8 va = frag_rm(sv, i * 16, kk, lane);
+                    s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[kk], s[i], 0, 0, 0);
+                    dp[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[kk], dp[i], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt * 64 + i * 16 + g * 4 + r;
+                    const bool ok = (q < S) && (key <= q) && (key >= kvs);
+                    const float pe = ok ? exp2f(s[i][r] * p.scale2 - my_lse) : 0.f;
+                    s[i][r] = pe * (dp[i][r] - my_ds);   // dS^T
+                }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const bf16x8 dsf = pack_frag(s[2 * a], s[2 * a + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    const bf16x8 kt_ = frag_tr(sk, a * 32, a * 32 + 16, dt * 16, lane);
+                    dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsf, dq[dt], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    if (q < S) {
+        bf16_t* qp = p.dqkv + ((long)b * S + q) * ld + h * HD + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            u32x2 w = {pack2bf(dq[dt][0] * p.scale, dq[dt][1] * p.scale), pack2bf(dq[dt][2] * p.scale, dq[dt][3] * p.scale)};
+            *(u32x2*)(qp + dt * 16) = w;
+        }
+    }
+}
+
+int set_lds(const void* fn, int bytes) {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? NV_OK : NV_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, int B, int S, int H, int head_dim,
+                     void* stream) {
+    if (!qkv || !out || !lse2 || !kv_start) return NV_ERR_ARG;
+    if (head_dim != HD) return NV_ERR_SHAPE;
+    if (B == 0 || S == 0) return NV_OK;
+    static bool once = false;
+    if (!once) { if (set_lds((const void*)attn_fwd_kernel, 65536)) return NV_ERR_LAUNCH; once = true; }
+    AttnArgs p{};
+    p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = kv_start;
+    p.B = B; p.S = S; p.H = H; p.ld = 3 * H * HD;
+    p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + 127) / 128, B * H), dim3(256), 65536, (hipStream_t)stream, p);
+    return nv_check_launch();
+}
+
+// dsum: workspace [B,H,S] fp32 (nv_attn_bwd_workspace_bytes)
+size_t nv_attn_bwd_workspace_bytes(int B, int S, int H) { return (size_t)B * S * H * sizeof(float); }
+
+int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
+                     void* workspace, int B, int S, int H, int head_dim, void* stream) {
+    if (!qkv || !out || !dout || !lse2 || !kv_start || !dqkv || !workspace) return NV_ERR_ARG;
+    if (head_dim != HD) return NV_ERR_SHAPE;
+    if (B == 0 || S == 0) return NV_OK;
+    static bool once = false;
+    if (!once) {
+        if (set_lds((const void*)attn_bwd_dkv_kernel, 32768) || set_lds((const void*)attn_bwd_dq_kernel, 65536))
+            return NV_ERR_LAUNCH;
+        once = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* dsum = (float*)workspace;
+    const long items = (long)B * S * H;
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const bf16_t*)dout,
+                       (const bf16_t*)out, dsum, B, S, H);
+    AttnArgs p{};
+    p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.lse2 = (float*)lse2; p.dsum = dsum; p.dqkv = (bf16_t*)dqkv;
+    p.kv_start = kv_start; p.B = B; p.S = S; p.H = H; p.ld = 3 * H * HD;
+    p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((S + 63) / 64, B * H), dim3(256), 32768, st, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((S + 63) / 64, B * H), dim3(256), 65536, st, p);
+    return nv_check_launch();
+}
+
+}  // extern "C"

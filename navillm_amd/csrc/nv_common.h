@@ -1,0 +1,96 @@
+// Shared device helpers for the NaviLLM gfx950 kernels (CDNA4 only; no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NV_OK 0
+#define NV_ERR_ARG (-1)
+#define NV_ERR_SHAPE (-2)
+#define NV_ERR_LAUNCH (-3)
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(T) __attribute__((address_space(3))) T*
+#define GLB_PTR(T) __attribute__((address_space(1))) T*
+
+// ---- bf16 <-> f32, round-to-nearest-even (matches torch's CPU/GPU conversions) ----
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+// round a float to bf16 precision and widen back (a "rounding point")
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---- buffer resource (bounds-checked, OOB loads return 0) ----
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)bytes, 0x00020000);
+}
+
+// ---- wave reductions (wave = 64) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block reductions for blockDim.x = 64*NW threads; `red` must hold >= NW floats.
+// The broadcast result is returned to every thread.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    if (NW == 1) return v;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    if (NW == 1) return v;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// XCD-aware, bijective block-id remap (8 XCDs, block b runs on XCD b%8): give each XCD a
+// contiguous chunk of tile ids so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+static inline int nv_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? NV_OK : NV_ERR_LAUNCH;
+}

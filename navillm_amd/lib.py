@@ -1,0 +1,89 @@
+"""ctypes binding of libnavillm_hip.so -- the ONLY way the package reaches the GPU kernels.
+
+There is no fallback: if the library is missing or a symbol declared in include/navillm_hip.h is
+not exported, importing/using the product path raises.  (The CPU oracle lives in oracle/ and is
+never imported from here.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnavillm_hip.so")
+
+vp = ip = fp = lp = C.c_void_p   # every device pointer travels as void*
+i, f, l, sz = C.c_int, C.c_float, C.c_long, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/navillm_hip.h one to one
+SIGNATURES = {
+    "nv_gemm_bf16": (i, [i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp]),
+    "nv_embed_vis_bf16": (i, [vp, ip, ip, fp, vp, i, i, vp]),
+    "nv_vis_grad_f32": (i, [vp, ip, fp, i, i, vp]),
+    "nv_embed_grad_bf16": (i, [vp, ip, ip, ip, vp, i, i, vp]),
+    "nv_rmsnorm_fwd_bf16": (i, [vp, vp, vp, fp, i, i, f, vp]),
+    "nv_rmsnorm_bwd_workspace_bytes": (sz, [i]),
+    "nv_rmsnorm_bwd_bf16": (i, [vp, vp, vp, fp, vp, vp, vp, vp, i, i, vp]),
+    "nv_rope_bf16": (i, [vp, vp, vp, i, i, i, i, i, i, vp]),
+    "nv_swiglu_fwd_bf16": (i, [vp, vp, i, i, vp]),
+    "nv_swiglu_bwd_bf16": (i, [vp, vp, vp, i, i, vp]),
+    "nv_gather_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
+    "nv_scatter_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
+    "nv_attn_fwd_bf16": (i, [vp, vp, fp, ip, i, i, i, i, vp]),
+    "nv_attn_bwd_workspace_bytes": (sz, [i, i, i]),
+    "nv_attn_bwd_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, vp]),
+    "nv_head_fwd_bf16": (i, [vp, vp, vp, vp, i, i, i, vp]),
+    "nv_head_bwd_bf16": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
+    "nv_action_ce_bf16": (i, [vp, lp, fp, vp, i, i, f, vp]),
+    "nv_lm_ce_bf16": (i, [vp, ip, fp, i, i, i, i, i, f, i, vp]),
+    "nv_sumsq": (i, [vp, l, i, fp, C.POINTER(C.c_int), vp]),
+    "nv_clip_coef": (i, [fp, i, f, fp, vp]),
+    "nv_adamw": (i, [vp, vp, vp, vp, l, i, f, f, f, f, f, i, fp, vp]),
+    "nv_gemm_f32": (i, [i, fp, fp, fp, fp, i, i, i, i, i, i, i, vp]),
+    "nv_layernorm_fwd_f32": (i, [fp, fp, fp, fp, fp, fp, i, i, f, vp]),
+    "nv_layernorm_bwd_workspace_bytes": (sz, [i]),
+    "nv_layernorm_bwd_f32": (i, [fp, fp, fp, fp, fp, fp, fp, fp, vp, i, i, i, vp]),
+    "nv_colsum_f32": (i, [fp, fp, i, i, i, i, vp]),
+    "nv_mha_fwd_f32": (i, [fp, ip, fp, fp, i, i, i, i, vp]),
+    "nv_mha_bwd_f32": (i, [fp, fp, fp, fp, i, i, i, i, vp]),
+    "nv_gelu_fwd_f32": (i, [fp, fp, l, vp]),
+    "nv_gelu_bwd_f32": (i, [fp, fp, fp, l, vp]),
+    "nv_add_f32": (i, [fp, fp, fp, l, i, i, vp]),
+    "nv_rowscale_f32": (i, [fp, fp, fp, l, i, vp]),
+    "nv_gather_add_f32": (i, [fp, ip, fp, fp, l, i, vp]),
+    "nv_index_sum_f32": (i, [fp, ip, fp, i, i, i, i, vp]),
+    "nv_masked_mean_f32": (i, [fp, fp, fp, i, i, i, vp]),
+}
+
+_lib = None
+
+
+class NaviLLMHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and bind every declared symbol. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NaviLLMHipError(
+            f"{LIB_PATH} not found: build it with `python -m navillm_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NaviLLMHipError(f"libnavillm_hip.so does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "invalid argument", -2: "unsupported shape", -3: "launch failed"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NaviLLMHipError(f"{what} failed: {_ERR.get(rc, rc)}")

@@ -1,0 +1,348 @@
+"""Raw (non-autograd) tensor-level wrappers over the C ABI of libnavillm_hip.so.
+
+torch is used here only for device memory (tensors), the current HIP stream and shapes.
+Every function launches hand-written gfx950 kernels; nothing falls back to torch math.
+"""
+import ctypes
+import torch
+from . import lib as _lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+EPI_STORE, EPI_ACCUM, EPI_RESID, EPI_BIAS = 0, 1, 2, 3
+NT, NN, TN = 0, 1, 2
+
+
+def _L():
+    return _lib.load()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk2d(t, dt):
+    assert t.is_cuda and t.dtype == dt and t.dim() == 2 and t.stride(1) == 1, (t.shape, t.dtype, t.stride())
+
+
+# ------------------------------------------------------------------ bf16 GEMM
+def gemm_bf16(layout, A, B, out=None, R=None, epilogue=EPI_STORE, tile_cfg=0):
+    """C = Aop @ Bop^T (see include/navillm_hip.h). A, B, out, R: 2-D bf16, unit inner stride."""
+    _chk2d(A, BF16)
+    _chk2d(B, BF16)
+    if layout == NT:
+        M, K = A.shape
+        N, K2 = B.shape
+    elif layout == NN:
+        M, K = A.shape
+        K2, N = B.shape
+    else:
+        K, M = A.shape
+        K2, N = B.shape
+    assert K == K2, (A.shape, B.shape, layout)
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=A.device)
+    _chk2d(out, BF16)
+    assert tuple(out.shape) == (M, N)
+    ldr = 0
+    if epilogue == EPI_RESID:
+        _chk2d(R, BF16)
+        ldr = R.stride(0)
+    rc = _L().nv_gemm_bf16(layout, A.data_ptr(), B.data_ptr(), out.data_ptr(), _p(R), M, N, K, A.stride(0), B.stride(0),
+                           out.stride(0), ldr, epilogue, tile_cfg, _st())
+    _lib.check(rc, "nv_gemm_bf16")
+    return out
+
+
+# ------------------------------------------------------------------ LM row ops
+def embed_vis(table, ids_i32, vis_idx_i32, vis_f32, out=None):
+    M, d = ids_i32.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty((M, d), dtype=BF16, device=table.device)
+    rc = _L().nv_embed_vis_bf16(table.data_ptr(), ids_i32.data_ptr(), vis_idx_i32.data_ptr(), _p(vis_f32), out.data_ptr(), M, d,
+                                _st())
+    _lib.check(rc, "nv_embed_vis_bf16")
+    return out
+
+
+def vis_grad(dE, vis_rows_i32):
+    n, d = vis_rows_i32.numel(), dE.shape[1]
+    out = torch.empty((n, d), dtype=F32, device=dE.device)
+    _lib.check(_L().nv_vis_grad_f32(dE.data_ptr(), vis_rows_i32.data_ptr(), out.data_ptr(), n, d, _st()), "nv_vis_grad_f32")
+    return out
+
+
+def embed_grad(dE, uniq_i32, seg_off_i32, tok_i32, gtable):
+    _lib.check(_L().nv_embed_grad_bf16(dE.data_ptr(), uniq_i32.data_ptr(), seg_off_i32.data_ptr(), tok_i32.data_ptr(),
+                                       gtable.data_ptr(), uniq_i32.numel(), dE.shape[1], _st()), "nv_embed_grad_bf16")
+
+
+def rmsnorm_fwd(x, w, eps, out=None, rstd=None):
+    M, d = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    if rstd is None:
+        rstd = torch.empty((M,), dtype=F32, device=x.device)
+    _lib.check(_L().nv_rmsnorm_fwd_bf16(x.data_ptr(), w.data_ptr(), out.data_ptr(), rstd.data_ptr(), M, d, eps, _st()),
+               "nv_rmsnorm_fwd_bf16")
+    return out, rstd
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag):
+    key = (tag, str(device))
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def rmsnorm_bwd(dy, x, w, rstd, gw, resid_grad=None, out=None):
+    """dx (+ resid_grad) ; weight gradient accumulated into gw (bf16)."""
+    M, d = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    ws = _workspace(_L().nv_rmsnorm_bwd_workspace_bytes(d), x.device, "rms")
+    rc = _L().nv_rmsnorm_bwd_bf16(dy.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(resid_grad), out.data_ptr(),
+                                  gw.data_ptr(), ws.data_ptr(), M, d, _st())
+    _lib.check(rc, "nv_rmsnorm_bwd_bf16")
+    return out
+
+
+def rope_(qkv, cos_t, sin_t, S, H, hd, backward=False):
+    M = qkv.shape[0]
+    _lib.check(_L().nv_rope_bf16(qkv.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), M, S, H, hd, qkv.stride(0),
+                                 1 if backward else 0, _st()), "nv_rope_bf16")
+    return qkv
+
+
+def swiglu_fwd(gu, out=None):
+    M, ff2 = gu.shape
+    if out is None:
+        out = torch.empty((M, ff2 // 2), dtype=BF16, device=gu.device)
+    _lib.check(_L().nv_swiglu_fwd_bf16(gu.data_ptr(), out.data_ptr(), M, ff2 // 2, _st()), "nv_swiglu_fwd_bf16")
+    return out
+
+
+def swiglu_bwd(gu, dh, out=None):
+    M, ff2 = gu.shape
+    if out is None:
+        out = torch.empty_like(gu)
+    _lib.check(_L().nv_swiglu_bwd_bf16(gu.data_ptr(), dh.data_ptr(), out.data_ptr(), M, ff2 // 2, _st()), "nv_swiglu_bwd_bf16")
+    return out
+
+
+def gather_rows_bf16(src, rows_i32):
+    n, d = rows_i32.numel(), src.shape[1]
+    out = torch.empty((n, d), dtype=BF16, device=src.device)
+    _lib.check(_L().nv_gather_rows_bf16(src.data_ptr(), rows_i32.data_ptr(), out.data_ptr(), n, d, _st()), "nv_gather_rows_bf16")
+    return out
+
+
+def scatter_rows_bf16_(src, rows_i32, dst):
+    _lib.check(_L().nv_scatter_rows_bf16(src.data_ptr(), rows_i32.data_ptr(), dst.data_ptr(), rows_i32.numel(), src.shape[1],
+                                         _st()), "nv_scatter_rows_bf16")
+    return dst
+
+
+# ------------------------------------------------------------------ attention
+def attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=None, lse2=None):
+    if out is None:
+        out = torch.empty((B * S, H * hd), dtype=BF16, device=qkv.device)
+    if lse2 is None:
+        lse2 = torch.empty((B, H, S), dtype=F32, device=qkv.device)
+    rc = _L().nv_attn_fwd_bf16(qkv.data_ptr(), out.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(), B, S, H, hd, _st())
+    _lib.check(rc, "nv_attn_fwd_bf16")
+    return out, lse2
+
+
+def attn_bwd(qkv, out, dout, lse2, kv_start_i32, B, S, H, hd, dqkv=None):
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    ws = _workspace(_L().nv_attn_bwd_workspace_bytes(B, S, H), qkv.device, "attn")
+    rc = _L().nv_attn_bwd_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(),
+                               dqkv.data_ptr(), ws.data_ptr(), B, S, H, hd, _st())
+    _lib.check(rc, "nv_attn_bwd_bf16")
+    return dqkv
+
+
+# ------------------------------------------------------------------ heads / losses / optimizer
+def head_fwd(x, W, bias):
+    B, d = x.shape
+    N = W.shape[0]
+    y = torch.empty((B, N), dtype=BF16, device=x.device)
+    _lib.check(_L().nv_head_fwd_bf16(x.data_ptr(), W.data_ptr(), bias.data_ptr(), y.data_ptr(), B, d, N, _st()), "nv_head_fwd_bf16")
+    return y
+
+
+def head_bwd(dy, x, W, gW, gb):
+    B, d = x.shape
+    N = W.shape[0]
+    dx = torch.empty_like(x)
+    _lib.check(_L().nv_head_bwd_bf16(dy.data_ptr(), x.data_ptr(), W.data_ptr(), dx.data_ptr(), gW.data_ptr(), gb.data_ptr(), B, d,
+                                     N, _st()), "nv_head_bwd_bf16")
+    return dx
+
+
+def action_ce(logits, targets_i64, gscale=1.0, want_grad=True):
+    B, G = logits.shape
+    logits = logits.contiguous()
+    loss_rows = torch.empty((B,), dtype=F32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    _lib.check(_L().nv_action_ce_bf16(logits.data_ptr(), targets_i64.data_ptr(), loss_rows.data_ptr(), _p(dl), B, G, gscale,
+                                      _st()), "nv_action_ce_bf16")
+    return loss_rows, dl
+
+
+def lm_ce_(logits, labels_i32, V, special0, nspecial, gscale, write_grad=True):
+    M = logits.shape[0]
+    loss_rows = torch.empty((M,), dtype=F32, device=logits.device)
+    _lib.check(_L().nv_lm_ce_bf16(logits.data_ptr(), labels_i32.data_ptr(), loss_rows.data_ptr(), M, V, logits.stride(0), special0,
+                                  nspecial, gscale, 1 if write_grad else 0, _st()), "nv_lm_ce_bf16")
+    return loss_rows
+
+
+def clip_coef(flat_grads, max_norm, out2=None):
+    """flat_grads: list of 1-D bf16/fp32 tensors. Returns device tensor [total_norm, coef]."""
+    dev = flat_grads[0].device
+    part = _workspace(4 * 2048 * 8 * len(flat_grads), dev, "sumsq").view(torch.float32)
+    off = 0
+    for g in flat_grads:
+        n = ctypes.c_int(0)
+        _lib.check(_L().nv_sumsq(g.data_ptr(), g.numel(), 1 if g.dtype == BF16 else 0, part[off:].data_ptr(), ctypes.byref(n),
+                                 _st()), "nv_sumsq")
+        off += n.value
+    if out2 is None:
+        out2 = torch.empty((2,), dtype=F32, device=dev)
+    _lib.check(_L().nv_clip_coef(part.data_ptr(), off, float(max_norm), out2.data_ptr(), _st()), "nv_clip_coef")
+    return out2
+
+
+def adamw_(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01, clip=None):
+    _lib.check(_L().nv_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 1 if p.dtype == BF16 else 0, lr,
+                             beta1, beta2, eps, wd, step, _p(clip), _st()), "nv_adamw")
+
+
+# ------------------------------------------------------------------ fp32 encoder ops
+def gemm_f32(layout, A, B, bias=None, out=None, accumulate=False):
+    _chk2d(A, F32)
+    _chk2d(B, F32)
+    if layout == NT:
+        M, K = A.shape
+        N, K2 = B.shape
+    elif layout == NN:
+        M, K = A.shape
+        K2, N = B.shape
+    else:
+        K, M = A.shape
+        K2, N = B.shape
+    assert K == K2
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, N), dtype=F32, device=A.device)
+    rc = _L().nv_gemm_f32(layout, A.data_ptr(), B.data_ptr(), out.data_ptr(), _p(bias), M, N, K, A.stride(0), B.stride(0),
+                          out.stride(0), 1 if accumulate else 0, _st())
+    _lib.check(rc, "nv_gemm_f32")
+    return out
+
+
+def layernorm_fwd(x, w, b, eps):
+    M, d = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty((M,), dtype=F32, device=x.device)
+    rstd = torch.empty((M,), dtype=F32, device=x.device)
+    _lib.check(_L().nv_layernorm_fwd_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                         M, d, eps, _st()), "nv_layernorm_fwd_f32")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd):
+    M, d = x.shape
+    dx = torch.empty_like(x)
+    gw = torch.empty((d,), dtype=F32, device=x.device)
+    gb = torch.empty((d,), dtype=F32, device=x.device)
+    ws = _workspace(_L().nv_layernorm_bwd_workspace_bytes(d), x.device, "ln")
+    _lib.check(_L().nv_layernorm_bwd_f32(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                                         gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), M, d, 0, _st()), "nv_layernorm_bwd_f32")
+    return dx, gw, gb
+
+
+def colsum_f32(x):
+    M, d = x.shape
+    out = torch.empty((d,), dtype=F32, device=x.device)
+    _lib.check(_L().nv_colsum_f32(x.data_ptr(), out.data_ptr(), M, d, x.stride(0), 0, _st()), "nv_colsum_f32")
+    return out
+
+
+def mha_fwd(qkv, lens_i32, B, N, heads, hd):
+    h = heads * hd
+    out = torch.empty((B * N, h), dtype=F32, device=qkv.device)
+    P = torch.empty((B, heads, N, N), dtype=F32, device=qkv.device)
+    _lib.check(_L().nv_mha_fwd_f32(qkv.data_ptr(), lens_i32.data_ptr(), out.data_ptr(), P.data_ptr(), B, N, heads, hd, _st()),
+               "nv_mha_fwd_f32")
+    return out, P
+
+
+def mha_bwd(qkv, P, dout, B, N, heads, hd):
+    dqkv = torch.empty_like(qkv)
+    _lib.check(_L().nv_mha_bwd_f32(qkv.data_ptr(), P.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, N, heads, hd, _st()),
+               "nv_mha_bwd_f32")
+    return dqkv
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    _lib.check(_L().nv_gelu_fwd_f32(x.data_ptr(), y.data_ptr(), x.numel(), _st()), "nv_gelu_fwd_f32")
+    return y
+
+
+def gelu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    _lib.check(_L().nv_gelu_bwd_f32(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _st()), "nv_gelu_bwd_f32")
+    return dx
+
+
+def add_f32(a, b, bcast_rows=False):
+    out = torch.empty_like(a)
+    d = a.shape[-1]
+    _lib.check(_L().nv_add_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), d, 1 if bcast_rows else 0, _st()), "nv_add_f32")
+    return out
+
+
+def rowscale_f32(x, s):
+    """x [rows, d] * s [rows] (fp32 0/1 masks)."""
+    out = torch.empty_like(x)
+    d = x.shape[-1]
+    _lib.check(_L().nv_rowscale_f32(x.data_ptr(), s.data_ptr(), out.data_ptr(), x.numel() // d, d, _st()), "nv_rowscale_f32")
+    return out
+
+
+def gather_add_f32(src, idx_i32, base=None):
+    """out[i] = (src[idx[i]] if idx[i] >= 0 else 0) (+ base[i])."""
+    rows, d = idx_i32.numel(), src.shape[-1]
+    out = torch.empty((rows, d), dtype=F32, device=src.device)
+    _lib.check(_L().nv_gather_add_f32(src.data_ptr(), idx_i32.data_ptr(), _p(base), out.data_ptr(), rows, d, _st()),
+               "nv_gather_add_f32")
+    return out
+
+
+def index_sum_f32(src, idx_i32, R):
+    """dst[r] = sum_{i: idx[i]==r} src[i]  for r < R."""
+    n, d = src.shape
+    dst = torch.empty((R, d), dtype=F32, device=src.device)
+    _lib.check(_L().nv_index_sum_f32(src.data_ptr(), idx_i32.data_ptr(), dst.data_ptr(), n, R, d, 0, _st()), "nv_index_sum_f32")
+    return dst
+
+
+def masked_mean_f32(x, mask_f32):
+    B, N, d = x.shape
+    out = torch.empty((B, d), dtype=F32, device=x.device)
+    _lib.check(_L().nv_masked_mean_f32(x.data_ptr(), mask_f32.data_ptr(), out.data_ptr(), B, N, d, _st()), "nv_masked_mean_f32")
+    return out

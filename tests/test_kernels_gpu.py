@@ -1,0 +1,405 @@
+"""GPU: every C-ABI kernel against a plain PyTorch fp32 restatement of the same op (per-kernel
+numerics).  The end-to-end parity against the oracle / golden vectors is in test_parity_gpu.py.
+Tolerances: fp32 kernels 1e-4 relative to the tensor scale (MFMA f32 is an exact fmaf chain,
+only summation order differs); bf16 kernels one bf16 rounding of the result (2^-8 relative)
+plus accumulate-order noise."""
+import math
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF, F32 = torch.bfloat16, torch.float32
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, dtype=F32, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).to(dev())
+
+
+def assert_close(got, ref, rtol, atol_scale, what):
+    got, ref = got.float(), ref.float()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{what}: non-finite output"
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs()
+    tol = rtol * ref.abs() + atol_scale * scale
+    bad = err > tol
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} bad; max err {err.max().item():.4e} "
+                             f"(scale {scale:.3e}); first bad at {idx}: got {got[tuple(idx)].item():.6f} "
+                             f"ref {ref[tuple(idx)].item():.6f}")
+
+
+# ------------------------------------------------------------------------------ bf16 GEMM
+@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 192), (77, 520, 64), (1000, 384, 448)])
+def test_gemm_bf16_layouts(layout, tile, M, N, K):
+    from navillm_amd import ops
+    if layout == 2:
+        Kc = K + 37          # wgrad: ragged contraction length
+        A = rnd(Kc, (M + 7) // 8 * 8 + 8, dtype=BF, seed=1)[:, :M]     # strided views (ld != cols)
+        B = rnd(Kc, N + 16, dtype=BF, seed=2)[:, :N]
+        ref = A.float().t() @ B.float()
+    elif layout == 1:
+        A = rnd(M, K + 8, dtype=BF, seed=3)[:, :K]
+        B = rnd(K, N, dtype=BF, seed=4)
+        ref = A.float() @ B.float()
+    else:
+        A = rnd(M, K, dtype=BF, seed=5)
+        B = rnd(N, K + 64, dtype=BF, seed=6)[:, :K]
+        ref = A.float() @ B.float().t()
+    out = ops.gemm_bf16(layout, A, B, tile_cfg=tile)
+    torch.cuda.synchronize()
+    assert_close(out, ref, 2 ** -7, 2e-3, f"gemm layout={layout} tile={tile} {M}x{N}x{K}")
+
+
+def test_gemm_bf16_epilogues():
+    from navillm_amd import ops
+    M, N, K = 200, 328, 128
+    A, B = rnd(M, K, dtype=BF, seed=7), rnd(N, K, dtype=BF, seed=8)
+    acc = A.float() @ B.float().t()
+    R = rnd(M, N, dtype=BF, seed=9)
+    out = ops.gemm_bf16(0, A, B, R=R, epilogue=ops.EPI_RESID)
+    assert_close(out, R.float() + acc.to(BF).float(), 2 ** -7, 2e-3, "resid")
+    C0 = rnd(M, N, dtype=BF, seed=10)
+    C = C0.clone()
+    ops.gemm_bf16(0, A, B, out=C, epilogue=ops.EPI_ACCUM)
+    assert_close(C, C0.float() + acc.to(BF).float(), 2 ** -7, 2e-3, "accum")
+    bias = rnd(N, dtype=BF, seed=11)
+    out = ops.gemm_bf16(0, A, B, R=bias.view(1, N), epilogue=ops.EPI_BIAS)
+    assert_close(out, acc + bias.float(), 2 ** -7, 2e-3, "bias")
+
+
+def test_gemm_bf16_large_llama_shapes():
+    from navillm_amd import ops
+    M = 1500
+    for (N, K) in ((4096, 4096), (2048, 11008)):
+        A, B = rnd(M, K, dtype=BF, scale=0.5, seed=12), rnd(N, K, dtype=BF, scale=0.05, seed=13)
+        out = ops.gemm_bf16(0, A, B)
+        ref = A.float() @ B.float().t()
+        assert_close(out, ref, 2 ** -7, 2e-3, f"llama NT {N}x{K}")
+        dY = rnd(M, N, dtype=BF, seed=14)
+        dx = ops.gemm_bf16(1, dY, B)
+        assert_close(dx, dY.float() @ B.float(), 2 ** -7, 2e-3, f"llama NN {N}x{K}")
+        dW = ops.gemm_bf16(2, dY, A)
+        assert_close(dW, dY.float().t() @ A.float(), 2 ** -7, 2e-3, f"llama TN {N}x{K}")
+
+
+# ------------------------------------------------------------------------------ row ops
+def test_embed_vis_and_grads():
+    from navillm_amd import ops
+    V, d, M = 50, 256, 40
+    table = rnd(V, d, dtype=BF, seed=20)
+    ids = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(1)).int().to(dev())
+    vis_idx = torch.full((M,), -1, dtype=torch.int32)
+    vis_rows = [3, 7, 8, 30]
+    for i, r in enumerate(vis_rows):
+        vis_idx[r] = i
+    vis_idx = vis_idx.to(dev())
+    vis = rnd(len(vis_rows), d, seed=21)
+    out = ops.embed_vis(table, ids, vis_idx, vis)
+    ref = table[ids.long()].float()
+    ref[vis_rows] = ref[vis_rows] + vis
+    assert torch.equal(out, ref.to(BF)), "embed_vis must be bit exact"
+    dE = rnd(M, d, dtype=BF, seed=22)
+    dv = ops.vis_grad(dE, torch.tensor(vis_rows, dtype=torch.int32, device=dev()))
+    assert torch.equal(dv, dE[vis_rows].float())
+    # table grad
+    idl = ids.cpu().long()
+    order = torch.argsort(idl, stable=True)
+    uniq, counts = torch.unique_consecutive(idl[order], return_counts=True)
+    seg = torch.zeros(len(uniq) + 1, dtype=torch.int32)
+    seg[1:] = torch.cumsum(counts, 0)
+    g0 = rnd(V, d, dtype=BF, seed=23)
+    g = g0.clone()
+    ops.embed_grad(dE, uniq.int().to(dev()), seg.to(dev()), order.int().to(dev()), g)
+    ref = torch.zeros(V, d, device=dev())
+    ref.index_add_(0, ids.long(), dE.float())
+    assert_close(g, g0.float() + ref.to(BF).float(), 2 ** -7, 1e-3, "embed_grad")
+
+
+def _rms_ref(x, w, eps):
+    xf = x.float()
+    rstd = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + eps)
+    return (w.float() * (xf * rstd).to(BF).float()).to(BF), rstd.squeeze(-1)
+
+
+@pytest.mark.parametrize("M,d", [(37, 256), (300, 4096), (600, 5120)])
+def test_rmsnorm_fwd_bwd(M, d):
+    from navillm_amd import ops
+    x = rnd(M, d, dtype=BF, seed=30)
+    w = (1 + 0.1 * torch.randn(d)).to(BF).to(dev())
+    y, rstd = ops.rmsnorm_fwd(x, w, 1e-6)
+    yr, rr = _rms_ref(x, w, 1e-6)
+    assert_close(rstd, rr, 1e-5, 1e-6, "rstd")
+    assert_close(y, yr, 2 ** -7, 1e-6, "rmsnorm y")
+    # backward vs autograd of the fp32 formula
+    dy = rnd(M, d, dtype=BF, seed=31)
+    rg = rnd(M, d, dtype=BF, seed=32)
+    xf = x.float().requires_grad_(True)
+    wf = w.float().requires_grad_(True)
+    out = wf * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
+    out.backward(dy.float())
+    gw0 = rnd(d, dtype=BF, seed=33, scale=0.1)
+    gw = gw0.clone()
+    dx = ops.rmsnorm_bwd(dy, x, w, rstd, gw, resid_grad=rg)
+    assert_close(dx, rg.float() + xf.grad, 2 ** -6, 4e-3, "rmsnorm dx")
+    assert_close(gw, gw0.float() + wf.grad, 2 ** -6, 4e-3, "rmsnorm dw")
+
+
+def test_rope_fwd_bwd():
+    from navillm_amd import ops
+    B, S, H, hd = 2, 50, 2, 128
+    M, d = B * S, H * hd
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(S).float(), inv)
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos().to(BF).to(dev()), emb.sin().to(BF).to(dev())
+    qkv = rnd(M, 3 * d, dtype=BF, seed=40)
+
+    def ref(t, sign):
+        x = t.view(B, S, 3, H, hd).clone()
+        c, s = cos.view(1, S, 1, hd), sin.view(1, S, 1, hd)
+        for part in (0, 1):
+            q = x[:, :, part]
+            rot = torch.cat([-q[..., hd // 2:], q[..., :hd // 2]], -1) if sign > 0 else \
+                torch.cat([q[..., hd // 2:], -q[..., :hd // 2]], -1)
+            x[:, :, part] = q * c + rot * s
+        return x.view(M, 3 * d)
+    out = ops.rope_(qkv.clone(), cos, sin, S, H, hd)
+    assert torch.equal(out, ref(qkv, 1)), "rope fwd must match torch bf16 eager bit for bit"
+    outb = ops.rope_(qkv.clone(), cos, sin, S, H, hd, backward=True)
+    assert torch.equal(outb, ref(qkv, -1)), "rope bwd"
+
+
+def test_swiglu_fwd_bwd():
+    from navillm_amd import ops
+    M, ff = 123, 1408
+    gu = rnd(M, 2 * ff, dtype=BF, seed=50, scale=2.0)
+    h = ops.swiglu_fwd(gu)
+    g, u = gu[:, :ff], gu[:, ff:]
+    ref = torch.nn.functional.silu(g) * u
+    assert_close(h, ref, 2 ** -7, 1e-6, "swiglu fwd")
+    dh = rnd(M, ff, dtype=BF, seed=51)
+    gf = g.float().requires_grad_(True)
+    uf = u.float().requires_grad_(True)
+    (torch.nn.functional.silu(gf) * uf).backward(dh.float())
+    dgu = ops.swiglu_bwd(gu, dh)
+    assert_close(dgu[:, :ff], gf.grad, 2 ** -6, 1e-5, "swiglu dg")
+    assert_close(dgu[:, ff:], uf.grad, 2 ** -6, 1e-5, "swiglu du")
+
+
+# ------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, B, S, H, hd, kv_start):
+    x = qkv.float().view(B, S, 3, H, hd)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))      # [B,H,S,hd]
+    s = q @ k.transpose(-1, -2) / math.sqrt(hd)
+    pos = torch.arange(S, device=qkv.device)
+    ok = (pos[None, :] <= pos[:, None])[None] & (pos[None, None, :] >= kv_start.view(B, 1, 1).long())
+    s = s.masked_fill(~ok[:, None], float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    o = (p @ v).transpose(1, 2).reshape(B * S, H * hd)
+    return o, ok
+
+
+@pytest.mark.parametrize("B,S,H,pads", [(2, 200, 2, [0, 37]), (1, 64, 1, [0]), (3, 333, 2, [5, 130, 0]), (2, 700, 4, [0, 64])])
+def test_attention_fwd_bwd(B, S, H, pads):
+    from navillm_amd import ops
+    hd = 128
+    qkv = rnd(B * S, 3 * H * hd, dtype=BF, seed=60, scale=1.0)
+    kvs = torch.tensor(pads, dtype=torch.int32, device=dev())
+    out, lse2 = ops.attn_fwd(qkv, kvs, B, S, H, hd)
+    torch.cuda.synchronize()
+    qf = qkv.float().requires_grad_(True)
+    ref, ok = _attn_ref(qf, B, S, H, hd, kvs)
+    real = (torch.arange(S, device=dev())[None] >= kvs[:, None].long()).reshape(-1)
+    assert_close(out[real], ref[real].detach(), 2 ** -6, 5e-3, "attn fwd")
+    assert bool((out[~real] == 0).all()), "pad query rows must be zero"
+    # backward
+    dout = rnd(B * S, H * hd, dtype=BF, seed=61)
+    dout[~real] = 0
+    (ref * dout.float()).sum().backward()
+    dqkv = ops.attn_bwd(qkv, out, dout, lse2, kvs, B, S, H, hd)
+    torch.cuda.synchronize()
+    g = qf.grad
+    d = H * hd
+    for name, sl in (("dq", slice(0, d)), ("dk", slice(d, 2 * d)), ("dv", slice(2 * d, 3 * d))):
+        got, want = dqkv[:, sl].float(), g[:, sl]
+        rel = (got - want).norm() / (want.norm() + 1e-20)
+        assert torch.isfinite(got).all() and rel < 2e-2, f"attn {name}: rel err {rel.item():.4e}"
+    # pad rows receive no gradient
+    assert bool((dqkv[~real].float().abs().max() == 0) if (~real).any() else True)
+
+
+# ------------------------------------------------------------------------------ heads / losses / optimizer
+def test_head_and_action_ce():
+    from navillm_amd import ops
+    B, d, N = 5, 512, 100
+    x, W, b = rnd(B, d, dtype=BF, seed=70), rnd(N, d, dtype=BF, seed=71, scale=0.05), rnd(N, dtype=BF, seed=72)
+    y = ops.head_fwd(x, W, b)
+    assert_close(y, x.float() @ W.float().t() + b.float(), 2 ** -7, 1e-3, "head fwd")
+    dy = rnd(B, N, dtype=BF, seed=73)
+    gW0, gb0 = rnd(N, d, dtype=BF, seed=74), rnd(N, dtype=BF, seed=75)
+    gW, gb = gW0.clone(), gb0.clone()
+    dx = ops.head_bwd(dy, x, W, gW, gb)
+    assert_close(dx, dy.float() @ W.float(), 2 ** -7, 1e-3, "head dx")
+    assert_close(gW, gW0.float() + (dy.float().t() @ x.float()).to(BF).float(), 2 ** -7, 2e-3, "head dW")
+    assert_close(gb, gb0.float() + dy.float().sum(0).to(BF).float(), 2 ** -7, 2e-3, "head db")
+    # action CE with -inf slots and an ignored row
+    G = 9
+    logits = rnd(B, G, dtype=BF, seed=76, scale=2.0)
+    logits[:, 6:] = float("-inf")
+    logits[1, 2] = float("-inf")
+    tg = torch.tensor([0, -100, 3, 5, 1], device=dev())
+    lf = logits.float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf, tg, ignore_index=-100, reduction="sum")
+    (ref * 0.25).backward()
+    rows, dl = ops.action_ce(logits, tg, gscale=0.25)
+    assert abs(rows.sum().item() - ref.item()) < 1e-4 * abs(ref.item()) + 1e-5
+    assert_close(dl, lf.grad, 2 ** -7, 1e-6, "action CE grad")
+
+
+def test_lm_ce():
+    from navillm_amd import ops
+    M, V, ldl = 13, 406, 408
+    special0 = 400
+    buf = rnd(M, ldl, dtype=BF, seed=80, scale=2.0)
+    labels = torch.randint(0, 400, (M,), generator=torch.Generator().manual_seed(5)).int()
+    labels[3] = -100
+    labels = labels.to(dev())
+    lf = buf[:, :V].float()
+    lf[:, special0:special0 + 5] = float("-inf")
+    lf.requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf, labels.long(), ignore_index=-100, reduction="sum")
+    (ref * 0.1).backward()
+    logits = buf.clone()
+    rows = ops.lm_ce_(logits, labels, V, special0, 5, 0.1)
+    assert abs(rows.sum().item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert_close(logits[:, :V], lf.grad, 2 ** -7, 1e-6, "lm CE grad")
+
+
+def test_clip_and_adamw_match_oracle_sequence():
+    import importlib.util, os
+    from navillm_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("navillm_oracle", os.path.join(root, "oracle", "navillm_oracle.py"))
+    O = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(O)
+    for dtype in (BF, F32):
+        n = 100003
+        p = rnd(n, dtype=dtype, seed=90, scale=0.05)
+        m = torch.zeros_like(p)
+        v = torch.zeros_like(p)
+        pc, mc, vc = p.cpu().clone(), m.cpu().clone(), v.cpu().clone()
+        for step in (1, 2, 3):
+            g = rnd(n, dtype=dtype, seed=91 + step, scale=1.0 if step == 2 else 0.01)
+            coef = ops.clip_coef([g], 40.0)
+            gc = g.cpu().clone()
+            total = O.clip_grad_norm_([gc], 40.0)
+            torch.cuda.synchronize()
+            assert abs(coef[0].item() - float(total)) < 5e-3 * float(total), (coef[0].item(), float(total))
+            ops.adamw_(p, g, m, v, step, 1e-3, clip=coef)
+            O.adamw_step_(pc, gc, mc, vc, step, 1e-3)
+            torch.cuda.synchronize()
+            # identical rounding sequence; the only slack is the clip coefficient's last bits
+            assert_close(p.cpu(), pc, 2 ** -7 if dtype == BF else 1e-5, 1e-6, f"adamw p {dtype} step {step}")
+            assert_close(m.cpu(), mc, 2 ** -7 if dtype == BF else 1e-5, 1e-6, f"adamw m {dtype} step {step}")
+            assert_close(v.cpu(), vc, 2 ** -7 if dtype == BF else 1e-5, 1e-7, f"adamw v {dtype} step {step}")
+
+
+# ------------------------------------------------------------------------------ fp32 encoder kernels
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(288, 1024, 768), (100, 130, 7), (36, 256, 64), (65, 129, 33)])
+def test_gemm_f32(layout, M, N, K):
+    from navillm_amd import ops
+    if layout == 0:
+        A, B = rnd(M, K, seed=100), rnd(N, K, seed=101)
+        ref = A.double() @ B.double().t()
+    elif layout == 1:
+        A, B = rnd(M, K, seed=102), rnd(K, N, seed=103)
+        ref = A.double() @ B.double()
+    else:
+        A, B = rnd(K, M, seed=104), rnd(K, N, seed=105)
+        ref = A.double().t() @ B.double()
+    bias = rnd(N, seed=106)
+    out = ops.gemm_f32(layout, A, B, bias=bias)
+    assert_close(out, (ref + bias.double()).float(), 1e-5, 2e-6, f"gemm_f32 layout {layout}")
+    acc = out.clone()
+    ops.gemm_f32(layout, A, B, out=acc, accumulate=True)
+    assert_close(acc, (2 * ref + bias.double()).float(), 1e-5, 4e-6, "gemm_f32 accumulate")
+
+
+@pytest.mark.parametrize("eps", [1e-12, 1e-5])
+def test_layernorm_f32(eps):
+    from navillm_amd import ops
+    M, d = 77, 1024
+    x, w, b = rnd(M, d, seed=110, scale=3.0), 1 + 0.1 * rnd(d, seed=111), rnd(d, seed=112)
+    y, mean, rstd = ops.layernorm_fwd(x, w, b, eps)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (d,), wr, br, eps)
+    assert_close(y, ref.detach(), 1e-5, 2e-6, "layernorm fwd")
+    dy = rnd(M, d, seed=113)
+    ref.backward(dy)
+    dx, gw, gb = ops.layernorm_bwd(dy, x, w, mean, rstd)
+    assert_close(dx, xr.grad, 1e-4, 5e-6, "layernorm dx")
+    assert_close(gw, wr.grad, 1e-4, 5e-6, "layernorm dgamma")
+    assert_close(gb, br.grad, 1e-4, 5e-6, "layernorm dbeta")
+
+
+@pytest.mark.parametrize("B,N,heads,hd,lens", [(3, 36, 16, 64, [36, 30, 1]), (2, 8, 4, 32, [8, 5])])
+def test_mha_f32(B, N, heads, hd, lens):
+    from navillm_amd import ops
+    h = heads * hd
+    qkv = rnd(B * N, 3 * h, seed=120)
+    ln = torch.tensor(lens, dtype=torch.int32, device=dev())
+    out, P = ops.mha_fwd(qkv, ln, B, N, heads, hd)
+    qr = qkv.clone().requires_grad_(True)
+    x = qr.view(B, N, 3, heads, hd)
+    q, k, v = (x[:, :, i].transpose(1, 2) for i in range(3))
+    s = (q / math.sqrt(hd)) @ k.transpose(-1, -2)
+    kp = torch.arange(N, device=dev())[None] >= ln[:, None].long()
+    s = s.masked_fill(kp[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * N, h)
+    assert_close(out, ref.detach(), 1e-5, 2e-6, "mha fwd")
+    dout = rnd(B * N, h, seed=121)
+    ref.backward(dout)
+    dqkv = ops.mha_bwd(qkv, P, dout, B, N, heads, hd)
+    assert_close(dqkv, qr.grad, 1e-4, 5e-6, "mha bwd")
+
+
+def test_small_f32_ops():
+    from navillm_amd import ops
+    x = rnd(50, 300, seed=130, scale=2.0)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.gelu(xr)
+    assert_close(ops.gelu_fwd(x), ref.detach(), 1e-5, 1e-6, "gelu")
+    dy = rnd(50, 300, seed=131)
+    ref.backward(dy)
+    assert_close(ops.gelu_bwd(x, dy), xr.grad, 1e-5, 1e-6, "gelu bwd")
+    y = rnd(50, 300, seed=132)
+    assert torch.equal(ops.add_f32(x, y), x + y)
+    b = rnd(300, seed=133)
+    assert torch.equal(ops.add_f32(x, b, bcast_rows=True), x + b)
+    s = (torch.arange(50, device=dev()) % 3 != 0).float()
+    assert torch.equal(ops.rowscale_f32(x, s), x * s[:, None])
+    idx = torch.tensor([3, -1, 0, 49, 3], dtype=torch.int32, device=dev())
+    base = rnd(5, 300, seed=134)
+    want = torch.where(idx[:, None] >= 0, x[idx.clamp(min=0).long()], torch.zeros(5, 300, device=dev())) + base
+    assert torch.equal(ops.gather_add_f32(x, idx, base), want)
+    ids = torch.randint(0, 3, (50,), generator=torch.Generator().manual_seed(2)).int().to(dev())
+    want = torch.zeros(3, 300, device=dev()).index_add_(0, ids.long(), x)
+    assert_close(ops.index_sum_f32(x, ids, 3), want, 1e-5, 1e-6, "index_sum")
+    assert_close(ops.colsum_f32(x), x.sum(0), 1e-5, 1e-6, "colsum")
+    xm = rnd(4, 36, 300, seed=135)
+    mk = (torch.arange(36, device=dev())[None] < torch.tensor([36, 20, 1, 30], device=dev())[:, None]).float()
+    want = (xm * mk[..., None]).sum(1) / mk.sum(1, keepdim=True)
+    assert_close(ops.masked_mean_f32(xm, mk), want, 1e-5, 1e-6, "masked mean")
