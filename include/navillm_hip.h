@@ -64,6 +64,7 @@ int nv_rope_bf16(void* qkv, const void* cos_t, const void* sin_t, int M, int S, 
 int nv_swiglu_fwd_bf16(const void* gu, void* h, int M, int ff, void* stream);
 int nv_swiglu_bwd_bf16(const void* gu, const void* dh, void* dgu, int M, int ff, void* stream);
 
+int nv_scale_bf16(const void* x, void* out, long n, float scale, void* stream);   /* n % 8 == 0 */
 int nv_gather_rows_bf16(const void* src, const int* rows, void* out, int n, int d, void* stream);
 int nv_scatter_rows_bf16(const void* src, const int* rows, void* dst, int n, int d, void* stream);
 
@@ -93,8 +94,8 @@ int nv_lm_ce_bf16(void* logits, const int* labels, float* loss_rows, int M, int 
 /* ---- K13: clip_grad_norm_(40) + AdamW on flat parameter buffers, train.py:86-89, tools/optims.py:43-45 */
 int nv_sumsq(const void* g, long n, int is_bf16, float* partial, int* n_partial_host, void* stream);
 int nv_clip_coef(const float* partial, int n_partial, float max_norm, float* out2, void* stream);
-int nv_adamw(void* p, const void* g, void* m, void* v, long n, int is_bf16, float lr, float beta1, float beta2, float eps,
-             float wd, int step, const float* clip_out2, void* stream);
+int nv_adamw(void* p, const void* g, void* m, void* v, long n, int is_bf16, double lr, double beta1, double beta2, double eps,
+             double wd, int step, const float* clip_out2, void* stream);
 
 /* ---- fp32 scene encoder + fusion (K1-K5, K12): models/image_embedding.py:51-121,
  *      models/detr_transformer.py:170-182, models/nav_model.py:146-194 */
@@ -112,6 +113,7 @@ int nv_mha_bwd_f32(const float* qkv, const float* P, const float* dout, float* d
 int nv_gelu_fwd_f32(const float* x, float* y, long n, void* stream);
 int nv_gelu_bwd_f32(const float* x, const float* dy, float* dx, long n, void* stream);
 int nv_add_f32(const float* a, const float* b, float* out, long n, int d, int b_bcast, void* stream);
+int nv_mul_f32(const float* a, const float* b, float* out, long n, void* stream);
 int nv_rowscale_f32(const float* x, const float* s, float* out, long rows, int d, void* stream);
 int nv_gather_add_f32(const float* src, const int* idx, const float* base, float* out, long rows, int d, void* stream);
 int nv_index_sum_f32(const float* src, const int* idx, float* dst, int n, int R, int d, int accumulate, void* stream);

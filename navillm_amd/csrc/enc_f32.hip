@@ -282,6 +282,11 @@ __global__ __launch_bounds__(256) void add_f32_kernel(const float* __restrict__ 
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L)
         out[i] = a[i] + (b_bcast ? b[i % d] : b[i]);
 }
+// out = a * b (elementwise; dropout masks pre-scaled by 1/(1-p))
+__global__ __launch_bounds__(256) void mul_f32_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      float* __restrict__ out, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) out[i] = a[i] * b[i];
+}
 // out[m,:] = x[m,:] * s[m]
 __global__ __launch_bounds__(256) void rowscale_f32_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                            float* __restrict__ out, long n, int d) {
@@ -430,6 +435,12 @@ int nv_add_f32(const float* a, const float* b, float* out, long n, int d, int b_
     if (!a || !b || !out) return NV_ERR_ARG;
     if (n == 0) return NV_OK;
     hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, d, b_bcast);
+    return nv_check_launch();
+}
+int nv_mul_f32(const float* a, const float* b, float* out, long n, void* stream) {
+    if (!a || !b || !out) return NV_ERR_ARG;
+    if (n == 0) return NV_OK;
+    hipLaunchKernelGGL(mul_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
     return nv_check_launch();
 }
 int nv_rowscale_f32(const float* x, const float* s, float* out, long rows, int d, void* stream) {

@@ -218,9 +218,10 @@ int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
     // tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128 (8 waves), 3 = 256x256 (8 waves)
     if (tile_cfg == 0) {
         // Fill the chip first: 256 CUs; the big tile only when it still gives >= ~2 rounds.
+        // measured on MI355X (profiles/r01_gemm_probe.txt): the 256x256 tile wins from ~1.4 rounds
+        // of the 256 CUs upward, in all three layouts
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        const long t2128 = (long)((p.M + 255) / 256) * ((p.N + 127) / 128);
-        tile_cfg = (t256 >= 1024) ? 3 : (t2128 >= 1024 ? 2 : 1);
+        tile_cfg = (t256 >= 128) ? 3 : 1;
     }
     switch (tile_cfg) {
         case 1: return launch<128, 128, 2, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
@@ -243,7 +244,9 @@ int dispatch_epi(const GemmArgs& p, int epi, int tile_cfg, hipStream_t st) {
 
 inline uint32_t span_bytes(long rows, long cols, long ld) {
     if (rows <= 0) return 0;
-    const long b = ((rows - 1) * ld + cols) * 2;
+    // bounds are checked per dword: round the last row up to an even element count (ld % 8 == 0
+    // guarantees that extra element still lies inside the row)
+    const long b = ((rows - 1) * ld + ((cols + 1) & ~1L)) * 2;
     return b > 0xffffffffL ? 0xffffffffu : (uint32_t)b;
 }
 

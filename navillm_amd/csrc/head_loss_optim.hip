@@ -179,17 +179,18 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
 // (oracle/navillm_oracle.py: adamw_step_), gradient pre-scaled by the clip coefficient.
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m,
-                                                    T* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
-                                                    float bc1, float sqrt_bc2, const float* __restrict__ clip) {
+                                                    T* __restrict__ v, long n, float decay, float w1, float b2, float w2,
+                                                    float eps, float step_size, float sqrt_bc2,
+                                                    const float* __restrict__ clip) {
+    // scalars arrive already rounded the way torch rounds its python-double hyper-parameters to fp32
     const float coef = clip ? clip[1] : 1.f;
-    const float step_size = lr / bc1;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
         const float gi = rnd<T>(ldf<T>(g, i) * coef);
-        float pi = rnd<T>(ldf<T>(p, i) * (1.f - lr * wd));
+        float pi = rnd<T>(ldf<T>(p, i) * decay);
         const float mo = ldf<T>(m, i);
-        const float mi = rnd<T>(mo + (1.f - b1) * (gi - mo));            // lerp_, weight < 0.5 form
+        const float mi = rnd<T>(mo + w1 * (gi - mo));            // lerp_, weight < 0.5 form
         float vi = rnd<T>(ldf<T>(v, i) * b2);
-        vi = rnd<T>(vi + (1.f - b2) * gi * gi);                           // addcmul_
+        vi = rnd<T>(vi + w2 * gi * gi);                           // addcmul_
         float den = rnd<T>(sqrtf(vi));
         den = rnd<T>(den / sqrt_bc2);
         den = rnd<T>(den + eps);
@@ -261,19 +262,22 @@ int nv_clip_coef(const float* partial, int n_partial, float max_norm, float* out
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n_partial, max_norm, out2);
     return nv_check_launch();
 }
-int nv_adamw(void* p, const void* g, void* m, void* v, long n, int is_bf16, float lr, float beta1, float beta2, float eps,
-             float wd, int step, const float* clip, void* stream) {
+int nv_adamw(void* p, const void* g, void* m, void* v, long n, int is_bf16, double lr, double beta1, double beta2, double eps,
+             double wd, int step, const float* clip, void* stream) {
     if (!p || !g || !m || !v || step < 1) return NV_ERR_ARG;
     if (n == 0) return NV_OK;
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float sbc2 = sqrtf(1.f - powf(beta2, (float)step));
+    // hyper-parameter arithmetic in double, like the python floats torch.optim.AdamW works with
+    const float decay = (float)(1.0 - lr * wd), w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2);
+    const float step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+    const float sbc2 = (float)sqrt(1.0 - pow(beta2, (double)step));
+    const float epsf = (float)eps;
     const int blocks = grid_for(n, 256 * 16);
     if (is_bf16)
         hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, (const bf16_t*)g,
-                           (bf16_t*)m, (bf16_t*)v, n, lr, beta1, beta2, eps, wd, bc1, sbc2, clip);
+                           (bf16_t*)m, (bf16_t*)v, n, decay, w1, b2, w2, epsf, step_size, sbc2, clip);
     else
         hipLaunchKernelGGL(adamw_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)p, (const float*)g,
-                           (float*)m, (float*)v, n, lr, beta1, beta2, eps, wd, bc1, sbc2, clip);
+                           (float*)m, (float*)v, n, decay, w1, b2, w2, epsf, step_size, sbc2, clip);
     return nv_check_launch();
 }
 

@@ -281,6 +281,18 @@ __global__ __launch_bounds__(256) void scatter_rows_bf16_kernel(const bf16_t* __
     }
 }
 
+// x *= scale (bf16, in place or out of place), n % 8 == 0
+__global__ __launch_bounds__(256) void scale_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long n8,
+                                                         float scale) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
+        float f[8];
+        ld8(x + i * 8, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] *= scale;
+        st8(out + i * 8, f);
+    }
+}
+
 inline int grid_for(long total, int cap = 256 * 8) {
     long b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -372,6 +384,14 @@ int nv_gather_rows_bf16(const void* src, const int* rows, void* out, int n, int 
     if (n == 0) return NV_OK;
     hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(grid_for((long)n * d / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, rows, (bf16_t*)out, n, d);
+    return nv_check_launch();
+}
+
+int nv_scale_bf16(const void* x, void* out, long n, float scale, void* stream) {
+    if (!x || !out || (n & 7)) return NV_ERR_ARG;
+    if (n == 0) return NV_OK;
+    hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (bf16_t*)out, n / 8, scale);
     return nv_check_launch();
 }
 

@@ -1,0 +1,131 @@
+"""Flat parameter / gradient storage in HBM.
+
+MI355X-first layout decision: all LM-dtype tensors live in ONE contiguous bf16 buffer and all
+fp32 tensors in ONE fp32 buffer (same for gradients and both AdamW moments).  Consequences:
+  * q|k|v and gate|up weights are adjacent, so each pair is ONE packed GEMM operand;
+  * weight-gradient GEMMs accumulate straight into their slice of the flat grad buffer
+    (fused `grad += dW` epilogue) -- no per-parameter `.grad` tensors to add later;
+  * the optimizer is a single fused kernel over each buffer (K13), and data-parallel
+    gradient exchange is an all-reduce over contiguous slices (one per decoder layer),
+    with no bucket copies.
+`nn.Parameter`s named exactly like the reference's state_dict (navillm_amd/params.py) are views
+into these buffers, so `state_dict()/load_state_dict()` keep working (tools/optims.py:12-24,65-78).
+"""
+import torch
+from .params import param_specs
+
+ALIGN = 64  # elements; keeps every tensor 128-B aligned for 16-B vector access and DMA
+
+
+def _lm_order(cfg):
+    """bf16 group order: per layer q,k,v | o | gate,up | down | norms, so packed views exist."""
+    names = ["lang_model.model.embed_tokens.weight"]
+    for i in range(cfg.num_layers):
+        p = f"lang_model.model.layers.{i}."
+        names += [p + "self_attn.q_proj.weight", p + "self_attn.k_proj.weight", p + "self_attn.v_proj.weight",
+                  p + "self_attn.o_proj.weight", p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight",
+                  p + "mlp.down_proj.weight", p + "input_layernorm.weight", p + "post_attention_layernorm.weight"]
+    names += ["lang_model.model.norm.weight", "lang_model.lm_head.weight"]
+    return names
+
+
+class FlatStore:
+    def __init__(self, cfg, device):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        specs = param_specs(cfg)
+        shape_of = {n: s for n, s, _ in specs}
+        group_of = {n: g for n, _, g in specs}
+        lm_names = [n for n in _lm_order(cfg)] + [n for n, _, g in specs if g == "lm" and not n.startswith("lang_model.")]
+        assert set(lm_names) == {n for n, _, g in specs if g == "lm"}
+        f32_names = [n for n, _, g in specs if g == "f32"]
+        self.lm_dtype = torch.bfloat16 if cfg.lm_is_bf16 else torch.float32
+        self.offsets = {}
+        self.sizes = {}
+        self.names = {"lm": lm_names, "f32": f32_names}
+        self.shape_of = shape_of
+        self.group_of = group_of
+        self.vocab_pad = (cfg.vocab_size + 63) // 64 * 64
+        tot = {}
+        for grp, names in self.names.items():
+            off = 0
+            for n in names:
+                numel = 1
+                for s in shape_of[n]:
+                    numel *= s
+                self.offsets[n] = off
+                self.sizes[n] = numel
+                alloc = numel
+                if n == "lang_model.lm_head.weight":
+                    # rows padded to a multiple of 64 (zero, never trained) so the vocab dimension can be
+                    # the contraction of the dgrad GEMM (K % 64 == 0) without copying logits
+                    alloc = self.vocab_pad * shape_of[n][1]
+                # packed partners must stay adjacent: q/k/v and gate/up sizes are multiples of ALIGN
+                off += (alloc + ALIGN - 1) // ALIGN * ALIGN
+            tot[grp] = off
+        self.total = tot
+        dt = {"lm": self.lm_dtype, "f32": torch.float32}
+        self.param = {g: torch.zeros(tot[g], dtype=dt[g], device=self.device) for g in tot}
+        self.grad = {g: torch.zeros(tot[g], dtype=dt[g], device=self.device) for g in tot}
+        self.exp_avg = None
+        self.exp_avg_sq = None
+
+    # ---- views
+    def _view(self, store, name):
+        g = self.group_of[name]
+        o, n = self.offsets[name], self.sizes[name]
+        return store[g][o:o + n].view(self.shape_of[name])
+
+    def p(self, name):
+        return self._view(self.param, name)
+
+    def g(self, name):
+        return self._view(self.grad, name)
+
+    def _packed(self, store, first, last):
+        """[rows_total, cols] view spanning adjacent tensors first..last (same cols)."""
+        cols = self.shape_of[first][1]
+        o0 = self.offsets[first]
+        o1 = self.offsets[last] + self.sizes[last]
+        assert (o1 - o0) % cols == 0
+        v = store["lm"][o0:o1].view(-1, cols)
+        return v
+
+    def qkv(self, i, grad=False):
+        p = f"lang_model.model.layers.{i}.self_attn."
+        v = self._packed(self.grad if grad else self.param, p + "q_proj.weight", p + "v_proj.weight")
+        assert v.shape[0] == 3 * self.cfg.hidden_size, "q/k/v must be adjacent and unpadded"
+        return v
+
+    def gate_up(self, i, grad=False):
+        p = f"lang_model.model.layers.{i}.mlp."
+        v = self._packed(self.grad if grad else self.param, p + "gate_proj.weight", p + "up_proj.weight")
+        assert v.shape[0] == 2 * self.cfg.intermediate_size, "gate/up must be adjacent and unpadded"
+        return v
+
+    def lm_head_padded(self, grad=False):
+        o = self.offsets["lang_model.lm_head.weight"]
+        d = self.cfg.hidden_size
+        return (self.grad if grad else self.param)["lm"][o:o + self.vocab_pad * d].view(self.vocab_pad, d)
+
+    def layer_slice(self, i):
+        """(start, end) element range of decoder layer i inside the lm buffers (one DP bucket)."""
+        p = f"lang_model.model.layers.{i}."
+        s = self.offsets[p + "self_attn.q_proj.weight"]
+        last = p + "post_attention_layernorm.weight"
+        e = self.offsets[last] + (self.sizes[last] + ALIGN - 1) // ALIGN * ALIGN
+        return s, e
+
+    def zero_grad(self):
+        for g in self.grad.values():
+            g.zero_()
+
+    def init_optimizer_state(self):
+        if self.exp_avg is None:
+            self.exp_avg = {g: torch.zeros_like(t) for g, t in self.param.items()}
+            self.exp_avg_sq = {g: torch.zeros_like(t) for g, t in self.param.items()}
+
+    def load_state_dict_tensors(self, sd):
+        for n in self.offsets:
+            if n in sd:
+                self.p(n).copy_(sd[n].to(self.p(n).dtype))

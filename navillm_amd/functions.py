@@ -1,0 +1,397 @@
+"""torch.autograd glue over the HIP ops: autograd is used only as the tape that connects the
+stages (scene encoder -> fusion -> LM -> head -> loss); every forward and backward body is a
+sequence of libnavillm_hip.so launches (navillm_amd/ops.py)."""
+import torch
+from . import ops
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# =============================================================================== fp32 side
+def _acc_target(p):
+    """Parameters of NavModel carry a persistent `.grad` view into the flat fp32 grad buffer: accumulate
+    there directly (no autograd `+=` pass). Plain tensors (tests) get a returned gradient instead."""
+    return p.grad if isinstance(p, torch.nn.Parameter) and p.grad is not None else None
+
+
+class LinearF32(torch.autograd.Function):
+    """y = x W^T + b on [rows, K] (nn.Linear; image_embedding.py:62-66,102; nav_model.py:59-76)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x2 = _c(x).view(-1, x.shape[-1])
+        ctx.save_for_backward(x2)
+        ctx.W, ctx.b = W, b
+        ctx.xshape = x.shape
+        y = ops.gemm_f32(ops.NT, x2, W, bias=b)
+        return y.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        dy2 = _c(dy).view(-1, W.shape[0])
+        dx = ops.gemm_f32(ops.NN, dy2, W).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        gW, gb = _acc_target(W), _acc_target(b)
+        if gW is not None:
+            ops.gemm_f32(ops.TN, dy2, x2, out=gW, accumulate=True)
+            dW = None
+        else:
+            dW = ops.gemm_f32(ops.TN, dy2, x2)
+        if gb is not None:
+            ops.colsum_f32(dy2, out=gb, accumulate=True)
+            db = None
+        else:
+            db = ops.colsum_f32(dy2)
+        return dx, dW, db
+
+
+class LayerNormF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        x2 = _c(x).view(-1, x.shape[-1])
+        y, mean, rstd = ops.layernorm_fwd(x2, w, b, eps)
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.w, ctx.b = w, b
+        ctx.xshape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        gw, gb = _acc_target(w), _acc_target(b)
+        if gw is not None and gb is not None:
+            dx, _, _ = ops.layernorm_bwd(_c(dy).view(x2.shape), x2, w, mean, rstd, gw=gw, gb=gb)
+            return dx.view(ctx.xshape), None, None, None
+        dx, dw, db = ops.layernorm_bwd(_c(dy).view(x2.shape), x2, w, mean, rstd)
+        return dx.view(ctx.xshape), dw, db, None
+
+
+class GeluF32(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return ops.gelu_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(x, _c(dy))
+
+
+class AddF32(torch.autograd.Function):
+    """a + b (same shape) or a + row-broadcast b."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a = _c(a)
+        ctx.bcast = (b.dim() == 1)
+        ctx.d = a.shape[-1]
+        return ops.add_f32(a, _c(b), bcast_rows=ctx.bcast)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        gb = ops.colsum_f32(g.view(-1, ctx.d)) if ctx.bcast else g
+        return g, gb
+
+
+def add(a, b):
+    return AddF32.apply(a, b)
+
+
+class RowScaleF32(torch.autograd.Function):
+    """x[rows, d] * s[rows]  (masked_fill(.., 0) with s in {0,1}; dropout with s = keep/(1-p) per element
+    uses MulF32)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        x = _c(x)
+        ctx.save_for_backward(s)
+        return ops.rowscale_f32(x, s)
+
+    @staticmethod
+    def backward(ctx, g):
+        (s,) = ctx.saved_tensors
+        return ops.rowscale_f32(_c(g), s), None
+
+
+class MulMaskF32(torch.autograd.Function):
+    """x * mask (dropout; mask already holds keep/(1-p))."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return ops.mul_f32(_c(x), mask)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return ops.mul_f32(_c(g), mask), None
+
+
+def dropout(x, p, training, mask=None):
+    """nn.Dropout. `mask` (0/1 keep flags) may be injected for parity tests, otherwise it is
+    drawn from torch's device generator."""
+    if not training or p == 0.0:
+        return x
+    if mask is None:
+        mask = (torch.rand(x.shape, device=x.device) >= p)
+    m = mask.to(torch.float32) * (1.0 / (1.0 - p))
+    return MulMaskF32.apply(x, m)
+
+
+class EmbedAddF32(torch.autograd.Function):
+    """base + table[idx]  (idx < 0 -> +0).  nn.Embedding lookups of the encoder/fusion."""
+
+    @staticmethod
+    def forward(ctx, table, idx_i32, base):
+        ctx.save_for_backward(idx_i32)
+        ctx.table = table
+        ctx.has_base = base is not None
+        b2 = _c(base).view(-1, table.shape[1]) if base is not None else None
+        out = ops.gather_add_f32(table, idx_i32, b2)
+        return out.view(*base.shape) if base is not None else out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g2 = _c(g).view(idx.numel(), -1)
+        gt = _acc_target(ctx.table)
+        if gt is not None:
+            ops.index_sum_f32(g2, idx, ctx.table.shape[0], out=gt, accumulate=True)
+            dt = None
+        else:
+            dt = ops.index_sum_f32(g2, idx, ctx.table.shape[0])
+        return dt, None, (g if ctx.has_base else None)
+
+
+class GatherRowsF32(torch.autograd.Function):
+    """out[i] = src[idx[i]] (idx<0 -> 0) (+ base[i]); src rows may be hit at most once (fusion /
+    candidate selection), so the backward is a gather with the inverse table."""
+
+    @staticmethod
+    def forward(ctx, src, idx_i32, inv_idx_i32, base):
+        src2 = _c(src).view(-1, src.shape[-1])
+        ctx.save_for_backward(idx_i32, inv_idx_i32)
+        ctx.sshape = src.shape
+        ctx.has_base = base is not None
+        b2 = _c(base).view(-1, src.shape[-1]) if base is not None else None
+        return ops.gather_add_f32(src2, idx_i32, b2)
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, inv = ctx.saved_tensors
+        g = _c(g)
+        ds = ops.gather_add_f32(g, inv, None).view(ctx.sshape)
+        return ds, None, None, (g if ctx.has_base else None)
+
+
+class MHAF32(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd) + key_padding) v per head on packed qkv (nn.MultiheadAttention core)."""
+
+    @staticmethod
+    def forward(ctx, qkv, lens_i32, B, N, heads, hd):
+        qkv = _c(qkv)
+        out, P = ops.mha_fwd(qkv, lens_i32, B, N, heads, hd)
+        ctx.save_for_backward(qkv, P)
+        ctx.dims = (B, N, heads, hd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, P = ctx.saved_tensors
+        return ops.mha_bwd(qkv, P, _c(dout), *ctx.dims), None, None, None, None, None
+
+
+def linear(x, W, b):
+    return LinearF32.apply(x, W, b)
+
+
+def layer_norm(x, w, b, eps):
+    return LayerNormF32.apply(x, w, b, eps)
+
+
+# =============================================================================== bf16 LM side
+class EmbedVis(torch.autograd.Function):
+    """E = embed_tokens[ids]; E[special] = bf16(f32(E) + vis)   (modified_lm.py:100-110)."""
+
+    @staticmethod
+    def forward(ctx, vis, anchor, model, ids_i32, vis_idx_i32, vis_rows_i32, ids_cpu):
+        st = model.store
+        table = st.p("lang_model.model.embed_tokens.weight")
+        E = ops.embed_vis(table, ids_i32, vis_idx_i32, vis)
+        ctx.model = model
+        ctx.vis_rows = vis_rows_i32
+        ctx.ids_cpu = ids_cpu
+        ctx.has_vis = vis is not None
+        return E
+
+    @staticmethod
+    def backward(ctx, dE):
+        dE = _c(dE)
+        st = ctx.model.store
+        dvis = ops.vis_grad(dE, ctx.vis_rows) if ctx.has_vis else None
+        # table gradient: group token rows by id on the host (ids are host data: tokenizer output)
+        ids = ctx.ids_cpu.view(-1).long()
+        order = torch.argsort(ids, stable=True)
+        uniq, counts = torch.unique_consecutive(ids[order], return_counts=True)
+        seg = torch.zeros(uniq.numel() + 1, dtype=torch.int32)
+        seg[1:] = torch.cumsum(counts, 0)
+        dev = dE.device
+        ops.embed_grad(dE, uniq.int().to(dev), seg.to(dev), order.int().to(dev), st.g("lang_model.model.embed_tokens.weight"))
+        return dvis, None, None, None, None, None, None
+
+
+class LlamaStack(torch.autograd.Function):
+    """All decoder layers + final RMSNorm (HF LlamaModel reached from modified_lm.py:112-116).
+    Weight gradients are accumulated straight into the flat grad buffer by GEMM epilogues."""
+
+    @staticmethod
+    def forward(ctx, E, model, B, S, kv_start_i32):
+        cfg, st = model.cfg, model.store
+        d, H, hd, eps = cfg.hidden_size, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps
+        x = E
+        saved = []
+        keep = torch.is_grad_enabled() or E.requires_grad
+        for i in range(cfg.num_layers):
+            p = f"lang_model.model.layers.{i}."
+            n1, rstd1 = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps)
+            qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i))
+            ops.rope_(qkv, model.rope_cos, model.rope_sin, S, H, hd)
+            attn, lse = ops.attn_fwd(qkv, kv_start_i32, B, S, H, hd)
+            x1 = ops.gemm_bf16(ops.NT, attn, st.p(p + "self_attn.o_proj.weight"), R=x, epilogue=ops.EPI_RESID)
+            n2, rstd2 = ops.rmsnorm_fwd(x1, st.p(p + "post_attention_layernorm.weight"), eps)
+            gu = ops.gemm_bf16(ops.NT, n2, st.gate_up(i))
+            h = ops.swiglu_fwd(gu)
+            x2 = ops.gemm_bf16(ops.NT, h, st.p(p + "mlp.down_proj.weight"), R=x1, epilogue=ops.EPI_RESID)
+            if keep:
+                saved.append((x, rstd1, n1, qkv, attn, lse, x1, rstd2, n2, gu, h))
+            x = x2
+        Hs, rstdf = ops.rmsnorm_fwd(x, st.p("lang_model.model.norm.weight"), eps)
+        ctx.model, ctx.saved, ctx.final = model, saved, (x, rstdf)
+        ctx.dims = (B, S, kv_start_i32)
+        return Hs
+
+    @staticmethod
+    def backward(ctx, dH):
+        model = ctx.model
+        cfg, st = model.cfg, model.store
+        B, S, kvs = ctx.dims
+        H, hd = cfg.num_heads, cfg.head_dim
+        xL, rstdf = ctx.final
+        dx = ops.rmsnorm_bwd(_c(dH), xL, st.p("lang_model.model.norm.weight"), rstdf, st.g("lang_model.model.norm.weight"))
+        model._dp_begin_backward()
+        for i in reversed(range(cfg.num_layers)):
+            p = f"lang_model.model.layers.{i}."
+            x, rstd1, n1, qkv, attn, lse, x1, rstd2, n2, gu, h = ctx.saved[i]
+            ctx.saved[i] = None
+            Wd, Wo = st.p(p + "mlp.down_proj.weight"), st.p(p + "self_attn.o_proj.weight")
+            dh = ops.gemm_bf16(ops.NN, dx, Wd)
+            ops.gemm_bf16(ops.TN, dx, h, out=st.g(p + "mlp.down_proj.weight"), epilogue=ops.EPI_ACCUM)
+            dgu = ops.swiglu_bwd(gu, dh)
+            del dh, h
+            dn2 = ops.gemm_bf16(ops.NN, dgu, st.gate_up(i))
+            ops.gemm_bf16(ops.TN, dgu, n2, out=st.gate_up(i, grad=True), epilogue=ops.EPI_ACCUM)
+            del dgu, gu
+            dx1 = ops.rmsnorm_bwd(dn2, x1, st.p(p + "post_attention_layernorm.weight"), rstd2,
+                                  st.g(p + "post_attention_layernorm.weight"), resid_grad=dx)
+            dattn = ops.gemm_bf16(ops.NN, dx1, Wo)
+            ops.gemm_bf16(ops.TN, dx1, attn, out=st.g(p + "self_attn.o_proj.weight"), epilogue=ops.EPI_ACCUM)
+            dqkv = ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd)
+            ops.rope_(dqkv, model.rope_cos, model.rope_sin, S, H, hd, backward=True)
+            dn1 = ops.gemm_bf16(ops.NN, dqkv, st.qkv(i))
+            ops.gemm_bf16(ops.TN, dqkv, n1, out=st.qkv(i, grad=True), epilogue=ops.EPI_ACCUM)
+            dx = ops.rmsnorm_bwd(dn1, x, st.p(p + "input_layernorm.weight"), rstd1, st.g(p + "input_layernorm.weight"),
+                                 resid_grad=dx1)
+            model._dp_layer_done(i)
+        return dx, None, None, None, None
+
+
+class GatherRowsBF16(torch.autograd.Function):
+    """rows of the hidden states (the <cls_1> positions, nav_model.py:237)."""
+
+    @staticmethod
+    def forward(ctx, Hs, rows_i32):
+        ctx.save_for_backward(rows_i32)
+        ctx.shape = Hs.shape
+        return ops.gather_rows_bf16(Hs, rows_i32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (rows,) = ctx.saved_tensors
+        dH = torch.zeros(ctx.shape, dtype=BF16, device=g.device)
+        ops.scatter_rows_bf16_(_c(g), rows, dH)
+        return dH, None
+
+
+class HeadBF16(torch.autograd.Function):
+    """out_head / og_head Linear(d -> 100) in the LM dtype; weight grads go to the flat buffer."""
+
+    @staticmethod
+    def forward(ctx, x, model, prefix):
+        st = model.store
+        W, b = st.p(prefix + ".weight"), st.p(prefix + ".bias")
+        ctx.save_for_backward(x)
+        ctx.model, ctx.prefix = model, prefix
+        return ops.head_fwd(x, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        st = ctx.model.store
+        pf = ctx.prefix
+        dx = ops.head_bwd(_c(dy), x, st.p(pf + ".weight"), st.g(pf + ".weight"), st.g(pf + ".bias"))
+        return dx, None, None
+
+
+class LMHeadLoss(torch.autograd.Function):
+    """lm_head + special-id mask + shifted mean CE (modified_lm.py:119-137).  Logits are materialised
+    once in bf16 and overwritten by their gradient (round-1 form of K9)."""
+
+    @staticmethod
+    def forward(ctx, Hs, model, labels_shift_i32, n_valid):
+        cfg, st = model.cfg, model.store
+        W = st.lm_head_padded()                 # [V_pad, d], pad rows are zero
+        V = cfg.vocab_size
+        logits = ops.gemm_bf16(ops.NT, Hs, W)   # [M, V_pad]; pad columns are exactly 0
+        rows = ops.lm_ce_(logits, labels_shift_i32, V, cfg.special_token_ids[0], len(cfg.special_token_ids),
+                          1.0 / max(n_valid, 1), write_grad=True)
+        loss = (rows.sum() / max(n_valid, 1)).to(BF16)
+        ctx.save_for_backward(Hs, logits)
+        ctx.model = model
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        Hs, dl = ctx.saved_tensors              # dl: [M, V_pad], pad columns 0
+        st = ctx.model.store
+        gs = float(g)
+        if gs != 1.0:
+            ops.scale_bf16_(dl, gs)             # loss coefficient applied by the caller after .loss
+        dH = ops.gemm_bf16(ops.NN, dl, st.lm_head_padded())
+        ops.gemm_bf16(ops.TN, dl, Hs, out=st.lm_head_padded(grad=True), epilogue=ops.EPI_ACCUM)
+        return dH, None, None, None
+
+
+class ActionCE(torch.autograd.Function):
+    """CrossEntropyLoss(ignore_index=-100, reduction='sum') on bf16 logits (train.py:229)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets):
+        logits = _c(logits)
+        rows, _ = ops.action_ce(logits, targets, want_grad=False)
+        ctx.save_for_backward(logits, targets)
+        return rows.sum().to(logits.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, targets = ctx.saved_tensors
+        _, dl = ops.action_ce(logits, targets, gscale=float(g), want_grad=True)
+        return dl, None

@@ -25,6 +25,7 @@ SIGNATURES = {
     "nv_rope_bf16": (i, [vp, vp, vp, i, i, i, i, i, i, vp]),
     "nv_swiglu_fwd_bf16": (i, [vp, vp, i, i, vp]),
     "nv_swiglu_bwd_bf16": (i, [vp, vp, vp, i, i, vp]),
+    "nv_scale_bf16": (i, [vp, vp, l, f, vp]),
     "nv_gather_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
     "nv_scatter_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
     "nv_attn_fwd_bf16": (i, [vp, vp, fp, ip, i, i, i, i, vp]),
@@ -36,7 +37,7 @@ SIGNATURES = {
     "nv_lm_ce_bf16": (i, [vp, ip, fp, i, i, i, i, i, f, i, vp]),
     "nv_sumsq": (i, [vp, l, i, fp, C.POINTER(C.c_int), vp]),
     "nv_clip_coef": (i, [fp, i, f, fp, vp]),
-    "nv_adamw": (i, [vp, vp, vp, vp, l, i, f, f, f, f, f, i, fp, vp]),
+    "nv_adamw": (i, [vp, vp, vp, vp, l, i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i, fp, vp]),
     "nv_gemm_f32": (i, [i, fp, fp, fp, fp, i, i, i, i, i, i, i, vp]),
     "nv_layernorm_fwd_f32": (i, [fp, fp, fp, fp, fp, fp, i, i, f, vp]),
     "nv_layernorm_bwd_workspace_bytes": (sz, [i]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "nv_gelu_fwd_f32": (i, [fp, fp, l, vp]),
     "nv_gelu_bwd_f32": (i, [fp, fp, fp, l, vp]),
     "nv_add_f32": (i, [fp, fp, fp, l, i, i, vp]),
+    "nv_mul_f32": (i, [fp, fp, fp, l, vp]),
     "nv_rowscale_f32": (i, [fp, fp, fp, l, i, vp]),
     "nv_gather_add_f32": (i, [fp, ip, fp, fp, l, i, vp]),
     "nv_index_sum_f32": (i, [fp, ip, fp, i, i, i, i, vp]),

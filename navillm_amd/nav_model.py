@@ -1,0 +1,486 @@
+"""Drop-in mirror of the reference's `NavModel` (models/nav_model.py:33-451) for MI355X.
+
+Same constructor (`NavModel(args, logger, model_config)`), same call protocol
+(`model(mode, batch, **kw) -> dict`, modes of nav_model.py:96-126), same attributes the agents
+touch (`.lang_model.cls_token`, `.lang_model.tokenizer`, `.lang_model.cls_token_id`), same
+`state_dict()` key layout.  Underneath, every device computation is a libnavillm_hip.so launch
+(navillm_amd/functions.py); the host only does what the reference also does on the host:
+tokenisation, vpid matching (nav_model.py:174-190), candidate permutation (:216-223).
+
+Not mirrored (raise NotImplementedError): `generate()` paths of summarization/3dqa/embodied_qa
+inference (SURVEY.md §8f "next"), fp32 LM, OPT LMs, fuse_obj=True.
+"""
+import collections
+import math
+import os
+import types
+
+import torch
+import torch.nn as nn
+
+from . import functions as Fn
+from . import ops
+from .config import NavConfig
+from .flat import FlatStore
+from .params import param_specs, synth_tensor
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+class _Box(nn.Module):
+    """anonymous container so parameters get the reference's dotted names"""
+
+
+class LangModelShell(nn.Module):
+    """Carries what the agents read from `model.lang_model` (modified_lm.py:56-87)."""
+
+    def __init__(self, cfg, tokenizer=None):
+        super().__init__()
+        self.cand_token = ["<cand>"]
+        self.hist_token = ["<hist>"]
+        self.obj_token = ["<obj>"]
+        self.cls_token = ["<cls_1>", "<cls_2>"]
+        self.cand_token_id = [cfg.cand_token_id]
+        self.hist_token_id = [cfg.hist_token_id]
+        self.obj_token_id = [cfg.obj_token_id]
+        self.cls_token_id = list(cfg.cls_token_ids)
+        self.special_token_ids = list(cfg.special_token_ids)
+        self.hidden_size = cfg.hidden_size
+        self.model_type = BF16 if cfg.lm_is_bf16 else F32
+        self.tokenizer = tokenizer
+
+    def tokenize(self, text, add_special_tokens=True):
+        """modified_lm.py:77-87 (left pad, left truncation at 1024, token_type_ids)."""
+        if self.tokenizer is None:
+            raise RuntimeError("no tokenizer attached: pass pre-tokenised batch['input_ids'] / "
+                               "batch['attention_mask'] or build the model from a tokenizer directory")
+        return self.tokenizer(text, max_length=1024, padding=True, truncation=True, return_tensors="pt",
+                              add_special_tokens=add_special_tokens, return_token_type_ids=True)
+
+
+def load_tokenizer(path, cfg):
+    """LlamaTokenizer + the five special tokens + <PAD> exactly as init_tokenizer does (modified_lm.py:56-75)."""
+    from transformers import LlamaTokenizer
+    tok = LlamaTokenizer.from_pretrained(path, padding_side="left", truncation_side="left")
+    tok.add_special_tokens({"additional_special_tokens": ["<cand>", "<hist>", "<obj>", "<cls_1>", "<cls_2>"]})
+    if tok.pad_token is None:
+        tok.add_special_tokens({"pad_token": "<PAD>"})
+    assert tok.encode("<cand>", add_special_tokens=False) == [cfg.cand_token_id]
+    assert tok.encode("<cls_1>", add_special_tokens=False) == [cfg.cls_token_ids[0]]
+    assert len(tok) == cfg.vocab_size, (len(tok), cfg.vocab_size)
+    return tok
+
+
+class _Out(dict):
+    """dict that also answers `.loss` (llava.py:38 reads `model("3dqa", batch).loss`)."""
+
+    @property
+    def loss(self):
+        return self["loss"]
+
+
+class NavModel(nn.Module):
+    def __init__(self, args=None, logger=None, model_config=None, *, nav_config=None, device=None, tokenizer=None,
+                 seed=0, init="synthetic"):
+        super().__init__()
+        if nav_config is None:
+            nav_config = self._config_from_args(args, model_config)
+        cfg = self.cfg = nav_config
+        self.args = args
+        if not cfg.lm_is_bf16:
+            raise NotImplementedError("the MI355X path implements the reference's amp_bf16 mode (bf16 LM + heads, fp32 "
+                                      "encoder); precision='fp32' has no HIP LM")
+        if cfg.fuse_obj:
+            raise NotImplementedError("fuse_obj=True is not built yet (default configs use False)")
+        if cfg.head_dim != 128:
+            raise NotImplementedError("attention kernels are built for head_dim 128 (Llama/Vicuna 7B/13B)")
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("NavModel needs a GPU: there is no CPU fallback (the CPU oracle is test-only)")
+        ops._L()  # fail loudly, now, if libnavillm_hip.so is missing
+        self.store = FlatStore(cfg, self.device)
+        self.hidden_size = cfg.hidden_size
+        self.model_type = BF16
+
+        # ---- parameters: nn.Parameters that are VIEWS into the flat buffers, reference names
+        if tokenizer is None and args is not None and getattr(args, "pretrained_model_name_or_path", None):
+            pth = args.pretrained_model_name_or_path
+            if os.path.exists(os.path.join(pth, "tokenizer.model")):
+                tokenizer = load_tokenizer(pth, cfg)
+        self.lang_model = LangModelShell(cfg, tokenizer)
+        self._named = collections.OrderedDict()
+        for name, shape, group in param_specs(cfg):
+            p = nn.Parameter(self.store.p(name), requires_grad=True)
+            p.grad = self.store.g(name)
+            self._attach(name, p)
+            self._named[name] = p
+        if init == "synthetic":
+            self.init_synthetic(seed)
+
+        # ---- RoPE tables, built the HF way (fp32 angles on the host, then cast to the LM dtype)
+        hd = cfg.head_dim
+        inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd))
+        fr = torch.outer(torch.arange(2048).float(), inv)
+        emb = torch.cat([fr, fr], -1)
+        self.rope_cos = emb.cos().to(BF16).to(self.device).contiguous()
+        self.rope_sin = emb.sin().to(BF16).to(self.device).contiguous()
+        self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
+        self._dp = None
+        self.drop_env_p = cfg.feat_dropout
+        self.injected_dropout = None   # tests: dict of keep masks
+
+    # ------------------------------------------------------------------ construction helpers
+    @staticmethod
+    def _config_from_args(args, model_config):
+        over = dict(image_feat_size=args.image_feat_size, angle_feat_size=args.angle_feat_size,
+                    obj_feat_size=args.obj_feat_size, enable_og=bool(args.enable_og), fuse_obj=bool(args.fuse_obj),
+                    feat_dropout=args.feat_dropout, precision=args.precision,
+                    num_pano_layers=model_config.num_pano_layers)
+        return NavConfig.from_hf_dir(args.pretrained_model_name_or_path, **over)
+
+    def _attach(self, dotted, param):
+        mod = self
+        parts = dotted.split(".")
+        for part in parts[:-1]:
+            if not hasattr(mod, part):
+                mod.add_module(part, _Box())
+            mod = getattr(mod, part)
+        mod.register_parameter(parts[-1], param)
+
+    @torch.no_grad()
+    def init_synthetic(self, seed=0):
+        """Seeded random weights (navillm_amd/params.py: per-name generators), generated on the device."""
+        for name, shape, group in param_specs(self.cfg):
+            self.store.p(name).copy_(synth_tensor(name, shape, seed, device="cpu" if self.cfg.hidden_size <= 1024 else self.device))
+
+    @torch.no_grad()
+    def load_reference_state_dict(self, sd):
+        """Load a NaviLLM checkpoint's `model_state_dict` (tools/optims.py:12-24 semantics: strip `module.`,
+        skip shape mismatches)."""
+        n = 0
+        for k, v in sd.items():
+            k = k[7:] if k.startswith("module.") else k
+            if k in self._named and tuple(v.shape) == tuple(self._named[k].shape):
+                self._named[k].copy_(v.to(self._named[k].dtype))
+                n += 1
+        return n
+
+    def zero_grad(self, set_to_none=False):
+        self.store.zero_grad()
+
+    def _apply(self, fn, recurse=True):
+        # .to(device)/.cuda() on the right device are no-ops; anything else would break the flat views
+        probe = fn(torch.empty(0, device=self.device))
+        if probe.device != self.device or probe.dtype != torch.float32:
+            raise RuntimeError("NavModel lives in flat HBM buffers: .to(other device/dtype) is not supported")
+        return self
+
+    # ---- DP hooks (navillm_amd/parallel.py installs itself here)
+    def _dp_begin_backward(self):
+        if self._dp is not None:
+            self._dp.on_backward_begin()
+
+    def _dp_layer_done(self, i):
+        if self._dp is not None:
+            self._dp.on_layer_done(i)
+
+    # ------------------------------------------------------------------ small helpers
+    def P(self, name):
+        return self._named[name]
+
+    def _lin(self, x, prefix):
+        return Fn.linear(x, self.P(prefix + ".weight"), self.P(prefix + ".bias"))
+
+    def _ln(self, x, prefix, eps):
+        return Fn.layer_norm(x, self.P(prefix + ".weight"), self.P(prefix + ".bias"), eps)
+
+    def _seq2(self, x, prefix):
+        return self._ln(self._lin(x, prefix + ".0"), prefix + ".1", 1e-12)
+
+    def _drop(self, x, p, key):
+        m = None if self.injected_dropout is None else self.injected_dropout.get(key)
+        return Fn.dropout(x, p, self.training, m)
+
+    def _i32(self, t):
+        return torch.as_tensor(t).to(device=self.device, dtype=torch.int32).contiguous()
+
+    # ------------------------------------------------------------------ forward dispatch (nav_model.py:96-126)
+    def forward(self, mode, batch, **kwargs):
+        batch = collections.defaultdict(lambda: None, batch)
+        if mode == "panorama":
+            v = batch["view_img_fts"]
+            if self.training and self.drop_env_p > 0:
+                v = self._drop(v, self.drop_env_p, "drop_env.view")
+            o = batch["obj_img_fts"]
+            if o is not None and self.training and self.drop_env_p > 0:
+                o = self._drop(o, self.drop_env_p, "drop_env.obj")
+            return self.forward_panorama_per_step(v, batch["view_lens"], batch["loc_fts"], batch["nav_types"], o,
+                                                  batch["obj_lens"], batch["obj_loc_fts"])
+        elif mode == "navigation":
+            return self.forward_navigation(mode, batch, **kwargs)
+        elif mode == "summarization" or mode == "embodied_qa":
+            return self.forward_summarization(mode, batch, **kwargs)
+        elif mode == "3dqa":
+            return self.forward_3dqa(mode, batch, **kwargs)
+        elif mode == "object_grounding":
+            return self.forward_object_grounding(mode, batch, **kwargs)
+        else:
+            raise NotImplementedError("wrong mode: %s" % mode)
+
+    # ------------------------------------------------------------------ scene encoder (image_embedding.py:51-121)
+    def forward_panorama_per_step(self, view_img_fts, view_lens, loc_fts=None, nav_types=None, obj_img_fts=None,
+                                  obj_lens=None, obj_loc_fts=None):
+        cfg = self.cfg
+        e = "img_embeddings"
+        view_img_fts = view_img_fts.to(self.device, F32)
+        B, N, _ = view_img_fts.shape
+        h = cfg.enc_hidden_size
+        x = self._ln(self._lin(view_img_fts, e + ".img_linear"), e + ".img_layer_norm", 1e-12)
+        if loc_fts is None:
+            loc_fts = torch.zeros((B, N, 7), dtype=F32, device=self.device)
+        x = Fn.add(x, self._ln(self._lin(loc_fts.to(self.device, F32), e + ".loc_linear"), e + ".loc_layer_norm", 1e-12))
+        if nav_types is None:
+            nav_types = torch.ones((B, N), dtype=torch.int32, device=self.device)
+        x = Fn.EmbedAddF32.apply(self.P(e + ".nav_type_embedding.weight"), self._i32(nav_types).view(-1), x)
+        x = self._ln(x, e + ".layer_norm", 1e-12)
+        x = self._drop(x, cfg.enc_dropout, "emb.drop")
+        lens_dev = torch.as_tensor(view_lens).to(self.device)
+        pano_masks = torch.arange(N, device=self.device).unsqueeze(0) < lens_dev.unsqueeze(1)
+        lens_i32 = lens_dev.to(torch.int32).contiguous()
+        heads, hd = cfg.enc_num_heads, h // cfg.enc_num_heads
+        for i in range(cfg.num_pano_layers):
+            p = f"{e}.pano_encoder.layers.{i}"
+            y = self._ln(x, p + ".norm1", 1e-5)
+            qkv = Fn.linear(y, self.P(p + ".self_attn.in_proj_weight"), self.P(p + ".self_attn.in_proj_bias"))
+            a = Fn.MHAF32.apply(qkv.view(B * N, 3 * h), lens_i32, B, N, heads, hd).view(B, N, h)
+            a = self._lin(a, p + ".self_attn.out_proj")
+            x = Fn.add(x, self._drop(a, cfg.enc_dropout, f"l{i}.drop1"))
+            y = self._ln(x, p + ".norm2", 1e-5)
+            y = Fn.GeluF32.apply(self._lin(y, p + ".linear1"))
+            y = self._drop(y, cfg.enc_dropout, f"l{i}.drop")
+            y = self._lin(y, p + ".linear2")
+            x = Fn.add(x, self._drop(y, cfg.enc_dropout, f"l{i}.drop2"))
+        if cfg.num_pano_layers > 0:
+            x = self._ln(x, e + ".pano_encoder.norm", 1e-12)
+        x = self._lin(x, e + ".mapper")
+        x = Fn.RowScaleF32.apply(x, pano_masks.to(F32).view(-1).contiguous()).view(B, N, cfg.hidden_size)
+        ret = {"pano_embeds": x, "pano_masks": pano_masks}
+        if obj_img_fts is not None and obj_img_fts.shape[1] > 0:
+            oe = self._seq2(obj_img_fts.to(self.device, F32), e + ".obj_projector")
+            ol = torch.as_tensor(obj_lens).to(self.device)
+            obj_masks = torch.arange(obj_img_fts.shape[1], device=self.device).unsqueeze(0) < ol.unsqueeze(1)
+            assert oe.shape[:2] == obj_loc_fts.shape[:2], \
+                f"shape of obj_embeds {oe.shape[:2]} must equal to shape of obj_loc_fts {obj_loc_fts.shape[:2]}"
+            ret.update({"obj_embeds": oe, "obj_loc_fts": obj_loc_fts, "obj_masks": obj_masks})
+        return ret
+
+    # ------------------------------------------------------------------ the visual-token LM (modified_lm.py:89-146)
+    def _tokens(self, batch, text):
+        """ids/mask on the host: pre-tokenised (synthetic driver) or via the attached tokenizer."""
+        if batch.get("input_ids") is not None:
+            ids, am = torch.as_tensor(batch["input_ids"]).cpu(), torch.as_tensor(batch["attention_mask"]).cpu()
+            tt = batch.get("token_type_ids")
+            return ids, am, (None if tt is None else torch.as_tensor(tt).cpu())
+        tok = self.lang_model.tokenize(text)
+        return tok["input_ids"], tok["attention_mask"], tok.get("token_type_ids")
+
+    def _lm(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None):
+        """-> hidden states [B*S, d] bf16 (post final RMSNorm)."""
+        cfg = self.cfg
+        B, S = ids_cpu.shape
+        flat = ids_cpu.reshape(-1)
+        vis_idx = torch.full((B * S,), -1, dtype=torch.int32)
+        parts, rows, off = [], [], 0
+        for tok_id, vis in ((cfg.cand_token_id, cand_vis), (cfg.hist_token_id, hist_vis), (cfg.obj_token_id, obj_vis)):
+            loc = torch.nonzero(flat == tok_id).view(-1)
+            if loc.numel() == 0:
+                continue
+            assert vis is not None and vis.shape[0] == loc.numel(), \
+                f"{loc.numel()} special tokens of id {tok_id} but {None if vis is None else vis.shape[0]} visual rows"
+            vis_idx[loc] = torch.arange(off, off + loc.numel(), dtype=torch.int32)
+            rows.append(loc.to(torch.int32))
+            parts.append(vis.to(F32))
+            off += loc.numel()
+        vis_all = torch.cat(parts, 0).contiguous() if parts else None
+        vis_rows = torch.cat(rows).to(self.device) if rows else None
+        am = am_cpu.bool()
+        kv_start = (am.int().cumsum(1) == 0).sum(1).to(torch.int32)
+        assert bool((am == (torch.arange(S)[None] >= kv_start[:, None])).all()), "attention_mask must be left padding"
+        E = Fn.EmbedVis.apply(vis_all, self._anchor if torch.is_grad_enabled() else None, self,
+                              flat.to(torch.int32).to(self.device), vis_idx.to(self.device), vis_rows, flat)
+        return Fn.LlamaStack.apply(E, self, B, S, kv_start.to(self.device))
+
+    def _lm_loss(self, Hs, ids_cpu, labels_cpu):
+        """shifted mean CE over labels != -100 (modified_lm.py:126-137)."""
+        B, S = ids_cpu.shape
+        shift = torch.full((B, S), -100, dtype=torch.int64)
+        shift[:, :-1] = labels_cpu[:, 1:]
+        n_valid = int((shift != -100).sum())
+        return Fn.LMHeadLoss.apply(Hs, self, shift.view(-1).to(torch.int32).to(self.device), n_valid)
+
+    @staticmethod
+    def _stack_hist(hist_vis):
+        flat = [v for vis in hist_vis for v in vis]
+        return torch.stack(flat, 0) if flat else None
+
+    def _cls_rows(self, ids_cpu):
+        loc = torch.nonzero(ids_cpu.reshape(-1) == self.cfg.cls_token_ids[0]).view(-1)
+        return loc.to(torch.int32).to(self.device)
+
+    # ------------------------------------------------------------------ navigation (nav_model.py:129-247)
+    def forward_navigation(self, mode, batch, training=True, **kwargs):
+        cfg, dev = self.cfg, self.device
+        d = cfg.hidden_size
+        vp_img = batch["vp_img_embeds"]
+        B, Nv, _ = vp_img.shape
+        g_img, g_step, g_pos = batch["gmap_img_embeds"], batch["gmap_step_ids"], batch["gmap_pos_fts"]
+        G = g_img.shape[1]
+        # host copies of the two bool masks drive the python-side matching, as in the reference; a caller
+        # that already has them on the host can pass them along and skip the D2H sync
+        gm_cpu = batch["_gmask_cpu"] if batch["_gmask_cpu"] is not None else torch.as_tensor(batch["gmap_masks"]).cpu().bool()
+        gv_cpu = batch["_gvis_cpu"] if batch["_gvis_cpu"] is not None else torch.as_tensor(batch["gmap_visited_masks"]).cpu().bool()
+        g_vpids, vp_cand_vpids = batch["gmap_vpids"], batch["vp_cand_vpids"]
+
+        # global branch (:146-150) and local branch (:159-162)
+        gmap = Fn.EmbedAddF32.apply(self.P("gmap_step_embeddings.weight"), self._i32(g_step).view(-1), g_img.to(dev, F32))
+        gmap = Fn.add(gmap, self._seq2(g_pos.to(dev, F32), "gmap_pos_embeddings"))
+        vp = Fn.add(vp_img, self._seq2(batch["vp_pos_fts"].to(dev, F32), "vp_pos_embeddings"))
+        keep_g = (gm_cpu & ~gv_cpu)
+        keep_g_dev = keep_g.to(F32).view(-1).to(dev)
+        gmap = Fn.RowScaleF32.apply(gmap.view(B * G, d), keep_g_dev)
+        pm = torch.as_tensor(batch["pano_masks"]).to(dev).to(F32).view(-1).contiguous()
+        vp = Fn.RowScaleF32.apply(vp.view(B * Nv, d), pm)
+
+        # host: which current-view candidate feeds which map slot (:174-190)
+        src = torch.full((B * G,), -1, dtype=torch.int32)
+        inv = torch.full((B * Nv,), -1, dtype=torch.int32)
+        ttype = torch.zeros((B * G,), dtype=torch.int32)
+        for i in range(B):
+            visited = set(v for v, m in zip(g_vpids[i], gv_cpu[i].tolist()) if m)
+            tmp = {}
+            for j, cv in enumerate(vp_cand_vpids[i]):
+                if j > 0 and cv not in visited:
+                    tmp[cv] = j
+            for j, v in enumerate(g_vpids[i]):
+                if j > 0 and v not in visited:
+                    if v in tmp:
+                        src[i * G + j] = i * Nv + tmp[v]
+                        inv[i * Nv + tmp[v]] = i * G + j
+                    else:
+                        ttype[i * G + j] = 1
+        fuse = Fn.GatherRowsF32.apply(vp, src.to(dev), inv.to(dev), gmap)
+        fuse = Fn.EmbedAddF32.apply(self.P("token_type_embeddings.weight"), ttype.to(dev), fuse)
+        fuse = Fn.RowScaleF32.apply(fuse, keep_g_dev)                       # [B*G, d]
+
+        cand_masks = keep_g
+        cand_nums = cand_masks.sum(-1)
+        # candidate permutation with the reference's CPU RNG call order (:216-223)
+        sel, inv_sel, inv_perms = [], torch.full((B * G,), -1, dtype=torch.int32), []
+        for b in range(B):
+            slots = torch.nonzero(cand_masks[b]).view(-1)[1:]
+            rp = torch.randperm(slots.numel())
+            ip = torch.arange(slots.numel())
+            ip[rp] = torch.arange(slots.numel())
+            inv_perms.append(ip)
+            for s in slots[rp].tolist():
+                inv_sel[b * G + s] = len(sel)
+                sel.append(b * G + s)
+        cand_embeds = Fn.GatherRowsF32.apply(fuse, torch.tensor(sel, dtype=torch.int32, device=dev), inv_sel.to(dev), None)
+
+        hist_vis = self._stack_hist(batch["hist_vis"])
+        ids, am, _ = self._tokens(batch, batch["prompts"])
+        Hs = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis)
+        pred = Fn.HeadBF16.apply(Fn.GatherRowsBF16.apply(Hs, self._cls_rows(ids)), self, "out_head.0")   # [B,100]
+
+        # fuse_logits[b][cand slots] = [pred[b,0], pred[b,1:n][inv_perm]] ; -inf elsewhere (:234-242)
+        col = torch.zeros((B, G), dtype=torch.int64)
+        for b in range(B):
+            slots = torch.nonzero(cand_masks[b]).view(-1)
+            n = int(cand_nums[b])
+            col[b, slots[0]] = 0
+            col[b, slots[1:]] = 1 + inv_perms[b][: n - 1]
+        logits = torch.gather(pred, 1, col.to(dev)).masked_fill(cand_masks.logical_not().to(dev), float("-inf"))
+        return {"fuse_embeds": fuse.detach().view(B, G, d), "fuse_logits": logits}
+
+    # ------------------------------------------------------------------ object grounding (nav_model.py:407-451)
+    def forward_object_grounding(self, mode, batch, training=True, **kwargs):
+        dev, d = self.device, self.cfg.hidden_size
+        obj_embeds, obj_masks = batch["obj_embeds"], torch.as_tensor(batch["obj_masks"]).cpu().bool()
+        B, O, _ = obj_embeds.shape
+        oe = Fn.add(obj_embeds, self._seq2(batch["obj_loc_fts"].to(dev, F32), "obj_pos_embeddings")).view(B * O, d)
+        cand_nums = obj_masks.sum(1) + 1
+        sel = torch.nonzero(obj_masks.view(-1)).view(-1).to(torch.int32)
+        inv = torch.full((B * O,), -1, dtype=torch.int32)
+        inv[sel.long()] = torch.arange(sel.numel(), dtype=torch.int32)
+        cand_vis = Fn.GatherRowsF32.apply(oe, sel.to(dev), inv.to(dev), None) if sel.numel() else None
+        ids, am, _ = self._tokens(batch, batch["prompts"])
+        Hs = self._lm(ids, am, cand_vis=cand_vis, hist_vis=self._stack_hist(batch["hist_vis"]))
+        pred = Fn.HeadBF16.apply(Fn.GatherRowsBF16.apply(Hs, self._cls_rows(ids)), self, "out_head.0")
+        dead = torch.arange(pred.shape[1])[None] >= cand_nums[:, None]
+        return {"obj_logits": pred.masked_fill(dead.to(dev), float("-inf"))}
+
+    # ------------------------------------------------------------------ LM-loss modes, training branches
+    def _zero_pose_type0(self, rows):
+        z = torch.zeros((rows, 14), dtype=F32, device=self.device)
+        e = self._seq2(z, "vp_pos_embeddings")
+        return Fn.add(e, self.P("token_type_embeddings.weight")[0])
+
+    def forward_3dqa(self, mode, batch, training=True, **kwargs):
+        """nav_model.py:346-385 (training). Inference (`generate`) is not built yet."""
+        if not training:
+            raise NotImplementedError("3dqa generation path: SURVEY.md §8f item 2 (next)")
+        dev, d = self.device, self.cfg.hidden_size
+        feats = [f.to(dev, F32) for f in batch["features"]]
+        B = len(feats)
+        N = max(f.shape[0] for f in feats)
+        vf = torch.zeros((B, N, feats[0].shape[1]), dtype=F32, device=dev)
+        for i, f in enumerate(feats):
+            vf[i, : f.shape[0]] = f
+        vl = torch.tensor([f.shape[0] for f in feats])
+        out = self.forward_panorama_per_step(vf, vl)
+        pe = Fn.add(out["pano_embeds"].view(B * N, d), self._zero_pose_type0(B * N))
+        pm = (torch.arange(N)[None] < vl[:, None])
+        sel = torch.nonzero(pm.view(-1)).view(-1).to(torch.int32)
+        inv = torch.full((B * N,), -1, dtype=torch.int32)
+        inv[sel.long()] = torch.arange(sel.numel(), dtype=torch.int32)
+        cand_vis = Fn.GatherRowsF32.apply(pe, sel.to(dev), inv.to(dev), None)
+        if batch.get("input_ids") is None:
+            eos = self.lang_model.tokenizer.eos_token
+            text = [[batch["prompts"][bn], batch["answers"][bn][0] + f"{eos}"] for bn in range(B)]
+        else:
+            text = None
+        ids, am, tt = self._tokens(batch, text)
+        labels = ids.clone()
+        labels[tt[:, -labels.shape[-1]:] == 0] = -100
+        Hs = self._lm(ids, am, cand_vis=cand_vis)
+        return _Out(loss=self._lm_loss(Hs, ids, labels))
+
+    def forward_summarization(self, mode, batch, training=True, **kwargs):
+        """nav_model.py:251-319 (training branch)."""
+        if not training:
+            raise NotImplementedError("summarization/embodied_qa generation path: SURVEY.md §8f item 2 (next)")
+        dev, d = self.device, self.cfg.hidden_size
+        vp_img = batch["vp_img_embeds"][:, 1:, :]
+        nav_masks = torch.as_tensor(batch["vp_nav_masks"]).cpu().bool()[:, 1:]
+        B, N, _ = vp_img.shape
+        x = Fn.add(vp_img.contiguous().view(B * N, d), self._zero_pose_type0(B * N))
+        sel = torch.nonzero(nav_masks.reshape(-1)).view(-1).to(torch.int32)
+        inv = torch.full((B * N,), -1, dtype=torch.int32)
+        inv[sel.long()] = torch.arange(sel.numel(), dtype=torch.int32)
+        cand_vis = Fn.GatherRowsF32.apply(x, sel.to(dev), inv.to(dev), None) if sel.numel() else None
+        if batch.get("input_ids") is None:
+            eos = self.lang_model.tokenizer.eos_token
+            dt = batch["data_type"][0]
+            text = []
+            for bn in range(B):
+                label = (batch["answer"][bn] if dt in ("eqa", "fgr2r") else batch["instruction"][bn]) + f"{eos}"
+                text.append([batch["prompts"][bn], label])
+        else:
+            text = None
+        ids, am, tt = self._tokens(batch, text)
+        labels = ids.clone()
+        labels[tt[:, -labels.shape[-1]:] == 0] = -100
+        Hs = self._lm(ids, am, cand_vis=cand_vis, hist_vis=self._stack_hist(batch["hist_vis"]))
+        return _Out(loss=self._lm_loss(Hs, ids, labels))

@@ -139,6 +139,11 @@ def swiglu_bwd(gu, dh, out=None):
     return out
 
 
+def scale_bf16_(x, scale):
+    _lib.check(_L().nv_scale_bf16(x.data_ptr(), x.data_ptr(), x.numel(), float(scale), _st()), "nv_scale_bf16")
+    return x
+
+
 def gather_rows_bf16(src, rows_i32):
     n, d = rows_i32.numel(), src.shape[1]
     out = torch.empty((n, d), dtype=BF16, device=src.device)
@@ -263,21 +268,25 @@ def layernorm_fwd(x, w, b, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, w, mean, rstd):
+def layernorm_bwd(dy, x, w, mean, rstd, gw=None, gb=None):
+    """dx, dgamma, dbeta; when gw/gb are given the parameter gradients are ACCUMULATED into them."""
     M, d = x.shape
     dx = torch.empty_like(x)
-    gw = torch.empty((d,), dtype=F32, device=x.device)
-    gb = torch.empty((d,), dtype=F32, device=x.device)
+    acc = 1 if gw is not None else 0
+    if gw is None:
+        gw = torch.empty((d,), dtype=F32, device=x.device)
+        gb = torch.empty((d,), dtype=F32, device=x.device)
     ws = _workspace(_L().nv_layernorm_bwd_workspace_bytes(d), x.device, "ln")
     _lib.check(_L().nv_layernorm_bwd_f32(dy.data_ptr(), x.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
-                                         gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), M, d, 0, _st()), "nv_layernorm_bwd_f32")
+                                         gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), M, d, acc, _st()), "nv_layernorm_bwd_f32")
     return dx, gw, gb
 
 
-def colsum_f32(x):
+def colsum_f32(x, out=None, accumulate=False):
     M, d = x.shape
-    out = torch.empty((d,), dtype=F32, device=x.device)
-    _lib.check(_L().nv_colsum_f32(x.data_ptr(), out.data_ptr(), M, d, x.stride(0), 0, _st()), "nv_colsum_f32")
+    if out is None:
+        out = torch.empty((d,), dtype=F32, device=x.device)
+    _lib.check(_L().nv_colsum_f32(x.data_ptr(), out.data_ptr(), M, d, x.stride(0), 1 if accumulate else 0, _st()), "nv_colsum_f32")
     return out
 
 
@@ -316,6 +325,12 @@ def add_f32(a, b, bcast_rows=False):
     return out
 
 
+def mul_f32(a, b):
+    out = torch.empty_like(a)
+    _lib.check(_L().nv_mul_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _st()), "nv_mul_f32")
+    return out
+
+
 def rowscale_f32(x, s):
     """x [rows, d] * s [rows] (fp32 0/1 masks)."""
     out = torch.empty_like(x)
@@ -333,11 +348,12 @@ def gather_add_f32(src, idx_i32, base=None):
     return out
 
 
-def index_sum_f32(src, idx_i32, R):
-    """dst[r] = sum_{i: idx[i]==r} src[i]  for r < R."""
+def index_sum_f32(src, idx_i32, R, out=None, accumulate=False):
+    """dst[r] (+)= sum_{i: idx[i]==r} src[i]  for r < R."""
     n, d = src.shape
-    dst = torch.empty((R, d), dtype=F32, device=src.device)
-    _lib.check(_L().nv_index_sum_f32(src.data_ptr(), idx_i32.data_ptr(), dst.data_ptr(), n, R, d, 0, _st()), "nv_index_sum_f32")
+    dst = out if out is not None else torch.empty((R, d), dtype=F32, device=src.device)
+    _lib.check(_L().nv_index_sum_f32(src.data_ptr(), idx_i32.data_ptr(), dst.data_ptr(), n, R, d, 1 if accumulate else 0, _st()),
+               "nv_index_sum_f32")
     return dst
 
 

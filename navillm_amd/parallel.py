@@ -1,0 +1,152 @@
+"""Data parallelism over the 8 GPUs of one MI355X node: one process per GPU, RCCL through
+torch.distributed (backend "nccl" is RCCL on ROCm).  Replaces tools/distributed.py:105-183 (process
+group from the torchrun env) and the DDP wrapper of tools/optims.py:52-54.
+
+Design for xGMI (7 point-to-point links per GPU, no switch): few, large messages.  The flat
+gradient buffers (navillm_amd/flat.py) make every decoder layer one contiguous ~400 MB bf16 slice:
+as soon as layer i's backward has accumulated its weight gradients, its slice is all-reduced on a
+side stream while layers i-1..0 are still computing -- 32 large collectives per synced backward, no
+bucket copies, no `find_unused_parameters` bitmap (unused parameters simply carry zero gradients in
+the flat buffer; which is what DDP's flag achieves for `og_head`, nav_model.py:78-80).
+
+`no_sync()` and `.module` follow the DDP protocol the agent relies on (mp3d_agent.py:661-676).
+"""
+import contextlib
+import os
+import torch
+import torch.distributed as dist
+
+
+def world_info_from_env():
+    """tools/distributed.py:38-60 (torchrun variables only)."""
+    return int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_distributed_device(backend=None):
+    """-> (device, rank, world_size). env:// rendezvous, one GPU per process."""
+    local_rank, rank, world = world_info_from_env()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+        backend = backend or "nccl"
+    else:
+        device = torch.device("cpu")
+        backend = backend or "gloo"
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = device
+        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank, **kw)
+    return device, rank, world
+
+
+def _allreduce_mean_(t, group=None, async_op=False):
+    """In-place mean over ranks. RCCL has a native AVG; gloo (CPU tests) sums then scales."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "nccl":
+        return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+    w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=False)
+    t.div_(world)
+    return w
+
+
+class GradSlices:
+    """The ordered list of contiguous gradient slices exchanged per synced backward."""
+
+    def __init__(self, store):
+        self.store = store
+        lm = store.grad["lm"]
+        L = store.cfg.num_layers
+        first_s, _ = store.layer_slice(0)
+        _, last_e = store.layer_slice(L - 1)
+        self.layer = [lm[s:e] for (s, e) in (store.layer_slice(i) for i in range(L))]
+        self.rest = [lm[:first_s], lm[last_e:], store.grad["f32"]]   # embeddings | norm+lm_head+heads | fp32 side
+
+    def all_slices(self):
+        return self.layer + self.rest
+
+
+class NavDataParallel(torch.nn.Module):
+    def __init__(self, module, group=None, overlap=True):
+        super().__init__()
+        self.module = module
+        self.group = group
+        self.overlap = overlap
+        self.require_sync = True
+        self.slices = GradSlices(module.store)
+        self._comm_stream = torch.cuda.Stream() if module.store.device.type == "cuda" else None
+        self._pending = []
+        self._queued = False
+        module._dp = self
+        self.broadcast_parameters()
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    @torch.no_grad()
+    def broadcast_parameters(self):
+        """DDP's initial rank-0 broadcast."""
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            for t in self.module.store.param.values():
+                dist.broadcast(t, src=0, group=self.group)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        old, self.require_sync = self.require_sync, False
+        try:
+            yield
+        finally:
+            self.require_sync = old
+
+    # ---- hooks called from LlamaStack.backward
+    def _active(self):
+        return self.require_sync and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def on_backward_begin(self):
+        if not self._active() or self._queued:
+            return
+        self._queued = True
+        torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+
+    def on_layer_done(self, i):
+        if not self._active() or not self.overlap:
+            return
+        self._launch(self.slices.layer[i])
+
+    def _launch(self, t):
+        if self._comm_stream is not None:
+            self._comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm_stream):
+                self._pending.append(_allreduce_mean_(t, self.group, async_op=True))
+        else:
+            _allreduce_mean_(t, self.group)
+
+    def _finalize(self):
+        """end of the autograd pass: reduce what is left, then join the side stream."""
+        self._queued = False
+        todo = self.slices.rest if self.overlap else self.slices.all_slices()
+        for t in todo:
+            self._launch(t)
+        for w in self._pending:
+            if w is not None:
+                w.wait()
+        self._pending = []
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    @torch.no_grad()
+    def sync_gradients(self):
+        """Explicit one-shot reduction (e.g. once per optimizer step instead of per synced backward;
+        mathematically the same mean)."""
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            for t in self.slices.all_slices():
+                _allreduce_mean_(t, self.group)
+
+
+def broadcast_task_id(task_id, device, group=None):
+    """tasks/loaders.py:176-179: rank 0 picks the task, everyone follows (1 x int64)."""
+    t = torch.tensor([task_id], dtype=torch.int64, device=device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(t, src=0, group=group)
+    return int(t.item())

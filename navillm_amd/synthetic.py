@@ -1,0 +1,244 @@
+"""Synthetic episode driver: reproduces the CALL PATTERN of `MP3DAgent.rollout`
+(tasks/agents/mp3d_agent.py:593-964) on fabricated Matterport-shaped episodes (SURVEY.md §8d,
+Appendix B).  No MatterSim, no datasets, no tokenizer files: views are N(0,1) features with the
+simulator's 36 heading/elevation angles, the map is a random walk in 3-D, the instruction is 512
+random in-vocab token ids wrapped in the real R2R prompt template.
+
+Per nav step, in the reference's order:
+  model('panorama') -> masked mean-pool + map update (detached) -> gmap/vp collation ->
+  prompt -> model('navigation') -> CE_sum * w / B / accum -> backward (inside no_sync unless
+  last step) -> teacher action -> history append -> move.
+"""
+import contextlib
+import math
+import zlib
+
+import numpy as np
+import torch
+
+from . import ops
+from .graph import GraphMap, get_angle_fts
+from .prompts import navigation_prompt
+
+
+# --------------------------------------------------------------------------- stub tokenizer
+class StubTokenizer:
+    """whitespace/word-hash tokenizer for the fixed template text (roughly one token per word;
+    the real Llama tokenizer gives ~1.3) with the five special tokens mapped to their real ids."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.special = {"<cand>": cfg.cand_token_id, "<hist>": cfg.hist_token_id, "<obj>": cfg.obj_token_id,
+                        "<cls_1>": cfg.cls_token_ids[0], "<cls_2>": cfg.cls_token_ids[1]}
+        self.bos, self.pad = 1, cfg.pad_token_id
+
+    def _word(self, w):
+        return 3 + zlib.crc32(w.encode()) % (self.cfg.base_vocab_size - 3)
+
+    def encode(self, prompt, instr_ids=None, placeholder="{INSTR}"):
+        ids = [self.bos]
+        for w in prompt.split():
+            if w == placeholder and instr_ids is not None:
+                ids.extend(instr_ids)
+            elif w in self.special:
+                ids.append(self.special[w])
+            else:
+                ids.append(self._word(w))
+        return ids
+
+    def pad_left(self, seqs, max_length=1024):
+        seqs = [s[-max_length:] for s in seqs]              # truncation_side='left'
+        S = max(len(s) for s in seqs)
+        ids = torch.full((len(seqs), S), self.pad, dtype=torch.int64)
+        am = torch.zeros((len(seqs), S), dtype=torch.int64)
+        for i, s in enumerate(seqs):
+            ids[i, S - len(s):] = torch.tensor(s)
+            am[i, S - len(s):] = 1
+        return ids, am
+
+
+# --------------------------------------------------------------------------- view geometry
+def view_angle_features(angle_feat_size=4):
+    """36 discretised views: 12 headings x 3 elevations (tasks/datasets/mp3d_envs.py:42-62) + [1,1,1] box."""
+    h = np.array([(ix % 12) * math.radians(30) for ix in range(36)])
+    e = np.array([(ix // 12 - 1) * math.radians(30) for ix in range(36)])
+    return np.concatenate([get_angle_fts(h, e, angle_feat_size), np.ones((36, 3), np.float32)], 1)
+
+
+class SyntheticEpisodes:
+    """B lock-step episodes on one rank."""
+
+    def __init__(self, cfg, batch_size, seed, instr_len=512, n_views=36, device=None):
+        self.cfg, self.B, self.N = cfg, batch_size, n_views
+        self.rng = np.random.RandomState(seed)
+        self.tgen = torch.Generator().manual_seed(seed)
+        self.device = device
+        self.tok = StubTokenizer(cfg)
+        self.instr_len = instr_len
+        self.loc_fts = torch.from_numpy(view_angle_features(cfg.angle_feat_size)[:n_views])
+        self.reset()
+
+    def reset(self):
+        B = self.B
+        self.t = 0
+        self.instr = [self.rng.randint(3, self.cfg.base_vocab_size, size=self.instr_len).tolist() for _ in range(B)]
+        self.pos = [{f"e{b}_n0": self.rng.randn(3) * 2.0} for b in range(B)]
+        self.cur = [f"e{b}_n0" for b in range(B)]
+        self.heading = [float(self.rng.rand() * 2 * math.pi) for _ in range(B)]
+        self.gmaps = [GraphMap(self.cur[b]) for b in range(B)]
+        self.history = [[] for _ in range(B)]
+        self.hist_vis = [[] for _ in range(B)]
+        self.n_nodes = [1] * B
+        self.obs = [self._observe(b) for b in range(B)]
+        for b in range(B):
+            self.gmaps[b].update_graph(self.obs[b])
+
+    def _observe(self, b):
+        """new panorama at the current node: K candidates (mostly new frontier nodes, sometimes a known one)."""
+        K = int(self.rng.randint(2, 9))
+        cands = []
+        known = [v for v in self.pos[b] if v != self.cur[b]]
+        for j in range(K):
+            if known and self.rng.rand() < 0.25:
+                vp = known[self.rng.randint(len(known))]
+                if any(c["viewpointId"] == vp for c in cands):
+                    continue
+            else:
+                vp = f"e{b}_n{self.n_nodes[b]}"
+                self.n_nodes[b] += 1
+                self.pos[b][vp] = self.pos[b][self.cur[b]] + self.rng.randn(3) * np.array([2.0, 2.0, 0.3])
+            cands.append({"viewpointId": vp, "position": self.pos[b][vp], "pointId": j})
+        return {"viewpoint": self.cur[b], "position": self.pos[b][self.cur[b]], "heading": self.heading[b],
+                "elevation": 0.0, "candidate": cands}
+
+    # ---- tensor builders (mp3d_agent.py:143-212, 264-371)
+    def panorama_inputs(self):
+        B, N, F = self.B, self.N, self.cfg.image_feat_size
+        x = torch.randn(B, N, F, generator=self.tgen)
+        nav = torch.zeros(B, N, dtype=torch.int64)
+        cand_vpids = []
+        for b, ob in enumerate(self.obs):
+            k = len(ob["candidate"])
+            nav[b, :k] = 1
+            cand_vpids.append([c["viewpointId"] for c in ob["candidate"]])
+        d = self.device
+        return {"view_img_fts": x.to(d), "loc_fts": self.loc_fts.unsqueeze(0).repeat(B, 1, 1).to(d),
+                "nav_types": nav.to(d), "view_lens": torch.full((B,), N, dtype=torch.int64).to(d),
+                "cand_vpids": cand_vpids}
+
+    def update_maps(self, pano_embeds, pano_masks, cand_vpids):
+        avg = ops.masked_mean_f32(pano_embeds.detach().contiguous(), pano_masks.to(torch.float32).contiguous())
+        pe = pano_embeds.detach()
+        for b, gmap in enumerate(self.gmaps):
+            gmap.node_step_ids[self.cur[b]] = self.t + 1
+            gmap.update_node_embed(self.cur[b], avg[b], rewrite=True)
+            for j, vp in enumerate(cand_vpids[b]):
+                if not gmap.graph.visited(vp):
+                    gmap.update_node_embed(vp, pe[b, j])
+
+    def nav_inputs(self, pano_embeds, pano_masks, cand_vpids):
+        B, d, dev = self.B, self.cfg.hidden_size, self.device
+        vpids, vis, steps, embeds, posf = [], [], [], [], []
+        for b, gmap in enumerate(self.gmaps):
+            visited = [k for k in gmap.node_positions if gmap.graph.visited(k)]
+            unvisited = [k for k in gmap.node_positions if not gmap.graph.visited(k)]
+            gv = [None] + visited + unvisited                                  # enc_full_graph (configs/multi.yaml:109)
+            vpids.append(gv)
+            vis.append([0] + [1] * len(visited) + [0] * len(unvisited))
+            steps.append([gmap.node_step_ids.get(v, 0) for v in gv])
+            e = [gmap.get_node_embed(v) for v in gv[1:]]
+            embeds.append(torch.stack([torch.zeros_like(e[0])] + e, 0))
+            posf.append(gmap.get_pos_fts(self.cur[b], gv, self.heading[b], 0.0))
+        G = max(len(v) for v in vpids)
+        gmask = torch.zeros(B, G, dtype=torch.bool)
+        gvis = torch.zeros(B, G, dtype=torch.bool)
+        gstep = torch.zeros(B, G, dtype=torch.int64)
+        gpos = torch.zeros(B, G, 7)
+        gimg = torch.zeros(B, G, d, device=dev)
+        for b in range(B):
+            n = len(vpids[b])
+            gmask[b, :n] = True
+            gvis[b, :n] = torch.tensor(vis[b]).bool()
+            gstep[b, :n] = torch.tensor(steps[b])
+            gpos[b, :n] = torch.from_numpy(posf[b])
+            gimg[b, :n] = embeds[b]
+        Nv = pano_embeds.shape[1] + 1
+        vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
+        pm = torch.cat([torch.ones_like(pano_masks[:, :1]), pano_masks], 1)
+        vp_pos = np.zeros((B, Nv, 14), dtype=np.float32)
+        for b, gmap in enumerate(self.gmaps):
+            cf = gmap.get_pos_fts(self.cur[b], cand_vpids[b], self.heading[b], 0.0)
+            sf = gmap.get_pos_fts(self.cur[b], [gmap.start_vp], self.heading[b], 0.0)
+            vp_pos[b, :, :7] = sf
+            vp_pos[b, 1:len(cf) + 1, 7:] = cf
+        return {"gmap_vpids": vpids, "gmap_img_embeds": gimg, "gmap_step_ids": gstep.to(dev), "gmap_pos_fts": gpos.to(dev),
+                "gmap_visited_masks": gvis.to(dev), "gmap_masks": gmask.to(dev), "vp_img_embeds": vp_img,
+                "pano_masks": pm, "vp_pos_fts": torch.from_numpy(vp_pos).to(dev),
+                "vp_nav_masks": torch.ones(B, Nv, dtype=torch.bool, device=dev),
+                "vp_cand_vpids": [[None] + x for x in cand_vpids], "hist_vis": self.hist_vis, "history": self.history,
+                "data_type": ["r2r"] * B, "instruction": ["{INSTR}"] * B,
+                "_gmask_cpu": gmask, "_gvis_cpu": gvis}
+
+    def tokenise(self, nav, cls_token):
+        cand_nums = (nav["_gmask_cpu"] & ~nav["_gvis_cpu"]).sum(-1)
+        seqs = []
+        for b in range(self.B):
+            p = navigation_prompt("r2r", "{INSTR}", len(self.history[b]), int(cand_nums[b]), cls_token)
+            seqs.append(self.tok.encode(p, self.instr[b]))
+        return self.tok.pad_left(seqs)
+
+    def teacher_targets(self, nav, last):
+        """a random unvisited current candidate's map slot (0 = stop on the last step)."""
+        tg = []
+        for b in range(self.B):
+            if last:
+                tg.append(0)
+                continue
+            gv = nav["gmap_vpids"][b]
+            opts = [gv.index(c["viewpointId"]) for c in self.obs[b]["candidate"]
+                    if not self.gmaps[b].graph.visited(c["viewpointId"])]
+            tg.append(opts[self.rng.randint(len(opts))] if opts else 0)
+        return torch.tensor(tg, dtype=torch.int64)
+
+    def advance(self, nav, actions, fuse_embeds):
+        for b in range(self.B):
+            a = int(actions[b])
+            if a == -100:
+                continue
+            self.history[b].append("<hist>")
+            self.hist_vis[b].append(fuse_embeds[b, a])
+            if a > 0:
+                self.cur[b] = nav["gmap_vpids"][b][a]
+                self.heading[b] = float(self.rng.rand() * 2 * math.pi)
+        self.t += 1
+        self.obs = [self._observe(b) for b in range(self.B)]
+        for b in range(self.B):
+            self.gmaps[b].update_graph(self.obs[b])
+
+
+def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accum=1):
+    """One iteration of the rollout loop for all B episodes. Returns (loss tensor or None, logits)."""
+    inner = model.module if hasattr(model, "module") else model
+    ctx = contextlib.nullcontext
+    if train and hasattr(model, "no_sync") and not last:
+        ctx = model.no_sync
+    with ctx():
+        pin = ep.panorama_inputs()
+        pano = model("panorama", pin)
+        pe, pm = pano["pano_embeds"], pano["pano_masks"]
+        ep.update_maps(pe, pm, pin["cand_vpids"])
+        nav = ep.nav_inputs(pe, pm, pin["cand_vpids"])
+        ids, am = ep.tokenise(nav, inner.lang_model.cls_token[0])
+        nav["input_ids"], nav["attention_mask"] = ids, am
+        out = model("navigation", nav)
+        logits = out["fuse_logits"]
+        targets = ep.teacher_targets(nav, last)
+        loss = None
+        if train:
+            loss = criterion(logits, targets.to(logits.device)) * loss_weight / ep.B / accum
+            loss.backward()
+            actions = targets
+        else:
+            actions = logits.float().argmax(1).cpu()
+        ep.advance(nav, actions, out["fuse_embeds"])
+    return loss, logits
