@@ -463,7 +463,7 @@ int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_star
     p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = kv_start;
     p.B = B; p.S = S; p.H = H; p.ld = 3 * H * HD;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + 127) / 128, B * H), dim3(256), 65536, (hipStream_t)stream, p);
+    NV_LAUNCH(attn_fwd_kernel, dim3((S + 127) / 128, B * H), dim3(256), 65536, (hipStream_t)stream, p);
     return nv_check_launch();
 }
 
@@ -484,14 +484,14 @@ int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const f
     hipStream_t st = (hipStream_t)stream;
     float* dsum = (float*)workspace;
     const long items = (long)B * S * H;
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const bf16_t*)dout,
+    NV_LAUNCH(attn_bwd_prep_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const bf16_t*)dout,
                        (const bf16_t*)out, dsum, B, S, H);
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.lse2 = (float*)lse2; p.dsum = dsum; p.dqkv = (bf16_t*)dqkv;
     p.kv_start = kv_start; p.B = B; p.S = S; p.H = H; p.ld = 3 * H * HD;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((S + 63) / 64, B * H), dim3(256), 32768, st, p);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((S + 63) / 64, B * H), dim3(256), 65536, st, p);
+    NV_LAUNCH(attn_bwd_dkv_kernel, dim3((S + 63) / 64, B * H), dim3(256), 32768, st, p);
+    NV_LAUNCH(attn_bwd_dq_kernel, dim3((S + 63) / 64, B * H), dim3(256), 65536, st, p);
     return nv_check_launch();
 }
 

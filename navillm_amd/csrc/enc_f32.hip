@@ -355,7 +355,7 @@ int nv_gemm_f32(int layout, const float* A, const float* B, float* C, const floa
         case 2: p.sam = 1; p.sak = lda; p.sbn = 1; p.sbk = ldb; break;
         default: return NV_ERR_ARG;
     }
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + FBN - 1) / FBN, (M + FBM - 1) / FBM), dim3(256), 0, (hipStream_t)stream, p);
+    NV_LAUNCH(gemm_f32_kernel, dim3((N + FBN - 1) / FBN, (M + FBM - 1) / FBM), dim3(256), 0, (hipStream_t)stream, p);
     return nv_check_launch();
 }
 
@@ -363,7 +363,7 @@ int nv_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* 
                          float eps, void* stream) {
     if (!x || !w || !b || !y) return NV_ERR_ARG;
     if (M == 0) return NV_OK;
-    hipLaunchKernelGGL(layernorm_fwd_kernel<4>, dim3(M), dim3(256), 0, (hipStream_t)stream, x, w, b, y, mean, rstd, d, eps);
+    NV_LAUNCH(layernorm_fwd_kernel<4>, dim3(M), dim3(256), 0, (hipStream_t)stream, x, w, b, y, mean, rstd, d, eps);
     return nv_check_launch();
 }
 
@@ -378,16 +378,16 @@ int nv_layernorm_bwd_f32(const float* dy, const float* x, const float* w, const 
     float* dgp = (float*)workspace;
     float* dbp = dgp + (size_t)128 * d;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(P), dim3(256), 0, st, dy, x, w, mean, rstd, dx, dgp, dbp, M, d);
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((d + 255) / 256), dim3(256), 0, st, dgp, gw, P, d, (long)d, accumulate);
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((d + 255) / 256), dim3(256), 0, st, dbp, gb, P, d, (long)d, accumulate);
+    NV_LAUNCH(layernorm_bwd_kernel<4>, dim3(P), dim3(256), 0, st, dy, x, w, mean, rstd, dx, dgp, dbp, M, d);
+    NV_LAUNCH(colsum_f32_kernel, dim3((d + 255) / 256), dim3(256), 0, st, dgp, gw, P, d, (long)d, accumulate);
+    NV_LAUNCH(colsum_f32_kernel, dim3((d + 255) / 256), dim3(256), 0, st, dbp, gb, P, d, (long)d, accumulate);
     return nv_check_launch();
 }
 
 // out[c] (+)= sum_m x[m,c]   (bias gradients)
 int nv_colsum_f32(const float* x, float* out, int M, int d, int ld, int accumulate, void* stream) {
     if (!x || !out) return NV_ERR_ARG;
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, M, d, (long)ld,
+    NV_LAUNCH(colsum_f32_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, M, d, (long)ld,
                        accumulate);
     return nv_check_launch();
 }
@@ -403,7 +403,7 @@ int nv_mha_fwd_f32(const float* qkv, const int* lens, float* out, float* P, int 
     if (lds > 160 * 1024) return NV_ERR_SHAPE;
     if (hipFuncSetAttribute((const void*)mha_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return NV_ERR_LAUNCH;
-    hipLaunchKernelGGL(mha_fwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, lens, out, P, N, heads, hd);
+    NV_LAUNCH(mha_fwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, lens, out, P, N, heads, hd);
     return nv_check_launch();
 }
 
@@ -415,58 +415,58 @@ int nv_mha_bwd_f32(const float* qkv, const float* P, const float* dout, float* d
     if (lds > 160 * 1024) return NV_ERR_SHAPE;
     if (hipFuncSetAttribute((const void*)mha_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return NV_ERR_LAUNCH;
-    hipLaunchKernelGGL(mha_bwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, P, dout, dqkv, N, heads, hd);
+    NV_LAUNCH(mha_bwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, P, dout, dqkv, N, heads, hd);
     return nv_check_launch();
 }
 
 int nv_gelu_fwd_f32(const float* x, float* y, long n, void* stream) {
     if (!x || !y) return NV_ERR_ARG;
     if (n == 0) return NV_OK;
-    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    NV_LAUNCH(gelu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
     return nv_check_launch();
 }
 int nv_gelu_bwd_f32(const float* x, const float* dy, float* dx, long n, void* stream) {
     if (!x || !dy || !dx) return NV_ERR_ARG;
     if (n == 0) return NV_OK;
-    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
+    NV_LAUNCH(gelu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n);
     return nv_check_launch();
 }
 int nv_add_f32(const float* a, const float* b, float* out, long n, int d, int b_bcast, void* stream) {
     if (!a || !b || !out) return NV_ERR_ARG;
     if (n == 0) return NV_OK;
-    hipLaunchKernelGGL(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, d, b_bcast);
+    NV_LAUNCH(add_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, d, b_bcast);
     return nv_check_launch();
 }
 int nv_mul_f32(const float* a, const float* b, float* out, long n, void* stream) {
     if (!a || !b || !out) return NV_ERR_ARG;
     if (n == 0) return NV_OK;
-    hipLaunchKernelGGL(mul_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    NV_LAUNCH(mul_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
     return nv_check_launch();
 }
 int nv_rowscale_f32(const float* x, const float* s, float* out, long rows, int d, void* stream) {
     if (!x || !s || !out) return NV_ERR_ARG;
     if (rows == 0) return NV_OK;
-    hipLaunchKernelGGL(rowscale_f32_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, x, s, out, rows * d, d);
+    NV_LAUNCH(rowscale_f32_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, x, s, out, rows * d, d);
     return nv_check_launch();
 }
 int nv_gather_add_f32(const float* src, const int* idx, const float* base, float* out, long rows, int d, void* stream) {
     if (!src || !idx || !out) return NV_ERR_ARG;
     if (rows == 0) return NV_OK;
-    hipLaunchKernelGGL(gather_add_f32_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, src, idx, base, out,
+    NV_LAUNCH(gather_add_f32_kernel, dim3(grid_for(rows * d)), dim3(256), 0, (hipStream_t)stream, src, idx, base, out,
                        rows * d, d);
     return nv_check_launch();
 }
 int nv_index_sum_f32(const float* src, const int* idx, float* dst, int n, int R, int d, int accumulate, void* stream) {
     if (!src || !idx || !dst) return NV_ERR_ARG;
     if (R == 0) return NV_OK;
-    hipLaunchKernelGGL(index_sum_f32_kernel, dim3((d + 255) / 256, R), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, R,
+    NV_LAUNCH(index_sum_f32_kernel, dim3((d + 255) / 256, R), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, R,
                        d, accumulate);
     return nv_check_launch();
 }
 int nv_masked_mean_f32(const float* x, const float* mask, float* out, int B, int N, int d, void* stream) {
     if (!x || !mask || !out) return NV_ERR_ARG;
     if (B == 0) return NV_OK;
-    hipLaunchKernelGGL(masked_mean_kernel, dim3((d + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, mask, out, N, d);
+    NV_LAUNCH(masked_mean_kernel, dim3((d + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, mask, out, N, d);
     return nv_check_launch();
 }
 

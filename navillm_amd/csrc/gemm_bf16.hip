@@ -209,7 +209,7 @@ int launch(const GemmArgs& p, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(WGM * WGN * 64), LDS, st, p);
+    NV_LAUNCH(kern, dim3(tiles), dim3(WGM * WGN * 64), LDS, st, p);
     return nv_check_launch();
 }
 

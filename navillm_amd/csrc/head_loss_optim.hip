@@ -214,7 +214,7 @@ extern "C" {
 int nv_head_fwd_bf16(const void* x, const void* W, const void* bias, void* y, int B, int d, int N, void* stream) {
     if (!x || !W || !bias || !y || (d & 7)) return NV_ERR_ARG;
     if (B == 0) return NV_OK;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)W,
+    NV_LAUNCH(head_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)W,
                        (const bf16_t*)bias, (bf16_t*)y, d, N);
     return nv_check_launch();
 }
@@ -223,9 +223,9 @@ int nv_head_bwd_bf16(const void* dy, const void* x, const void* W, void* dx, voi
     if (!dy || !x || !W || !dx || !gW || !gb) return NV_ERR_ARG;
     if (B == 0) return NV_OK;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(head_bwd_dx_kernel, dim3((d + 255) / 256, B), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)W,
+    NV_LAUNCH(head_bwd_dx_kernel, dim3((d + 255) / 256, B), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)W,
                        (bf16_t*)dx, d, N);
-    hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((d + 255) / 256, N), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
+    NV_LAUNCH(head_bwd_dw_kernel, dim3((d + 255) / 256, N), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)x,
                        (bf16_t*)gW, (bf16_t*)gb, B, d, N);
     return nv_check_launch();
 }
@@ -233,7 +233,7 @@ int nv_action_ce_bf16(const void* logits, const long* targets, float* loss_rows,
                       void* stream) {
     if (!logits || !targets || !loss_rows) return NV_ERR_ARG;
     if (B == 0) return NV_OK;
-    hipLaunchKernelGGL(action_ce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)logits, targets, loss_rows,
+    NV_LAUNCH(action_ce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)logits, targets, loss_rows,
                        (bf16_t*)dlogits, G, gscale);
     return nv_check_launch();
 }
@@ -241,7 +241,7 @@ int nv_lm_ce_bf16(void* logits, const int* labels, float* loss_rows, int M, int 
                   float gscale, int write_grad, void* stream) {
     if (!logits || !labels || !loss_rows) return NV_ERR_ARG;
     if (M == 0) return NV_OK;
-    hipLaunchKernelGGL(lm_ce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (bf16_t*)logits, labels, loss_rows, V, ldl,
+    NV_LAUNCH(lm_ce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (bf16_t*)logits, labels, loss_rows, V, ldl,
                        special0, nspecial, gscale, write_grad);
     return nv_check_launch();
 }
@@ -252,14 +252,14 @@ int nv_sumsq(const void* g, long n, int is_bf16, float* partial, int* n_partial,
     const int blocks = grid_for(is_bf16 ? (n + 7) / 8 : n);
     *n_partial = blocks;
     if (is_bf16)
-        hipLaunchKernelGGL(sumsq_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, n, partial);
+        NV_LAUNCH(sumsq_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, n, partial);
     else
-        hipLaunchKernelGGL(sumsq_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)g, n, partial);
+        NV_LAUNCH(sumsq_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)g, n, partial);
     return nv_check_launch();
 }
 int nv_clip_coef(const float* partial, int n_partial, float max_norm, float* out2, void* stream) {
     if (!partial || !out2) return NV_ERR_ARG;
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n_partial, max_norm, out2);
+    NV_LAUNCH(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, n_partial, max_norm, out2);
     return nv_check_launch();
 }
 int nv_adamw(void* p, const void* g, void* m, void* v, long n, int is_bf16, double lr, double beta1, double beta2, double eps,
@@ -273,10 +273,10 @@ int nv_adamw(void* p, const void* g, void* m, void* v, long n, int is_bf16, doub
     const float epsf = (float)eps;
     const int blocks = grid_for(n, 256 * 16);
     if (is_bf16)
-        hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, (const bf16_t*)g,
+        NV_LAUNCH(adamw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)p, (const bf16_t*)g,
                            (bf16_t*)m, (bf16_t*)v, n, decay, w1, b2, w2, epsf, step_size, sbc2, clip);
     else
-        hipLaunchKernelGGL(adamw_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)p, (const float*)g,
+        NV_LAUNCH(adamw_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)p, (const float*)g,
                            (float*)m, (float*)v, n, decay, w1, b2, w2, epsf, step_size, sbc2, clip);
     return nv_check_launch();
 }

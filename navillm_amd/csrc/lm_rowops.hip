@@ -307,7 +307,7 @@ int nv_embed_vis_bf16(const void* table, const int* ids, const int* vis_idx, con
                       void* stream) {
     if (!table || !ids || !vis_idx || !out || (d & 7)) return NV_ERR_ARG;
     if (M == 0) return NV_OK;
-    hipLaunchKernelGGL(embed_vis_kernel, dim3(grid_for((long)M * d / 8)), dim3(256), 0, (hipStream_t)stream,
+    NV_LAUNCH(embed_vis_kernel, dim3(grid_for((long)M * d / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)table, ids, vis_idx, vis, (bf16_t*)out, M, d);
     return nv_check_launch();
 }
@@ -315,7 +315,7 @@ int nv_embed_vis_bf16(const void* table, const int* ids, const int* vis_idx, con
 int nv_vis_grad_f32(const void* dE, const int* vis_rows, float* dvis, int nvis, int d, void* stream) {
     if (!dE || !vis_rows || !dvis || (d & 7)) return NV_ERR_ARG;
     if (nvis == 0) return NV_OK;
-    hipLaunchKernelGGL(vis_grad_kernel, dim3(grid_for((long)nvis * d / 8)), dim3(256), 0, (hipStream_t)stream,
+    NV_LAUNCH(vis_grad_kernel, dim3(grid_for((long)nvis * d / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dE, vis_rows, dvis, nvis, d);
     return nv_check_launch();
 }
@@ -324,7 +324,7 @@ int nv_embed_grad_bf16(const void* dE, const int* uniq, const int* seg_off, cons
                        void* stream) {
     if (!dE || !uniq || !seg_off || !tok || !gtable || (d & 7)) return NV_ERR_ARG;
     if (n_uniq == 0) return NV_OK;
-    hipLaunchKernelGGL(embed_grad_kernel, dim3(n_uniq), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dE, uniq, seg_off,
+    NV_LAUNCH(embed_grad_kernel, dim3(n_uniq), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dE, uniq, seg_off,
                        tok, (bf16_t*)gtable, d);
     return nv_check_launch();
 }
@@ -332,7 +332,7 @@ int nv_embed_grad_bf16(const void* dE, const int* uniq, const int* seg_off, cons
 int nv_rmsnorm_fwd_bf16(const void* x, const void* w, void* y, float* rstd, int M, int d, float eps, void* stream) {
     if (!x || !w || !y || (d & 7)) return NV_ERR_ARG;
     if (M == 0) return NV_OK;
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel<4>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w,
+    NV_LAUNCH(rmsnorm_fwd_kernel<4>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)w,
                        (bf16_t*)y, rstd, d, eps);
     return nv_check_launch();
 }
@@ -346,10 +346,10 @@ int nv_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const floa
     if (d > 4 * 256 * 8) return NV_ERR_SHAPE;  // VEC=4 covers d <= 8192
     if (M == 0) return NV_OK;
     const int P = M < 512 ? M : 512;
-    hipLaunchKernelGGL((rmsnorm_bwd_kernel<4, 4>), dim3(P), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+    NV_LAUNCH((rmsnorm_bwd_kernel<4, 4>), dim3(P), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)resid_grad, (bf16_t*)dx, (float*)workspace, M,
                        d);
-    hipLaunchKernelGGL(dw_reduce_bf16_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    NV_LAUNCH(dw_reduce_bf16_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, (bf16_t*)gw, P, d);
     return nv_check_launch();
 }
@@ -358,7 +358,7 @@ int nv_rope_bf16(void* qkv, const void* cos_t, const void* sin_t, int M, int S, 
                  void* stream) {
     if (!qkv || !cos_t || !sin_t || (hd & 15) || S <= 0) return NV_ERR_ARG;
     if (M == 0) return NV_OK;
-    hipLaunchKernelGGL(rope_kernel, dim3(grid_for((long)M * 2 * H * hd / 16)), dim3(256), 0, (hipStream_t)stream,
+    NV_LAUNCH(rope_kernel, dim3(grid_for((long)M * 2 * H * hd / 16)), dim3(256), 0, (hipStream_t)stream,
                        (bf16_t*)qkv, (const bf16_t*)cos_t, (const bf16_t*)sin_t, M, S, H, hd, ld, backward ? -1.f : 1.f);
     return nv_check_launch();
 }
@@ -366,7 +366,7 @@ int nv_rope_bf16(void* qkv, const void* cos_t, const void* sin_t, int M, int S, 
 int nv_swiglu_fwd_bf16(const void* gu, void* h, int M, int ff, void* stream) {
     if (!gu || !h || (ff & 7)) return NV_ERR_ARG;
     if (M == 0) return NV_OK;
-    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for((long)M * ff / 8)), dim3(256), 0, (hipStream_t)stream,
+    NV_LAUNCH(swiglu_fwd_kernel, dim3(grid_for((long)M * ff / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)gu, (bf16_t*)h, M, ff);
     return nv_check_launch();
 }
@@ -374,7 +374,7 @@ int nv_swiglu_fwd_bf16(const void* gu, void* h, int M, int ff, void* stream) {
 int nv_swiglu_bwd_bf16(const void* gu, const void* dh, void* dgu, int M, int ff, void* stream) {
     if (!gu || !dh || !dgu || (ff & 7)) return NV_ERR_ARG;
     if (M == 0) return NV_OK;
-    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for((long)M * ff / 8)), dim3(256), 0, (hipStream_t)stream,
+    NV_LAUNCH(swiglu_bwd_kernel, dim3(grid_for((long)M * ff / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)gu, (const bf16_t*)dh, (bf16_t*)dgu, M, ff);
     return nv_check_launch();
 }
@@ -382,7 +382,7 @@ int nv_swiglu_bwd_bf16(const void* gu, const void* dh, void* dgu, int M, int ff,
 int nv_gather_rows_bf16(const void* src, const int* rows, void* out, int n, int d, void* stream) {
     if (!src || !rows || !out || (d & 7)) return NV_ERR_ARG;
     if (n == 0) return NV_OK;
-    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(grid_for((long)n * d / 8)), dim3(256), 0, (hipStream_t)stream,
+    NV_LAUNCH(gather_rows_bf16_kernel, dim3(grid_for((long)n * d / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, rows, (bf16_t*)out, n, d);
     return nv_check_launch();
 }
@@ -390,7 +390,7 @@ int nv_gather_rows_bf16(const void* src, const int* rows, void* out, int n, int 
 int nv_scale_bf16(const void* x, void* out, long n, float scale, void* stream) {
     if (!x || !out || (n & 7)) return NV_ERR_ARG;
     if (n == 0) return NV_OK;
-    hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+    NV_LAUNCH(scale_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                        (bf16_t*)out, n / 8, scale);
     return nv_check_launch();
 }
@@ -398,7 +398,7 @@ int nv_scale_bf16(const void* x, void* out, long n, float scale, void* stream) {
 int nv_scatter_rows_bf16(const void* src, const int* rows, void* dst, int n, int d, void* stream) {
     if (!src || !rows || !dst || (d & 7)) return NV_ERR_ARG;
     if (n == 0) return NV_OK;
-    hipLaunchKernelGGL(scatter_rows_bf16_kernel, dim3(grid_for((long)n * d / 8)), dim3(256), 0, (hipStream_t)stream,
+    NV_LAUNCH(scatter_rows_bf16_kernel, dim3(grid_for((long)n * d / 8)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, rows, (bf16_t*)dst, n, d);
     return nv_check_launch();
 }

@@ -90,6 +90,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// hipGetLastError() is per-thread and sticky across *every* runtime call, including the ones torch
+// makes (an hipEventQuery that returned hipErrorNotReady, ...): clear it before each launch so that the
+// status we report belongs to our own launch.
+#define NV_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 static inline int nv_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? NV_OK : NV_ERR_LAUNCH;
