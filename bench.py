@@ -142,6 +142,7 @@ def main():
     torch.manual_seed(seed)
     model = NavModel(nav_config=cfg, device=device, seed=0)   # same weights on every rank
     model.train()
+    model.reserve_activations(a.batch, a.instr_len + 256)
     opt = FlatAdamW(model, lr=a.lr)
     wrapped = NavDataParallel(model) if world > 1 else model
     crit = CrossEntropyLoss()

@@ -177,14 +177,21 @@ __global__ __launch_bounds__(NW * 64) void rmsnorm_bwd_kernel(const bf16_t* __re
     }
 }
 
-// gw[c] = bf16( gw[c] + bf16( sum_p part[p,c] ) )
+// gw[c] = bf16( gw[c] + bf16( sum_p part[p,c] ) ) ; block = 64 columns x 4 row slices
 __global__ __launch_bounds__(256) void dw_reduce_bf16_kernel(const float* __restrict__ part, bf16_t* __restrict__ gw, int P,
                                                              int d) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= d) return;
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(long)p * d + c];
-    gw[c] = f2bf(bf2f(gw[c]) + rbf(s));
+    if (c < d)
+        for (int p = sl; p < P; p += 4) s += part[(long)p * d + c];
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && c < d) {
+        s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        gw[c] = f2bf(bf2f(gw[c]) + rbf(s));
+    }
 }
 
 // ---------------------------------------------------------------- RoPE on packed qkv
@@ -345,11 +352,11 @@ int nv_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const floa
     if (!dy || !x || !w || !rstd || !dx || !gw || !workspace || (d & 7)) return NV_ERR_ARG;
     if (d > 4 * 256 * 8) return NV_ERR_SHAPE;  // VEC=4 covers d <= 8192
     if (M == 0) return NV_OK;
-    const int P = M < 512 ? M : 512;
+    const int P = M < 256 ? M : 256;
     NV_LAUNCH((rmsnorm_bwd_kernel<4, 4>), dim3(P), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)resid_grad, (bf16_t*)dx, (float*)workspace, M,
                        d);
-    NV_LAUNCH(dw_reduce_bf16_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+    NV_LAUNCH(dw_reduce_bf16_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, (bf16_t*)gw, P, d);
     return nv_check_launch();
 }

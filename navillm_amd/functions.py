@@ -249,69 +249,130 @@ class EmbedVis(torch.autograd.Function):
         return dvis, None, None, None, None, None, None
 
 
+class ActivationArena:
+    """Persistent HBM arena for the decoder stack's saved activations and backward scratch.
+
+    MI355X-first memory plan: with 288 GB per GPU there is no reason to churn a caching allocator with
+    ~350 differently-sized tensors per step whose sizes change whenever the prompt grows by one history
+    token (that churn cost 25% of the step in hipMalloc stalls, profiles/r01_*).  One slab, sized for
+    M_cap = B*S rounded up to 2048 rows, carved once into per-layer views; a step just slices [:M].
+    A later LM forward reuses the slab, so backward must run before the next forward of the same model
+    (true for the rollout loop: every loss is followed by backward(), mp3d_agent.py:756,824,866,902)."""
+
+    LAYER_FIELDS = (("n1", 1, 0), ("qkv", 3, 0), ("attn", 1, 0), ("x1", 1, 0), ("n2", 1, 0), ("gu", 0, 2), ("h", 0, 1),
+                    ("x2", 1, 0))
+    SCRATCH_FIELDS = (("dh", 0, 1), ("dgu", 0, 2), ("dn2", 1, 0), ("dx1", 1, 0), ("dattn", 1, 0), ("dqkv", 3, 0),
+                      ("dn1", 1, 0), ("dxa", 1, 0), ("dxb", 1, 0))
+
+    def __init__(self, cfg, device):
+        self.cfg, self.device = cfg, device
+        self.cap = 0
+        self.generation = 0
+        self.layers, self.scratch = [], {}
+
+    def reserve(self, M):
+        if M <= self.cap:
+            return
+        cfg = self.cfg
+        cap = (M + 2047) // 2048 * 2048
+        d, ff, L, H = cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.num_heads
+        self.layers, self.scratch, self.slab = [], {}, None      # drop the old slab before allocating the new one
+        per_layer = sum(cap * (a * d + b * ff) for _, a, b in self.LAYER_FIELDS)
+        per_scr = sum(cap * (a * d + b * ff) for _, a, b in self.SCRATCH_FIELDS)
+        self.slab = torch.empty(L * per_layer + per_scr, dtype=BF16, device=self.device)
+        self.fslab = torch.empty(L * (2 * cap + cap * H), dtype=F32, device=self.device)
+        off = 0
+        foff = 0
+        for _ in range(L):
+            rec = {}
+            for name, a, b in self.LAYER_FIELDS:
+                w = a * d + b * ff
+                rec[name] = self.slab[off:off + cap * w].view(cap, w)
+                off += cap * w
+            rec["rstd1"] = self.fslab[foff:foff + cap]; foff += cap
+            rec["rstd2"] = self.fslab[foff:foff + cap]; foff += cap
+            rec["lse"] = self.fslab[foff:foff + cap * H]; foff += cap * H
+            self.layers.append(rec)
+        for name, a, b in self.SCRATCH_FIELDS:
+            w = a * d + b * ff
+            self.scratch[name] = self.slab[off:off + cap * w].view(cap, w)
+            off += cap * w
+        self.cap = cap
+
+
 class LlamaStack(torch.autograd.Function):
     """All decoder layers + final RMSNorm (HF LlamaModel reached from modified_lm.py:112-116).
-    Weight gradients are accumulated straight into the flat grad buffer by GEMM epilogues."""
+    Weight gradients are accumulated straight into the flat grad buffer by GEMM epilogues; activations
+    live in the model's ActivationArena."""
 
     @staticmethod
     def forward(ctx, E, model, B, S, kv_start_i32):
-        cfg, st = model.cfg, model.store
-        d, H, hd, eps = cfg.hidden_size, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps
+        cfg, st, ar = model.cfg, model.store, model.arena
+        H, hd, eps = cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps
+        M = B * S
+        ar.reserve(M)
+        ar.generation += 1
         x = E
-        saved = []
-        keep = torch.is_grad_enabled() or E.requires_grad
         for i in range(cfg.num_layers):
             p = f"lang_model.model.layers.{i}."
-            n1, rstd1 = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps)
-            qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i))
+            a = ar.layers[i]
+            n1, rstd1 = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps, out=a["n1"][:M], rstd=a["rstd1"][:M])
+            qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i), out=a["qkv"][:M])
             ops.rope_(qkv, model.rope_cos, model.rope_sin, S, H, hd)
-            attn, lse = ops.attn_fwd(qkv, kv_start_i32, B, S, H, hd)
-            x1 = ops.gemm_bf16(ops.NT, attn, st.p(p + "self_attn.o_proj.weight"), R=x, epilogue=ops.EPI_RESID)
-            n2, rstd2 = ops.rmsnorm_fwd(x1, st.p(p + "post_attention_layernorm.weight"), eps)
-            gu = ops.gemm_bf16(ops.NT, n2, st.gate_up(i))
-            h = ops.swiglu_fwd(gu)
-            x2 = ops.gemm_bf16(ops.NT, h, st.p(p + "mlp.down_proj.weight"), R=x1, epilogue=ops.EPI_RESID)
-            if keep:
-                saved.append((x, rstd1, n1, qkv, attn, lse, x1, rstd2, n2, gu, h))
-            x = x2
+            attn, lse = ops.attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=a["attn"][:M], lse2=a["lse"][:M * H].view(B, H, S))
+            x1 = ops.gemm_bf16(ops.NT, attn, st.p(p + "self_attn.o_proj.weight"), out=a["x1"][:M], R=x, epilogue=ops.EPI_RESID)
+            n2, rstd2 = ops.rmsnorm_fwd(x1, st.p(p + "post_attention_layernorm.weight"), eps, out=a["n2"][:M],
+                                        rstd=a["rstd2"][:M])
+            gu = ops.gemm_bf16(ops.NT, n2, st.gate_up(i), out=a["gu"][:M])
+            h = ops.swiglu_fwd(gu, out=a["h"][:M])
+            x = ops.gemm_bf16(ops.NT, h, st.p(p + "mlp.down_proj.weight"), out=a["x2"][:M], R=x1, epilogue=ops.EPI_RESID)
         Hs, rstdf = ops.rmsnorm_fwd(x, st.p("lang_model.model.norm.weight"), eps)
-        ctx.model, ctx.saved, ctx.final = model, saved, (x, rstdf)
+        ctx.model, ctx.E, ctx.rstdf = model, E, rstdf
         ctx.dims = (B, S, kv_start_i32)
+        ctx.generation = ar.generation
         return Hs
 
     @staticmethod
     def backward(ctx, dH):
         model = ctx.model
-        cfg, st = model.cfg, model.store
+        cfg, st, ar = model.cfg, model.store, model.arena
+        if ctx.generation != ar.generation:
+            raise RuntimeError("the LM activation arena was reused by a later forward before this backward ran; "
+                               "call backward() right after each loss (as the rollout loop does)")
         B, S, kvs = ctx.dims
-        H, hd = cfg.num_heads, cfg.head_dim
-        xL, rstdf = ctx.final
-        dx = ops.rmsnorm_bwd(_c(dH), xL, st.p("lang_model.model.norm.weight"), rstdf, st.g("lang_model.model.norm.weight"))
+        M = B * S
+        H, hd, L = cfg.num_heads, cfg.head_dim, cfg.num_layers
+        sc = {k: v[:M] for k, v in ar.scratch.items()}
+        xL = ar.layers[L - 1]["x2"][:M]
+        dx = ops.rmsnorm_bwd(_c(dH), xL, st.p("lang_model.model.norm.weight"), ctx.rstdf, st.g("lang_model.model.norm.weight"),
+                             out=sc["dxa"])
+        nxt = sc["dxb"]
         model._dp_begin_backward()
-        for i in reversed(range(cfg.num_layers)):
+        for i in reversed(range(L)):
             p = f"lang_model.model.layers.{i}."
-            x, rstd1, n1, qkv, attn, lse, x1, rstd2, n2, gu, h = ctx.saved[i]
-            ctx.saved[i] = None
+            a = ar.layers[i]
+            x = ctx.E if i == 0 else ar.layers[i - 1]["x2"][:M]
+            n1, qkv, attn, x1, n2, gu, h = (a[k][:M] for k in ("n1", "qkv", "attn", "x1", "n2", "gu", "h"))
+            lse = a["lse"][:M * H].view(B, H, S)
             Wd, Wo = st.p(p + "mlp.down_proj.weight"), st.p(p + "self_attn.o_proj.weight")
-            dh = ops.gemm_bf16(ops.NN, dx, Wd)
+            dh = ops.gemm_bf16(ops.NN, dx, Wd, out=sc["dh"])
             ops.gemm_bf16(ops.TN, dx, h, out=st.g(p + "mlp.down_proj.weight"), epilogue=ops.EPI_ACCUM)
-            dgu = ops.swiglu_bwd(gu, dh)
-            del dh, h
-            dn2 = ops.gemm_bf16(ops.NN, dgu, st.gate_up(i))
+            dgu = ops.swiglu_bwd(gu, dh, out=sc["dgu"])
+            dn2 = ops.gemm_bf16(ops.NN, dgu, st.gate_up(i), out=sc["dn2"])
             ops.gemm_bf16(ops.TN, dgu, n2, out=st.gate_up(i, grad=True), epilogue=ops.EPI_ACCUM)
-            del dgu, gu
-            dx1 = ops.rmsnorm_bwd(dn2, x1, st.p(p + "post_attention_layernorm.weight"), rstd2,
-                                  st.g(p + "post_attention_layernorm.weight"), resid_grad=dx)
-            dattn = ops.gemm_bf16(ops.NN, dx1, Wo)
+            dx1 = ops.rmsnorm_bwd(dn2, x1, st.p(p + "post_attention_layernorm.weight"), a["rstd2"][:M],
+                                  st.g(p + "post_attention_layernorm.weight"), resid_grad=dx, out=sc["dx1"])
+            dattn = ops.gemm_bf16(ops.NN, dx1, Wo, out=sc["dattn"])
             ops.gemm_bf16(ops.TN, dx1, attn, out=st.g(p + "self_attn.o_proj.weight"), epilogue=ops.EPI_ACCUM)
-            dqkv = ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd)
+            dqkv = ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd, dqkv=sc["dqkv"])
             ops.rope_(dqkv, model.rope_cos, model.rope_sin, S, H, hd, backward=True)
-            dn1 = ops.gemm_bf16(ops.NN, dqkv, st.qkv(i))
+            dn1 = ops.gemm_bf16(ops.NN, dqkv, st.qkv(i), out=sc["dn1"])
             ops.gemm_bf16(ops.TN, dqkv, n1, out=st.qkv(i, grad=True), epilogue=ops.EPI_ACCUM)
-            dx = ops.rmsnorm_bwd(dn1, x, st.p(p + "input_layernorm.weight"), rstd1, st.g(p + "input_layernorm.weight"),
-                                 resid_grad=dx1)
+            ndx = ops.rmsnorm_bwd(dn1, x, st.p(p + "input_layernorm.weight"), a["rstd1"][:M], st.g(p + "input_layernorm.weight"),
+                                  resid_grad=dx1, out=nxt)
+            dx, nxt = ndx, dx
             model._dp_layer_done(i)
-        return dx, None, None, None, None
+        return dx.clone(), None, None, None, None
 
 
 class GatherRowsBF16(torch.autograd.Function):

@@ -127,6 +127,7 @@ class NavModel(nn.Module):
         self.rope_cos = emb.cos().to(BF16).to(self.device).contiguous()
         self.rope_sin = emb.sin().to(BF16).to(self.device).contiguous()
         self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
+        self.arena = Fn.ActivationArena(cfg, self.device)
         self._dp = None
         self.drop_env_p = cfg.feat_dropout
         self.injected_dropout = None   # tests: dict of keep masks
@@ -166,6 +167,10 @@ class NavModel(nn.Module):
                 self._named[k].copy_(v.to(self._named[k].dtype))
                 n += 1
         return n
+
+    def reserve_activations(self, batch, seq_len):
+        """size the LM activation arena once, up front (B*S rows)"""
+        self.arena.reserve(batch * seq_len)
 
     def zero_grad(self, set_to_none=False):
         self.store.zero_grad()

@@ -128,10 +128,11 @@ def test_g3_g4_navigation_loss_grads_vs_reference():
             continue
         n = k[5:]
         g = m.store.g(n)
-        r16, r32 = relerr(g, zb[k]), relerr(g, zf[k])
+        r16, r32, base = relerr(g, zb[k]), relerr(g, zf[k]), relerr(T(zb[k]), zf[k])
         worst[n] = (r16, r32)
-        tol = 1e-3 if m.store.group_of[n] == "f32" and "img_embeddings" not in n and False else 8e-2
-        assert r16 < tol and r32 < tol, (n, r16, r32)
+        # bf16-vs-bf16 (same rounding points) within 8%; and as close to the fp32 reference as the
+        # reference's own bf16 run is (its relative error `base`), x1.5
+        assert r16 < 8e-2 and r32 < 1.5 * base + 5e-2, (n, r16, r32, base)
     print("[g4] grad rel errs (vs ref bf16, vs ref fp32):", {k: (round(a, 4), round(b, 4)) for k, (a, b) in worst.items()})
     # embedding-table gradient row norms
     gn = m.store.g("lang_model.model.embed_tokens.weight").float().norm(dim=1).cpu()
