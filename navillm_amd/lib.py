@@ -67,6 +67,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64 (torch/lib, SONAME libamdhip64.so.7).  Import torch FIRST so that
+    # our library's NEEDED libamdhip64.so.7 binds to that same runtime instance; loading ours first would
+    # pull /opt/rocm's copy and leave two HIP runtimes in the process (torch's streams/pointers would then
+    # be foreign handles to our launches).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NaviLLMHipError(
             f"{LIB_PATH} not found: build it with `python -m navillm_amd.build` "

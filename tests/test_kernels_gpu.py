@@ -317,7 +317,8 @@ def test_clip_and_adamw_match_oracle_sequence():
                 err = (a - b).abs()
                 ulp = (2 ** -7 if dtype == BF else 1e-5) * b.abs() + 1e-9
                 lim = 6.0 if step >= 2 else 1.01
-                assert bool((err <= lim * ulp).all()), f"adamw {name} {dtype} step {step}: max err/ulp {(err / ulp).max().item():.2f}"
+                floor = 2e-4 * b.abs().max()          # values near zero: differences are bounded by the update size
+                assert bool((err <= lim * ulp + floor).all()), f"adamw {name} {dtype} step {step}: max err/ulp {(err / ulp).max().item():.2f}"
                 frac = (err > 0).float().mean().item()
                 if step != 2 and dtype == BF:
                     assert frac < 1e-4, f"adamw {name} step {step}: {frac:.2e} of elements differ"
