@@ -27,8 +27,9 @@ __device__ __forceinline__ int key4(int row) { return ((row & 7) << 1) | ((row >
 
 // DMA `ROWS` rows x 128 bf16 (global row stride ld elements) into an LDS image.
 template <int ROWS, int NT>
-__device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rsrc, LDS_PTR(char) lds, int row0, int col0, int ld,
+__device__ __forceinline__ void stage_rows(const u32x4& rsrc, LDS_PTR(char) lds_p, int row0, int col0, int ld,
                                            int tid) {
+    const uint32_t lds = lds_addr_of(lds_p);
     constexpr int ITERS = (ROWS * ROWB) / (NT * 16);
     static_assert((ROWS * ROWB) % (NT * 16) == 0, "tile/threads mismatch");
     const int wave = tid >> 6, lane = tid & 63;
@@ -38,7 +39,7 @@ __device__ __forceinline__ void stage_rows(__amdgpu_buffer_rsrc_t rsrc, LDS_PTR(
         const int row = chunk * 4 + (lane >> 4);
         const int slot = (lane & 15) ^ key4(row);
         const uint32_t voff = (uint32_t)(((long)(row0 + row) * ld + col0 + slot * 8) * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_PTR(void))(lds + chunk * 1024), 16, voff, 0, 0, 0);
+        dma16(rsrc, __builtin_amdgcn_readfirstlane(lds + chunk * 1024), voff);
     }
 }
 
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const int qi = lane & 15, g = lane >> 4;
     const bf16_t* base = p.qkv + (long)b * S * ld;
     const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, span);
+    const u32x4 rs = make_desc(base, span);
     const int kcol = p.H * HD + h * HD, vcol = 2 * p.H * HD + h * HD;
 
     // Q fragments (B operand: j = query, k = head dim), straight from HBM
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             stage_rows<64, 256>(rs, smem + buf * 2 * TILE + TILE, kt * 64, vcol, ld, tid);
         };
         stage(kt_beg, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
         int cur = 0;
         for (int kt = kt_beg; kt <= kt_end; ++kt) {
             if (kt < kt_end) stage(kt + 1, cur ^ 1);
@@ -198,8 +199,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
                         o[dt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[j], o[dt][j], 0, 0, 0);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
             cur ^= 1;
         }
     }
@@ -257,10 +258,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     const int key = kblk + wave * 16 + ki;
     const bf16_t* base = p.qkv + (long)b * S * ld;
     const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(base, span);
+    const u32x4 rq = make_desc(base, span);
     const int od = p.H * HD;
     const bf16_t* dobase = p.dout + (long)b * S * od;
-    const __amdgpu_buffer_rsrc_t rdo = make_rsrc(dobase, (uint32_t)(((long)(S - 1) * od + od) * 2));
+    const u32x4 rdo = make_desc(dobase, (uint32_t)(((long)(S - 1) * od + od) * 2));
     const float* lse2 = p.lse2 + ((long)b * p.H + h) * S;
     const float* dsum = p.dsum + ((long)b * p.H + h) * S;
 
@@ -287,8 +288,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         stage_rows<32, 256>(rdo, smem + buf * 2 * TILE + TILE, qt * 32, h * HD, od, tid);
     };
     stage(qt_beg, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
     int cur = 0;
     for (int qt = qt_beg; qt <= qt_end; ++qt) {
         if (qt < qt_end) stage(qt + 1, cur ^ 1);
@@ -330,8 +331,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
             dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_, pfrag, dv[dt], 0, 0, 0);
             dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsfrag, dk[dt], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
         cur ^= 1;
     }
     if (key < S) {
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     const int ql = q < S ? q : S - 1;
     const bf16_t* base = p.qkv + (long)b * S * ld;
     const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, span);
+    const u32x4 rs = make_desc(base, span);
     const int od = p.H * HD;
     const int kcol = p.H * HD + h * HD, vcol = 2 * p.H * HD + h * HD;
 
@@ -391,8 +392,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
             stage_rows<64, 256>(rs, smem + buf * 2 * TILE + TILE, kt * 64, vcol, ld, tid);
         };
         stage(kt_beg, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
         int cur = 0;
         for (int kt = kt_beg; kt <= kt_end; ++kt) {
             if (kt < kt_end) stage(kt + 1, cur ^ 1);
@@ -429,8 +430,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
                     dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsf, dq[dt], 0, 0, 0);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
             cur ^= 1;
         }
     }

@@ -18,10 +18,9 @@
 // MFMA operands are swapped (D[n][m]) so each lane ends with 4 consecutive n: 8-byte stores
 // and room for fused row-wise epilogues.
 #include "nv_common.h"
+#include <stdlib.h>
 
 namespace {
-
-constexpr int BK = 64;
 
 enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_RESID = 2, EPI_BIAS = 3 };
 
@@ -31,21 +30,24 @@ struct GemmArgs {
     int M, N, K;
     int lda, ldb, ldc, ldr;
     uint32_t a_bytes, b_bytes;
+    int group_m;            // tile-order super-row height (L2 reuse), >= 1
 };
 
-// ---- LDS images -------------------------------------------------------------------------
-// KMAJ tile  : [R][64] bf16, 128-B rows = 8 slots of 16 B; phys_slot = slot ^ ((row>>1)&7)
-//              -> a ds_read_b128 lane group (16 distinct rows, 2 adjacent slots) is conflict-free.
-// MN tile    : [64][R] bf16, 2R-B rows; phys_slot = slot ^ (key(krow)<<1),
+// ---- LDS images (BKT = K extent of a stage, 64 or 32) -----------------------------------
+// KMAJ tile  : [R][BKT] bf16; 16-B slots per row S = BKT/8; phys_slot = slot ^ swz(row) with
+//              swz = (row>>1)&7 (BKT=64) or (row>>2)&3 (BKT=32): the 16 rows a ds_read_b128 lane
+//              group touches land on 16 distinct 16-B bank slots -> conflict-free (PMC: 0).
+// MN tile    : [BKT][R] bf16, 2R-B rows; phys_slot = slot ^ (key(krow)<<1),
 //              key = (krow&3) | ((krow>>3)&1)<<2 -> the 8 k-rows one half-wave touches in a
 //              ds_read_b64_tr_b16 land on 8 distinct 32-B bank groups.
 __device__ __forceinline__ int mn_key(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
+template <int BKT>
+__device__ __forceinline__ int km_swz(int row) { return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
-// Issue the loads of one [R x 64] operand tile into LDS (all NT threads cooperate).
-template <int R, bool KMAJ, int NT>
-__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, LDS_PTR(char) lds, int row0, int k0,
-                                           int ld, int tid) {
-    constexpr int TILE_BYTES = R * BK * 2;
+// Issue the loads of one [R x BKT] operand tile into LDS (all NT threads cooperate).
+template <int R, bool KMAJ, int NT, int BKT>
+__device__ __forceinline__ void stage_tile(const u32x4& desc, uint32_t lds, int row0, int k0, int ld, int tid) {
+    constexpr int TILE_BYTES = R * BKT * 2;
     constexpr int ITERS = TILE_BYTES / (NT * 16);
     static_assert(TILE_BYTES % (NT * 16) == 0, "tile/threads mismatch");
     const int wave = tid >> 6, lane = tid & 63;
@@ -55,8 +57,10 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, LDS_PTR(
         const int chunk = it * (NT / 64) + wave;
         uint32_t voff;
         if (KMAJ) {
-            const int row = chunk * 8 + (lane >> 3);           // 8 rows of 128 B per KiB
-            const int slot = (lane & 7) ^ ((row >> 1) & 7);    // logical slot living at phys slot lane&7
+            constexpr int SLOTS = BKT / 8;                     // 16-B slots per row
+            constexpr int RPK = 64 / SLOTS;                    // rows per KiB
+            const int row = chunk * RPK + lane / SLOTS;
+            const int slot = (lane % SLOTS) ^ km_swz<BKT>(row);  // logical slot living at this phys slot
             voff = (uint32_t)(((long)(row0 + row) * ld + k0 + slot * 8) * 2);
         } else {
             constexpr int SLOTS = R / 8;                       // 16-B slots per k-row
@@ -65,18 +69,18 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, LDS_PTR(
             const int slot = (lane % SLOTS) ^ (mn_key(krow) << 1);
             voff = (uint32_t)(((long)(k0 + krow) * ld + row0 + slot * 8) * 2);
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (LDS_PTR(void))(lds + chunk * 1024), 16, voff, 0, 0, 0);
+        dma16(desc, __builtin_amdgcn_readfirstlane(lds + chunk * 1024), voff);
     }
 }
 
 // One MFMA operand fragment (16 rows x 32 k) from an LDS tile.
-template <int R, bool KMAJ>
+template <int R, bool KMAJ, int BKT>
 __device__ __forceinline__ bf16x8 load_frag(LDS_PTR(char) tile, int r0, int kk, int lane) {
     const int idx = lane & 15, kg = lane >> 4;
     if (KMAJ) {
         const int row = r0 + idx;
-        const int slot = (kk * 4 + kg) ^ ((row >> 1) & 7);
-        return *(LDS_PTR(bf16x8))(tile + row * 128 + slot * 16);
+        const int slot = (kk * 4 + kg) ^ km_swz<BKT>(row);
+        return *(LDS_PTR(bf16x8))(tile + row * (BKT * 2) + slot * 16);
     } else {
         // transposing read: lane t of a 16-lane group hands in the address of row (t>>2),
         // 8-byte chunk (t&3) of a [4 k][16 col] block and receives column t (4 k values).
@@ -93,27 +97,45 @@ __device__ __forceinline__ bf16x8 load_frag(LDS_PTR(char) tile, int r0, int kk, 
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI>
+// wait until at most `tiles` whole stages (LOADS buffer_loads each) are still in flight
+template <int LOADS, int MAXT>
+__device__ __forceinline__ void wait_tiles(int tiles) {
+    if (MAXT >= 3 && tiles >= 3) wait_vmcnt<3 * LOADS>();
+    else if (MAXT >= 2 && tiles == 2) wait_vmcnt<2 * LOADS>();
+    else if (MAXT >= 1 && tiles == 1) wait_vmcnt<LOADS>();
+    else wait_vmcnt<0>();
+}
+
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_kernel(GemmArgs p) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2;
+    constexpr int LOADS = (A_BYTES + B_BYTES) / (NT * 16);     // buffer_load...lds per thread per stage
+    static_assert(3 * LOADS < 64, "vmcnt immediate range");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
-    // XCD-aware tile order; N-tiles fastest so consecutive ids share the A row panel in L2.
+    // Tile order: each XCD (block b runs on XCD b%8) gets a contiguous chunk of a GROUPED order in which
+    // consecutive ids walk group_m tile-rows down, then one tile-column right.  The ~32 tiles an XCD has
+    // in flight then form a group_m x (32/group_m) patch sharing A row panels AND B column panels in
+    // that XCD's 4 MiB L2 (measured: strip order = 49% L2 hit rate on the forward GEMM).
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = t / tiles_n, tn = t % tiles_n;
+    const int per_group = p.group_m * tiles_n;
+    const int grp = t / per_group, within = t % per_group;
+    const int rows_here = min(p.group_m, tiles_m - grp * p.group_m);
+    const int tm = grp * p.group_m + within % rows_here, tn = within / rows_here;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
-    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+    const u32x4 ra = make_desc(p.A, p.a_bytes);
+    const u32x4 rb = make_desc(p.B, p.b_bytes);
+    const uint32_t smem_addr = lds_addr_of(smem);
 
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -121,22 +143,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = (p.K + BK - 1) / BK;
+    const int KT = (p.K + BKT - 1) / BKT;
     auto stage = [&](int kt, int buf) {
-        LDS_PTR(char) sa = smem + buf * (A_BYTES + B_BYTES);
-        stage_tile<BM, A_KMAJ, NT>(ra, sa, m0, kt * BK, p.lda, tid);
-        stage_tile<BN, B_KMAJ, NT>(rb, sa + A_BYTES, n0, kt * BK, p.ldb, tid);
+        const uint32_t sa = smem_addr + buf * (A_BYTES + B_BYTES);
+        stage_tile<BM, A_KMAJ, NT, BKT>(ra, sa, m0, kt * BKT, p.lda, tid);
+        stage_tile<BN, B_KMAJ, NT, BKT>(rb, sa + A_BYTES, n0, kt * BKT, p.ldb, tid);
     };
     auto compute = [&](int buf) {
         LDS_PTR(char) sa = smem + buf * (A_BYTES + B_BYTES);
         LDS_PTR(char) sb = sa + A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < BK / 32; ++kk) {
+        for (int kk = 0; kk < BKT / 32; ++kk) {
             bf16x8 fa[TM], fb[TN];
 #pragma unroll
-            for (int j = 0; j < TM; ++j) fa[j] = load_frag<BM, A_KMAJ>(sa, wm * WTM + j * 16, kk, lane);
+            for (int j = 0; j < TM; ++j) fa[j] = load_frag<BM, A_KMAJ, BKT>(sa, wm * WTM + j * 16, kk, lane);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[i] = load_frag<BN, B_KMAJ>(sb, wn * WTN + i * 16, kk, lane);
+            for (int i = 0; i < TN; ++i) fb[i] = load_frag<BN, B_KMAJ, BKT>(sb, wn * WTN + i * 16, kk, lane);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -145,21 +167,51 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_kernel(GemmArgs p) {
         }
     };
 
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < KT - 1; ++kt) {
-        stage(kt + 1, cur ^ 1);
-        compute(cur);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
+    // ---- NSTAGE-deep DMA pipeline: stages kt+1 .. kt+NSTAGE-1 are in flight while kt is computed.
+    // Each wave waits (counted vmcnt, never a drain in steady state) for ITS share of the next stage,
+    // then the barrier at the top of the next iteration publishes every wave's share; the same barrier
+    // retires the reads of the buffer that the new DMA overwrites.
+#pragma unroll
+    for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
+        if (s_ < KT) stage(s_, s_);
+    wait_tiles<LOADS, NSTAGE - 2>(min(NSTAGE - 1, KT) - 1);
+    for (int kt = 0; kt < KT; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSTAGE - 1 < KT) stage(kt + NSTAGE - 1, (kt + NSTAGE - 1) % NSTAGE);
+        compute(kt % NSTAGE);
+        const int inflight = min(NSTAGE - 1, KT - 1 - kt);     // stages issued and not yet needed... incl. kt+1
+        if (inflight > 0) wait_tiles<LOADS, NSTAGE - 2>(inflight - 1);
     }
-    compute(cur);
 
     // ---- epilogue: lane holds D[n = g*4+r][m = lane&15] per 16x16 tile ----
     const int g = lane >> 4, mi = lane & 15;
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 7) == 0) &&
+                          (EPI != EPI_RESID || (((p.ldr & 3) == 0) && ((((uintptr_t)p.R) & 7) == 0)));
+    if (interior) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = m0 + wm * WTM + j * 16 + mi;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int n = n0 + wn * WTN + i * 16 + g * 4;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                bf16_t* cp = p.C + (long)m * p.ldc + n;
+                if (EPI == EPI_BIAS) {
+                    const u32x2 bb = *(const u32x2*)(p.R + n);
+                    v[0] += __uint_as_float(bb[0] << 16); v[1] += __uint_as_float(bb[0] & 0xffff0000u);
+                    v[2] += __uint_as_float(bb[1] << 16); v[3] += __uint_as_float(bb[1] & 0xffff0000u);
+                } else if (EPI == EPI_ACCUM || EPI == EPI_RESID) {
+                    const bf16_t* rp = (EPI == EPI_ACCUM) ? cp : p.R + (long)m * p.ldr + n;
+                    const u32x2 rr = *(const u32x2*)rp;
+                    v[0] = __uint_as_float(rr[0] << 16) + rbf(v[0]); v[1] = __uint_as_float(rr[0] & 0xffff0000u) + rbf(v[1]);
+                    v[2] = __uint_as_float(rr[1] << 16) + rbf(v[2]); v[3] = __uint_as_float(rr[1] & 0xffff0000u) + rbf(v[3]);
+                }
+                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                *(u32x2*)cp = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + wm * WTM + j * 16 + mi;
@@ -170,38 +222,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_kernel(GemmArgs p) {
             if (n >= p.N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             bf16_t* cp = p.C + (long)m * p.ldc + n;
-            const bool full = (n + 3 < p.N);
-            if (EPI == EPI_BIAS) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.N) v[r] += bf2f(p.R[n + r]);
-            } else if (EPI == EPI_ACCUM) {
-                // torch semantics of `grad += dW`: dW is rounded to bf16 first, then added
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.N) v[r] = bf2f(cp[r]) + rbf(v[r]);
-            } else if (EPI == EPI_RESID) {
-                const bf16_t* rp = p.R + (long)m * p.ldr + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.N) v[r] = bf2f(rp[r]) + rbf(v[r]);
-            }
-            if (full && ((((uintptr_t)cp) & 7) == 0)) {
-                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                *(u32x2*)cp = o;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.N) cp[r] = f2bf(v[r]);
+            for (int r = 0; r < 4; ++r) {
+                if (n + r >= p.N) continue;
+                if (EPI == EPI_BIAS) v[r] += bf2f(p.R[n + r]);
+                else if (EPI == EPI_ACCUM) v[r] = bf2f(cp[r]) + rbf(v[r]);   // torch: grad += bf16(dW)
+                else if (EPI == EPI_RESID) v[r] = bf2f(p.R[(long)m * p.ldr + n + r]) + rbf(v[r]);
+                cp[r] = f2bf(v[r]);
             }
         }
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool A_KMAJ, bool B_KMAJ, int EPI>
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI>
 int launch(const GemmArgs& p, hipStream_t st) {
-    constexpr int LDS = 2 * (BM + BN) * BK * 2;
-    auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, A_KMAJ, B_KMAJ, EPI>;
+    constexpr int LDS = NSTAGE * (BM + BN) * BKT * 2;
+    auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -215,18 +251,19 @@ int launch(const GemmArgs& p, hipStream_t st) {
 
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
 int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
-    // tile_cfg: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128 (8 waves), 3 = 256x256 (8 waves)
+    // tile_cfg: 0 = auto, 1 = 128x128x64 2-stage (4 waves), 2 = 256x128x64 3-stage (8 waves),
+    //           3 = 256x256x64 2-stage (8 waves), 4 = 256x256x32 4-stage (8 waves)
     if (tile_cfg == 0) {
-        // Fill the chip first: 256 CUs; the big tile only when it still gives >= ~2 rounds.
-        // measured on MI355X (profiles/r01_gemm_probe.txt): the 256x256 tile wins from ~1.4 rounds
+        // measured on MI355X (profiles/r01_gemm_probe*.txt): the 256x256 tile wins from ~1.4 rounds
         // of the 256 CUs upward, in all three layouts
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         tile_cfg = (t256 >= 128) ? 3 : 1;
     }
     switch (tile_cfg) {
-        case 1: return launch<128, 128, 2, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
-        case 2: return launch<256, 128, 4, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
-        case 3: return launch<256, 256, 2, 4, A_KMAJ, B_KMAJ, EPI>(p, st);
+        case 1: return launch<128, 128, 2, 2, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
+        case 2: return launch<256, 128, 4, 2, 64, 3, A_KMAJ, B_KMAJ, EPI>(p, st);
+        case 3: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
+        case 4: return launch<256, 256, 2, 4, 32, 4, A_KMAJ, B_KMAJ, EPI>(p, st);
     }
     return NV_ERR_ARG;
 }
@@ -263,14 +300,19 @@ extern "C" int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, c
     GemmArgs p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C; p.R = (const bf16_t*)R;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
+    {
+        const char* e = getenv("NV_GEMM_GROUP_M");   // tuning knob; default 4 (4 x 8 patch per XCD)
+        p.group_m = e ? atoi(e) : 4;
+        if (p.group_m < 1) p.group_m = 1;
+    }
     hipStream_t st = (hipStream_t)stream;
     switch (layout) {
         case 0:  // NT: A[M,K], B[N,K]
-            if (K % BK) return NV_ERR_SHAPE;
+            if (K % 64) return NV_ERR_SHAPE;
             p.a_bytes = span_bytes(M, K, lda); p.b_bytes = span_bytes(N, K, ldb);
             return dispatch_epi<true, true>(p, epilogue, tile_cfg, st);
         case 1:  // NN: A[M,K], B[K,N]
-            if (K % BK) return NV_ERR_SHAPE;
+            if (K % 64) return NV_ERR_SHAPE;
             p.a_bytes = span_bytes(M, K, lda); p.b_bytes = span_bytes(K, N, ldb);
             return dispatch_epi<true, false>(p, epilogue, tile_cfg, st);
         case 2:  // TN: A[K,M], B[K,N]   (K = contraction, any size: OOB k-rows read as zero)

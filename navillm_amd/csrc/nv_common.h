@@ -40,6 +40,31 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)bytes, 0x00020000);
 }
 
+// ---- LDS DMA (buffer_load_dwordx4 ... lds) issued from inline asm ----------------------------------
+// Why asm and not __builtin_amdgcn_raw_ptr_buffer_load_lds: hipcc's waitcnt pass treats every LDS read it
+// cannot disambiguate -- in particular ds_read_b64_tr_b16 -- as aliasing ALL pending LDS-DMA and puts an
+// `s_waitcnt vmcnt(0)` in front of the first such read of each k-step, i.e. it drains the prefetch pipeline
+// every iteration (seen in the .s; cost the dgrad/wgrad GEMMs ~35%).  DMA issued from asm is invisible to
+// that pass; completion is tracked by hand with counted `s_waitcnt vmcnt(N)` + s_barrier.
+// 16 bytes per lane land at LDS[lds_addr + lane*16]; OOB source lanes write zeros.
+__device__ __forceinline__ u32x4 make_desc(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void dma16(const u32x4& desc, uint32_t lds_addr_uniform, uint32_t voff) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(lds_addr_uniform), "s"(desc)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(LDS_PTR(char) p) { return (uint32_t)(uintptr_t)p; }
+
 // ---- wave reductions (wave = 64) ----
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

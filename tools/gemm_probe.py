@@ -25,12 +25,14 @@ def bench(fns, iters=12, warm=3):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     cold = "--cold" in sys.argv
-    tiles = (3,) if "--t3" in sys.argv else (1, 2, 3)
+    tiles = (3,) if "--t3" in sys.argv else ((2, 3, 4) if "--t234" in sys.argv else (1, 2, 3, 4))
     M = int(args[0]) if args else 5600
     nset = 12 if cold else 1
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(0)
     shapes = [(4096, 4096), (12288, 4096), (22016, 4096), (4096, 11008)]
+    if "--noblas" in sys.argv:
+        pass
     for (N, K) in shapes:
         X = [torch.randn(M, K, device=dev, generator=g).bfloat16() for _ in range(nset)]
         W = [(torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16() for _ in range(nset)]
@@ -43,10 +45,11 @@ def main():
             t_nn = bench([lambda i=i: ops.gemm_bf16(1, dY[i], W[i], tile_cfg=tile) for i in range(nset)])
             t_tn = bench([lambda i=i: ops.gemm_bf16(2, dY[i], X[i], out=G[i], epilogue=1, tile_cfg=tile) for i in range(nset)])
             line += f"  tile{tile}: NT {fl/t_nt/1e12:7.1f} NN {fl/t_nn/1e12:7.1f} TN+acc {fl/t_tn/1e12:7.1f} TF"
-        t_ref = bench([lambda i=i: X[i] @ W[i].t() for i in range(nset)])
-        t_ref2 = bench([lambda i=i: dY[i] @ W[i] for i in range(nset)])
-        t_ref3 = bench([lambda i=i: dY[i].t() @ X[i] for i in range(nset)])
-        line += f"  | hipBLASLt NT {fl/t_ref/1e12:7.1f} NN {fl/t_ref2/1e12:7.1f} TN {fl/t_ref3/1e12:7.1f} TF"
+        if "--noblas" not in sys.argv:
+            t_ref = bench([lambda i=i: X[i] @ W[i].t() for i in range(nset)])
+            t_ref2 = bench([lambda i=i: dY[i] @ W[i] for i in range(nset)])
+            t_ref3 = bench([lambda i=i: dY[i].t() @ X[i] for i in range(nset)])
+            line += f"  | hipBLASLt NT {fl/t_ref/1e12:7.1f} NN {fl/t_ref2/1e12:7.1f} TN {fl/t_ref3/1e12:7.1f} TF"
         print(line, flush=True)
         del X, W, dY, G
 
