@@ -315,12 +315,13 @@ def test_clip_and_adamw_match_oracle_sequence():
             for name, a, b in (("p", p, pc), ("m", m, mc), ("v", v, vc)):
                 a, b = a.cpu().float(), b.float()
                 err = (a - b).abs()
-                ulp = (2 ** -7 if dtype == BF else 1e-5) * b.abs() + 1e-9
+                ulp = (2 ** -7 if dtype == BF else 1e-5) * b.abs()
+                scale = b.abs().max()
                 lim = 6.0 if step >= 2 else 1.01
-                floor = 2e-4 * b.abs().max()          # values near zero: differences are bounded by the update size
-                assert bool((err <= lim * ulp + floor).all()), f"adamw {name} {dtype} step {step}: max err/ulp {(err / ulp).max().item():.2f}"
-                frac = (err > 0).float().mean().item()
-                if step != 2 and dtype == BF:
+                ok = err <= lim * ulp + 2e-4 * scale
+                assert bool(ok.all()), f"adamw {name} {dtype} step {step}: {int((~ok).sum())} bad, max err {err.max().item():.3e} (scale {scale.item():.3e})"
+                if step == 1 and dtype == BF:
+                    frac = (err > 0).float().mean().item()
                     assert frac < 1e-4, f"adamw {name} step {step}: {frac:.2e} of elements differ"
 
 
