@@ -37,6 +37,12 @@ extern "C" {
 int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
                  int ldb, int ldc, int ldr, int epilogue, int tile_cfg, void* stream);
 
+/* same, with the split-K tail enabled: `workspace` = nv_gemm_bf16_workspace_bytes() bytes, zero-filled once by
+ * the caller (ticket words are left zero again by the kernel), private to one stream at a time */
+size_t nv_gemm_bf16_workspace_bytes(void);
+int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
+                    int ldb, int ldc, int ldr, int epilogue, int tile_cfg, void* workspace, void* stream);
+
 /* ---- K6: embedding gather + visual-token add, models/modified_lm.py:100-110.
  *   out[m] = table[ids[m]]  or  bf16(f32(table[ids[m]]) + vis[vis_idx[m]])  when vis_idx[m] >= 0 */
 int nv_embed_vis_bf16(const void* table, const int* ids, const int* vis_idx, const float* vis, void* out, int M, int d,

@@ -31,6 +31,10 @@ struct GemmArgs {
     int lda, ldb, ldc, ldr;
     uint32_t a_bytes, b_bytes;
     int group_m;            // tile-order super-row height (L2 reuse), >= 1
+    // split-K tail (see launch()): blocks >= full_blocks are K-slices of the last, partial round of tiles
+    int full_blocks, rem, split;
+    float* slabs;           // [rem*split][BM*BN] fp32 partials
+    unsigned* counters;     // [rem] arrival tickets, zero between launches
 };
 
 // ---- LDS images (BKT = K extent of a stage, 64 or 32) -----------------------------------
@@ -107,7 +111,8 @@ __device__ __forceinline__ void wait_tiles(int tiles) {
 }
 
 template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_kernel(GemmArgs p) {
+__global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(1, ((NSTAGE * (BM + BN) * BKT * 2 > 80 * 1024) ? 1 : 2) * (WGM * WGN) / 4)))
+void gemm_bf16_kernel(GemmArgs p) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -126,7 +131,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_kernel(GemmArgs p) {
     // that XCD's 4 MiB L2 (measured: strip order = 49% L2 hit rate on the forward GEMM).
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tile_b = blockIdx.x, ks = 0, nsplit = 1, tail_u = 0;
+    if (tile_b >= p.full_blocks) {           // uniform per block
+        const int q = tile_b - p.full_blocks;
+        ks = q / p.rem;
+        tail_u = q % p.rem;
+        tile_b = p.full_blocks + tail_u;
+        nsplit = p.split;
+    }
+    const int t = xcd_remap(tile_b, tiles_m * tiles_n);
     const int per_group = p.group_m * tiles_n;
     const int grp = t / per_group, within = t % per_group;
     const int rows_here = min(p.group_m, tiles_m - grp * p.group_m);
@@ -143,8 +156,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = (p.K + BKT - 1) / BKT;
-    auto stage = [&](int kt, int buf) {
+    const int KT_all = (p.K + BKT - 1) / BKT;
+    const int kt0 = (int)(((long)KT_all * ks) / nsplit);
+    const int KT = (int)(((long)KT_all * (ks + 1)) / nsplit) - kt0;       // this block's K-tiles: kt0 .. kt0+KT-1
+    auto stage = [&](int kt_local, int buf) {
+        const int kt = kt0 + kt_local;
         const uint32_t sa = smem_addr + buf * (A_BYTES + B_BYTES);
         stage_tile<BM, A_KMAJ, NT, BKT>(ra, sa, m0, kt * BKT, p.lda, tid);
         stage_tile<BN, B_KMAJ, NT, BKT>(rb, sa + A_BYTES, n0, kt * BKT, p.ldb, tid);
@@ -181,6 +197,46 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_bf16_kernel(GemmArgs p) {
         compute(kt % NSTAGE);
         const int inflight = min(NSTAGE - 1, KT - 1 - kt);     // stages issued and not yet needed... incl. kt+1
         if (inflight > 0) wait_tiles<LOADS, NSTAGE - 2>(inflight - 1);
+    }
+
+    // ---- split-K tail: publish the fp32 partial, take a ticket, the last arriver reduces -------------
+    // Placement-independent hand-off (cdna_hip_programming.md §6 G16 counter form): plain slab stores ->
+    // every wave drains -> barrier -> ONE lane: agent-scope release, drain again (asm: the compiler drops
+    // the post-wbl2 wait), relaxed agent ticket.  Reducer: ONE lane agent-scope acquire -> barrier ->
+    // plain loads.  The slab image is the accumulator register image (lane-linear 16-B stores).
+    if (nsplit > 1) {
+        constexpr int SLAB = BM * BN;
+        float* mine = p.slabs + (size_t)(tail_u * p.split + ks) * SLAB;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                *(f32x4*)(mine + (size_t)(((wave * TN + i) * TM + j) * 64 + lane) * 4) = acc[i][j];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        LDS_PTR(unsigned) flag = (LDS_PTR(unsigned))smem;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *flag = __hip_atomic_fetch_add(p.counters + tail_u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const unsigned ticket = *flag;
+        if (ticket != (unsigned)(nsplit - 1)) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(p.counters + tail_u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        for (int o = 0; o < nsplit; ++o) {
+            if (o == ks) continue;
+            const float* other = p.slabs + (size_t)(tail_u * p.split + o) * SLAB;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] += *(const f32x4*)(other + (size_t)(((wave * TN + i) * TM + j) * 64 + lane) * 4);
+        }
     }
 
     // ---- epilogue: lane holds D[n = g*4+r][m = lane&15] per 16x16 tile ----
@@ -245,7 +301,23 @@ int launch(const GemmArgs& p, hipStream_t st) {
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    NV_LAUNCH(kern, dim3(tiles), dim3(WGM * WGN * 64), LDS, st, p);
+    GemmArgs q = p;
+    q.full_blocks = tiles; q.rem = 1; q.split = 1;
+    // Split-K tail: with one 256x256 block per CU, T tiles run in ceil(T/256) rounds and the last round is
+    // often nearly empty (M=5152,N=4096: 336 tiles = 2 rounds for 1.31 rounds of work).  The tiles of that
+    // partial round are cut into `split` K-slices so the round is ~full and 1/split as long.
+    constexpr int CUS = 256;
+    if (BM == 256 && BN == 256 && p.slabs && p.counters) {
+        const int rem = tiles % CUS, KT = (p.K + BKT - 1) / BKT;
+        if (rem > 0 && rem <= CUS / 2) {
+            int split = CUS / rem;
+            if (split > 4) split = 4;
+            if (split > KT / 8) split = KT / 8;
+            if (split >= 2) { q.full_blocks = tiles - rem; q.rem = rem; q.split = split; }
+        }
+    }
+    const int grid = q.full_blocks + (q.split > 1 ? q.rem * q.split : 0);
+    NV_LAUNCH(kern, dim3(grid), dim3(WGM * WGN * 64), LDS, st, q);
     return nv_check_launch();
 }
 
@@ -290,8 +362,13 @@ inline uint32_t span_bytes(long rows, long cols, long ld) {
 }  // namespace
 
 // ---------------------------------------------------------------- C ABI (see include/navillm_hip.h)
-extern "C" int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
-                            int lda, int ldb, int ldc, int ldr, int epilogue, int tile_cfg, void* stream) {
+extern "C" size_t nv_gemm_bf16_workspace_bytes() { return (size_t)256 * 256 * 256 * sizeof(float) + 4096; }
+
+// workspace: nv_gemm_bf16_workspace_bytes() bytes, ZERO-FILLED once by the caller (the kernel leaves its
+// ticket words zero again); NULL disables the split-K tail.
+extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
+                               int lda, int ldb, int ldc, int ldr, int epilogue, int tile_cfg, void* workspace,
+                               void* stream) {
     if (!A || !B || !C || M < 0 || N < 0 || K < 0) return NV_ERR_ARG;
     if (M == 0 || N == 0) return NV_OK;
     if ((epilogue == EPI_RESID || epilogue == EPI_BIAS) && !R) return NV_ERR_ARG;
@@ -300,6 +377,9 @@ extern "C" int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, c
     GemmArgs p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.C = (bf16_t*)C; p.R = (const bf16_t*)R;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
+    p.counters = (unsigned*)workspace;
+    p.slabs = workspace ? (float*)((char*)workspace + 4096) : nullptr;
+    p.full_blocks = 0; p.rem = 1; p.split = 1;
     {
         const char* e = getenv("NV_GEMM_GROUP_M");   // tuning knob; default 4 (4 x 8 patch per XCD)
         p.group_m = e ? atoi(e) : 4;
@@ -320,4 +400,9 @@ extern "C" int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, c
             return dispatch_epi<false, false>(p, epilogue, tile_cfg, st);
     }
     return NV_ERR_ARG;
+}
+
+extern "C" int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
+                            int lda, int ldb, int ldc, int ldr, int epilogue, int tile_cfg, void* stream) {
+    return nv_gemm_bf16_ws(layout, A, B, C, R, M, N, K, lda, ldb, ldc, ldr, epilogue, tile_cfg, nullptr, stream);
 }

@@ -52,10 +52,24 @@ def gemm_bf16(layout, A, B, out=None, R=None, epilogue=EPI_STORE, tile_cfg=0):
     if epilogue == EPI_RESID:
         _chk2d(R, BF16)
         ldr = R.stride(0)
-    rc = _L().nv_gemm_bf16(layout, A.data_ptr(), B.data_ptr(), out.data_ptr(), _p(R), M, N, K, A.stride(0), B.stride(0),
-                           out.stride(0), ldr, epilogue, tile_cfg, _st())
-    _lib.check(rc, "nv_gemm_bf16")
+    rc = _L().nv_gemm_bf16_ws(layout, A.data_ptr(), B.data_ptr(), out.data_ptr(), _p(R), M, N, K, A.stride(0), B.stride(0),
+                              out.stride(0), ldr, epilogue, tile_cfg, _gemm_ws(A.device) if SPLITK_TAIL else 0, _st())
+    _lib.check(rc, "nv_gemm_bf16_ws")
     return out
+
+
+SPLITK_TAIL = True
+_gemm_ws_cache = {}
+
+
+def _gemm_ws(device):
+    """zero-initialised split-K workspace, one per (device, stream)"""
+    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    t = _gemm_ws_cache.get(key)
+    if t is None:
+        t = torch.zeros((_L().nv_gemm_bf16_workspace_bytes(),), dtype=torch.uint8, device=device)
+        _gemm_ws_cache[key] = t
+    return t.data_ptr()
 
 
 # ------------------------------------------------------------------ LM row ops

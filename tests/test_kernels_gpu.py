@@ -37,7 +37,7 @@ def assert_close(got, ref, rtol, atol_scale, what):
 
 
 # ------------------------------------------------------------------------------ bf16 GEMM
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 192), (77, 520, 64), (1000, 384, 448)])
 def test_gemm_bf16_layouts(layout, tile, M, N, K):
@@ -75,6 +75,34 @@ def test_gemm_bf16_epilogues():
     bias = rnd(N, dtype=BF, seed=11)
     out = ops.gemm_bf16(0, A, B, R=bias.view(1, N), epilogue=ops.EPI_BIAS)
     assert_close(out, acc + bias.float(), 2 ** -7, 2e-3, "bias")
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(5152, 4096, 1024), (4864, 4096, 2048), (2100, 3072, 4096)])
+def test_gemm_bf16_splitk_tail(layout, M, N, K):
+    """shapes whose 256x256 tile count leaves a small partial round -> the split-K tail path (tickets, slabs);
+    repeated launches also check that the ticket words are left clean."""
+    from navillm_amd import ops
+    if layout == 0:
+        A, B = rnd(M, K, dtype=BF, seed=15), rnd(N, K, dtype=BF, seed=16, scale=0.05)
+        ref = A.float() @ B.float().t()
+    elif layout == 1:
+        A, B = rnd(M, K, dtype=BF, seed=17), rnd(K, N, dtype=BF, seed=18, scale=0.05)
+        ref = A.float() @ B.float()
+    else:
+        A, B = rnd(K, M, dtype=BF, seed=19), rnd(K, N, dtype=BF, seed=20, scale=0.05)
+        ref = A.float().t() @ B.float()
+    for rep in range(3):
+        out = ops.gemm_bf16(layout, A, B, tile_cfg=3)
+        torch.cuda.synchronize()
+        assert_close(out, ref, 2 ** -7, 2e-3, f"split-K tail layout={layout} {M}x{N}x{K} rep {rep}")
+    ops.SPLITK_TAIL = False
+    try:
+        out2 = ops.gemm_bf16(layout, A, B, tile_cfg=3)
+    finally:
+        ops.SPLITK_TAIL = True
+    # same products, different summation split: equal up to fp32 reassociation before the bf16 rounding
+    assert (out.float() - out2.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
 
 
 def test_gemm_bf16_large_llama_shapes():
@@ -314,8 +342,8 @@ def test_clip_and_adamw_match_oracle_sequence():
             # fp32), which flips a handful of bf16 roundings by one ulp: bound both the size and the count.
             for name, a, b in (("p", p, pc), ("m", m, mc), ("v", v, vc)):
                 a, b = a.cpu().float(), b.float()
-                if step == 1:
-                    # no clipping yet: the fused kernel reproduces torch's rounding sequence exactly
+                if step == 1 and dtype == BF:
+                    # no clipping yet: the fused kernel reproduces torch's bf16 rounding sequence exactly
                     frac = (a != b).float().mean().item()
                     assert frac < 1e-4, f"adamw {name} {dtype} step {step}: {frac:.2e} of elements differ"
                 else:
