@@ -102,6 +102,40 @@ __device__ __forceinline__ bf16x8 load_frag(LDS_PTR(char) tile, int r0, int kk, 
 }
 
 // wait until at most `tiles` whole stages (LOADS buffer_loads each) are still in flight
+// Per-lane fragment addressing for the software-pipelined main loop: everything that depends on the lane is
+// computed ONCE (2 VGPRs for a K-major operand, one per fragment for an MN-major one); tile index, k-step
+// and the second transposing read are immediates on the ds_read.
+template <int R, bool KMAJ, int NF>
+struct FragAddr {
+    int off[KMAJ ? 2 : NF];
+    __device__ __forceinline__ void init(int w0, int lane) {     // w0 = wave's first row/col in the tile (% 16 == 0)
+        const int idx = lane & 15, kg = lane >> 4;
+        if (KMAJ) {
+            const int s_ = (idx >> 1) & 7;                        // km_swz<64>(row): depends on idx only
+            off[0] = (w0 + idx) * 128 + ((kg ^ s_) << 4);
+            off[1] = off[0] ^ 64;                                 // slot (4+kg)^s
+        } else {
+            const int key = ((idx >> 2) & 3) | ((kg & 1) << 2);   // mn_key(krow): the same for both reads and both k-steps
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int slot = ((w0 >> 3) + 2 * j + ((idx & 3) >> 1)) ^ (key << 1);
+                off[KMAJ ? 0 : j] = (kg * 8 + (idx >> 2)) * (R * 2) + (slot << 4) + (idx & 1) * 8;
+            }
+        }
+    }
+    __device__ __forceinline__ bf16x8 load(LDS_PTR(char) tile, int j, int kk) const {
+        if (KMAJ) {
+            return *(LDS_PTR(bf16x8))(tile + off[KMAJ ? kk : 0] + j * 2048);
+        } else {
+            LDS_PTR(char) q = tile + off[KMAJ ? 0 : j] + kk * (32 * R * 2);
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))q);
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(q + 4 * R * 2));
+            s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, v);
+        }
+    }
+};
+
 template <int LOADS, int MAXT>
 __device__ __forceinline__ void wait_tiles(int tiles) {
     if (MAXT >= 3 && tiles >= 3) wait_vmcnt<3 * LOADS>();
@@ -110,7 +144,7 @@ __device__ __forceinline__ void wait_tiles(int tiles) {
     else wait_vmcnt<0>();
 }
 
-template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI>
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE>
 __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(1, ((NSTAGE * (BM + BN) * BKT * 2 > 80 * 1024) ? 1 : 2) * (WGM * WGN) / 4)))
 void gemm_bf16_kernel(GemmArgs p) {
     constexpr int NT = WGM * WGN * 64;
@@ -183,6 +217,56 @@ void gemm_bf16_kernel(GemmArgs p) {
         }
     };
 
+    if constexpr (PIPE >= 1) {
+        // ---- software-pipelined main loop (2 LDS stages, BK=64 = 2 k-steps of 32) ----------------------
+        // Fragment registers are double-buffered: the ds_reads of k-step 1 are in flight under the MFMAs of
+        // k-step 0, and the ds_reads of the NEXT tile's k-step 0 under the MFMAs of k-step 1.  One barrier
+        // per K-tile, in the middle: it publishes tile kt+1 (DMA'd a full iteration earlier) and retires every
+        // wave's reads of tile kt's buffer, which the DMA of tile kt+2 then overwrites.
+        static_assert(NSTAGE == 2 && BKT == 64, "pipelined loop is written for 2 stages of BK=64");
+        FragAddr<BM, A_KMAJ, TM> fa_addr;
+        FragAddr<BN, B_KMAJ, TN> fb_addr;
+        fa_addr.init(wm * WTM, lane);
+        fb_addr.init(wn * WTN, lane);
+        bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        auto ldfr = [&](int buf, int kk, bf16x8(&fa)[TM], bf16x8(&fb)[TN]) {
+            LDS_PTR(char) sa = smem + buf * (A_BYTES + B_BYTES);
+            LDS_PTR(char) sb = sa + A_BYTES;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) fa[j] = fa_addr.load(sa, j, kk);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fb[i] = fb_addr.load(sb, i, kk);
+        };
+        auto mma = [&](bf16x8(&fa)[TM], bf16x8(&fb)[TN]) {
+            if (PIPE == 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+            if (PIPE == 2) __builtin_amdgcn_s_setprio(0);
+        };
+        stage(0, 0);
+        if (KT > 1) { stage(1, 1); wait_vmcnt<LOADS>(); } else { wait_vmcnt<0>(); }
+        __builtin_amdgcn_s_barrier();
+        ldfr(0, 0, fa0, fb0);
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+            ldfr(buf, 1, fa1, fb1);
+            mma(fa0, fb0);
+            // MFMAs are register-only: without a scheduling fence hipcc sinks them below the asm waits and
+            // the barrier (seen in the .s), which would serialise the phases again
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of this buffer have returned
+            wait_vmcnt<0>();                                      // my share of tile kt+1 has landed
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < KT) stage(kt + 2, buf);
+            if (kt + 1 < KT) ldfr(buf ^ 1, 0, fa0, fb0);
+            mma(fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     // ---- NSTAGE-deep DMA pipeline: stages kt+1 .. kt+NSTAGE-1 are in flight while kt is computed.
     // Each wave waits (counted vmcnt, never a drain in steady state) for ITS share of the next stage,
     // then the barrier at the top of the next iteration publishes every wave's share; the same barrier
@@ -197,6 +281,7 @@ void gemm_bf16_kernel(GemmArgs p) {
         compute(kt % NSTAGE);
         const int inflight = min(NSTAGE - 1, KT - 1 - kt);     // stages issued and not yet needed... incl. kt+1
         if (inflight > 0) wait_tiles<LOADS, NSTAGE - 2>(inflight - 1);
+    }
     }
 
     // ---- split-K tail: publish the fp32 partial, take a ticket, the last arriver reduces -------------
@@ -290,10 +375,10 @@ void gemm_bf16_kernel(GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI>
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE = 0>
 int launch(const GemmArgs& p, hipStream_t st) {
     constexpr int LDS = NSTAGE * (BM + BN) * BKT * 2;
-    auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI>;
+    auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI, PIPE>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -329,13 +414,15 @@ int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
         // measured on MI355X (profiles/r01_gemm_probe*.txt): the 256x256 tile wins from ~1.4 rounds
         // of the 256 CUs upward, in all three layouts
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        tile_cfg = (t256 >= 128) ? 3 : 1;
+        tile_cfg = (t256 >= 128) ? 6 : 1;
     }
     switch (tile_cfg) {
         case 1: return launch<128, 128, 2, 2, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
         case 2: return launch<256, 128, 4, 2, 64, 3, A_KMAJ, B_KMAJ, EPI>(p, st);
         case 3: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
         case 4: return launch<256, 256, 2, 4, 32, 4, A_KMAJ, B_KMAJ, EPI>(p, st);
+        case 6: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 1>(p, st);   // software-pipelined fragments
+        case 7: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 2>(p, st);   // + s_setprio around the MFMA clusters
     }
     return NV_ERR_ARG;
 }

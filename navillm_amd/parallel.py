@@ -41,14 +41,16 @@ def init_distributed_device(backend=None):
     return device, rank, world
 
 
-def _allreduce_mean_(t, group=None, async_op=False):
-    """In-place mean over ranks. RCCL has a native AVG; gloo (CPU tests) sums then scales."""
+def _allreduce_mean_(t, group=None):
+    """In-place mean over ranks, enqueued on the CURRENT stream (SUM collective, then a 1/world scale:
+    the plainest RCCL call there is; for bf16 the scale is our own HIP kernel)."""
     world = dist.get_world_size(group)
-    if dist.get_backend(group) == "nccl":
-        return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
-    w = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=False)
-    t.div_(world)
-    return w
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if t.is_cuda and t.dtype == torch.bfloat16 and t.numel() % 8 == 0:
+        from . import ops
+        ops.scale_bf16_(t, 1.0 / world)
+    else:
+        t.mul_(1.0 / world)
 
 
 class GradSlices:
@@ -76,7 +78,6 @@ class NavDataParallel(torch.nn.Module):
         self.require_sync = True
         self.slices = GradSlices(module.store)
         self._comm_stream = torch.cuda.Stream() if module.store.device.type == "cuda" else None
-        self._pending = []
         self._queued = False
         module._dp = self
         self.broadcast_parameters()
@@ -115,10 +116,12 @@ class NavDataParallel(torch.nn.Module):
         self._launch(self.slices.layer[i])
 
     def _launch(self, t):
+        """all-reduce slice `t` on the side stream, ordered after everything enqueued so far on the compute
+        stream (the wgrad GEMMs that produced it); the host does not block."""
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm_stream):
-                self._pending.append(_allreduce_mean_(t, self.group, async_op=True))
+                _allreduce_mean_(t, self.group)
         else:
             _allreduce_mean_(t, self.group)
 
@@ -128,10 +131,6 @@ class NavDataParallel(torch.nn.Module):
         todo = self.slices.rest if self.overlap else self.slices.all_slices()
         for t in todo:
             self._launch(t)
-        for w in self._pending:
-            if w is not None:
-                w.wait()
-        self._pending = []
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
 

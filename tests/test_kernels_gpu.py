@@ -37,7 +37,7 @@ def assert_close(got, ref, rtol, atol_scale, what):
 
 
 # ------------------------------------------------------------------------------ bf16 GEMM
-@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 6])
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 192), (77, 520, 64), (1000, 384, 448)])
 def test_gemm_bf16_layouts(layout, tile, M, N, K):
@@ -78,7 +78,7 @@ def test_gemm_bf16_epilogues():
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(5152, 4096, 1024), (4864, 4096, 2048), (2100, 3072, 4096)])
+@pytest.mark.parametrize("M,N,K", [(5152, 4096, 1024), (4864, 4096, 2048), (2104, 3072, 4096)])
 def test_gemm_bf16_splitk_tail(layout, M, N, K):
     """shapes whose 256x256 tile count leaves a small partial round -> the split-K tail path (tickets, slabs);
     repeated launches also check that the ticket words are left clean."""
@@ -93,7 +93,7 @@ def test_gemm_bf16_splitk_tail(layout, M, N, K):
         A, B = rnd(K, M, dtype=BF, seed=19), rnd(K, N, dtype=BF, seed=20, scale=0.05)
         ref = A.float().t() @ B.float()
     for rep in range(3):
-        out = ops.gemm_bf16(layout, A, B, tile_cfg=3)
+        out = ops.gemm_bf16(layout, A, B, tile_cfg=3 if rep < 2 else 6)
         torch.cuda.synchronize()
         assert_close(out, ref, 2 ** -7, 2e-3, f"split-K tail layout={layout} {M}x{N}x{K} rep {rep}")
     ops.SPLITK_TAIL = False
