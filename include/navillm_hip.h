@@ -91,7 +91,7 @@ int nv_head_bwd_bf16(const void* dy, const void* x, const void* W, void* dx, voi
 /* ---- K11: CrossEntropyLoss(ignore_index=-100, reduction='sum') on bf16 logits with -inf slots,
  *      train.py:229 / tasks/agents/mp3d_agent.py:750. loss_rows[b] fp32; dlogits = bf16(gscale*(p-onehot)) */
 int nv_action_ce_bf16(const void* logits, const long* targets, float* loss_rows, void* dlogits, int B, int G, float gscale,
-                      void* stream);
+                      const float* gscale_dev /* optional device scalar multiplied into gscale */, void* stream);
 /* ---- K9: token CE of models/modified_lm.py:122-137 on materialised logits (special ids = -inf,
  *      labels already shifted on the host, -100 ignored); logits overwritten by their gradient */
 int nv_lm_ce_bf16(void* logits, const int* labels, float* loss_rows, int M, int V, int ldl, int special0, int nspecial,

@@ -88,7 +88,7 @@ struct AttnArgs {
 
 // =========================================================================== forward
 // grid (ceil(S/128), B*H), 256 threads: wave w owns queries q0 + w*32 .. +31 (two 16-query tiles)
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
     constexpr int TILE = 64 * ROWB;  // 16 KiB per K or V tile

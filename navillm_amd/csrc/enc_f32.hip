@@ -88,6 +88,115 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
     }
 }
 
+// Vectorised variant for the shapes that matter (weights streamed with 16-B bounds-checked buffer loads,
+// next K-tile prefetched into registers under the MFMAs).  A_KC / B_KC: operand is K-contiguous.
+// Preconditions (checked by the caller): K % 4 == 0 for K-contiguous operands, free dim % 4 == 0 for
+// the others, leading dimensions % 4 == 0, 16-B aligned bases.
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void gemm_f32_vec_kernel(GemmF32Args p, uint32_t a_bytes, uint32_t b_bytes) {
+    __shared__ __attribute__((aligned(16))) float As[FBK][FBM + FPAD];
+    __shared__ __attribute__((aligned(16))) float Bs[FBK][FBN + FPAD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * FBM, n0 = blockIdx.x * FBN;
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, b_bytes);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ga[2], gb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = e * 256 + tid;
+            if (A_KC) {
+                const int k4 = (idx & 7) * 4, r = idx >> 3;
+                const bool ok = (k0 + k4 < p.K);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)((((long)(m0 + r)) * p.sam + k0 + k4) * 4), 0, 0);
+                ga[e] = ok ? __builtin_bit_cast(f32x4, v) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const int r4 = (idx & 15) * 4, k = idx >> 4;
+                const bool ok = (m0 + r4 < p.M);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)((((long)(k0 + k)) * p.sak + m0 + r4) * 4), 0, 0);
+                ga[e] = ok ? __builtin_bit_cast(f32x4, v) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (B_KC) {
+                const int k4 = (idx & 7) * 4, r = idx >> 3;
+                const bool ok = (k0 + k4 < p.K);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)((((long)(n0 + r)) * p.sbn + k0 + k4) * 4), 0, 0);
+                gb[e] = ok ? __builtin_bit_cast(f32x4, v) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const int r4 = (idx & 15) * 4, k = idx >> 4;
+                const bool ok = (n0 + r4 < p.N);
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, (int)((((long)(k0 + k)) * p.sbk + n0 + r4) * 4), 0, 0);
+                gb[e] = ok ? __builtin_bit_cast(f32x4, v) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = e * 256 + tid;
+            if (A_KC) {
+                const int k4 = (idx & 7) * 4, r = idx >> 3;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) As[k4 + c][r] = ga[e][c];
+            } else {
+                const int r4 = (idx & 15) * 4, k = idx >> 4;
+                *(f32x4*)&As[k][r4] = ga[e];
+            }
+            if (B_KC) {
+                const int k4 = (idx & 7) * 4, r = idx >> 3;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Bs[k4 + c][r] = gb[e][c];
+            } else {
+                const int r4 = (idx & 15) * 4, k = idx >> 4;
+                *(f32x4*)&Bs[k][r4] = gb[e];
+            }
+        }
+    };
+    gload(0);
+    const int i16 = lane & 15, kq = lane >> 4;
+    for (int k0 = 0; k0 < p.K; k0 += FBK) {
+        __syncthreads();            // previous tile's LDS reads are done
+        sstore();
+        __syncthreads();
+        if (k0 + FBK < p.K) gload(k0 + FBK);   // in flight under the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < FBK; ks += 4) {
+            float fa[2], fb[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fa[j] = As[ks + kq][wm * 32 + j * 16 + i16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fb[i] = Bs[ks + kq][wn * 32 + i * 16 + i16];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int g = lane >> 4, mi = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wm * 32 + j * 16 + mi;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 32 + i * 16 + g * 4 + r;
+                if (n >= p.N) continue;
+                float v = acc[i][j][r];
+                if (p.bias) v += p.bias[n];
+                float* c = p.C + (long)m * p.ldc + n;
+                *c = p.accumulate ? (*c + v) : v;
+            }
+    }
+}
+
 // ---------------------------------------------------------------- LayerNorm (one row per block)
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -355,7 +464,21 @@ int nv_gemm_f32(int layout, const float* A, const float* B, float* C, const floa
         case 2: p.sam = 1; p.sak = lda; p.sbn = 1; p.sbk = ldb; break;
         default: return NV_ERR_ARG;
     }
-    NV_LAUNCH(gemm_f32_kernel, dim3((N + FBN - 1) / FBN, (M + FBM - 1) / FBM), dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 grid((N + FBN - 1) / FBN, (M + FBM - 1) / FBM);
+    // vector path: 16-B loads need aligned, 4-divisible extents along each operand's contiguous dimension
+    const bool a_kc = (layout != 2), b_kc = (layout == 0);
+    const bool aligned = !((((uintptr_t)A) | ((uintptr_t)B)) & 15) && !(lda & 3) && !(ldb & 3) &&
+                         (a_kc ? !(K & 3) : !(M & 3)) && (b_kc ? !(K & 3) : !(N & 3));
+    if (aligned) {
+        const long a_rows = a_kc ? M : K, a_cols = a_kc ? K : M, b_rows = b_kc ? N : K, b_cols = b_kc ? K : N;
+        const uint32_t ab = (uint32_t)(((a_rows - 1) * (long)lda + a_cols) * 4), bb = (uint32_t)(((b_rows - 1) * (long)ldb + b_cols) * 4);
+        hipStream_t st = (hipStream_t)stream;
+        if (layout == 0) NV_LAUNCH((gemm_f32_vec_kernel<true, true>), grid, dim3(256), 0, st, p, ab, bb);
+        else if (layout == 1) NV_LAUNCH((gemm_f32_vec_kernel<true, false>), grid, dim3(256), 0, st, p, ab, bb);
+        else NV_LAUNCH((gemm_f32_vec_kernel<false, false>), grid, dim3(256), 0, st, p, ab, bb);
+        return nv_check_launch();
+    }
+    NV_LAUNCH(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return nv_check_launch();
 }
 

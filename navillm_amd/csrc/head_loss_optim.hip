@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256) void head_bwd_dw_kernel(const bf16_t* __restri
 // dlogits[b,j] = bf16(gscale * (p_j - [j==t])) (0 if ignored / -inf slots)
 __global__ __launch_bounds__(64) void action_ce_kernel(const bf16_t* __restrict__ logits, const long* __restrict__ targets,
                                                        float* __restrict__ loss_rows, bf16_t* __restrict__ dlogits, int G,
-                                                       float gscale) {
+                                                       float gscale, const float* __restrict__ gscale_dev) {
+    if (gscale_dev) gscale *= gscale_dev[0];
     const int b = blockIdx.x, lane = threadIdx.x;
     const long t = targets[b];
     const bf16_t* lr = logits + (long)b * G;
@@ -230,11 +231,11 @@ int nv_head_bwd_bf16(const void* dy, const void* x, const void* W, void* dx, voi
     return nv_check_launch();
 }
 int nv_action_ce_bf16(const void* logits, const long* targets, float* loss_rows, void* dlogits, int B, int G, float gscale,
-                      void* stream) {
+                      const float* gscale_dev, void* stream) {
     if (!logits || !targets || !loss_rows) return NV_ERR_ARG;
     if (B == 0) return NV_OK;
     NV_LAUNCH(action_ce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)logits, targets, loss_rows,
-                       (bf16_t*)dlogits, G, gscale);
+                       (bf16_t*)dlogits, G, gscale, gscale_dev);
     return nv_check_launch();
 }
 int nv_lm_ce_bf16(void* logits, const int* labels, float* loss_rows, int M, int V, int ldl, int special0, int nspecial,

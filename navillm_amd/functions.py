@@ -245,7 +245,8 @@ class EmbedVis(torch.autograd.Function):
         seg = torch.zeros(uniq.numel() + 1, dtype=torch.int32)
         seg[1:] = torch.cumsum(counts, 0)
         dev = dE.device
-        ops.embed_grad(dE, uniq.int().to(dev), seg.to(dev), order.int().to(dev), st.g("lang_model.model.embed_tokens.weight"))
+        ops.embed_grad(dE, ops.h2d(uniq, dev, torch.int32), ops.h2d(seg, dev), ops.h2d(order, dev, torch.int32),
+                       st.g("lang_model.model.embed_tokens.weight"))
         return dvis, None, None, None, None, None, None
 
 
@@ -442,7 +443,8 @@ class LMHeadLoss(torch.autograd.Function):
 
 
 class ActionCE(torch.autograd.Function):
-    """CrossEntropyLoss(ignore_index=-100, reduction='sum') on bf16 logits (train.py:229)."""
+    """CrossEntropyLoss(ignore_index=-100, reduction='sum') on bf16 logits (train.py:229).
+    The upstream gradient (the loss coefficient, mp3d_agent.py:750) stays on the device: no host sync."""
 
     @staticmethod
     def forward(ctx, logits, targets):
@@ -454,5 +456,5 @@ class ActionCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         logits, targets = ctx.saved_tensors
-        _, dl = ops.action_ce(logits, targets, gscale=float(g), want_grad=True)
+        _, dl = ops.action_ce(logits, targets, gscale=1.0, gscale_dev=g.reshape(1).float(), want_grad=True)
         return dl, None

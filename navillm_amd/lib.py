@@ -35,7 +35,7 @@ SIGNATURES = {
     "nv_attn_bwd_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, vp]),
     "nv_head_fwd_bf16": (i, [vp, vp, vp, vp, i, i, i, vp]),
     "nv_head_bwd_bf16": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
-    "nv_action_ce_bf16": (i, [vp, lp, fp, vp, i, i, f, vp]),
+    "nv_action_ce_bf16": (i, [vp, lp, fp, vp, i, i, f, fp, vp]),
     "nv_lm_ce_bf16": (i, [vp, ip, fp, i, i, i, i, i, f, i, vp]),
     "nv_sumsq": (i, [vp, l, i, fp, C.POINTER(C.c_int), vp]),
     "nv_clip_coef": (i, [fp, i, f, fp, vp]),

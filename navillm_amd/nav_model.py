@@ -209,7 +209,7 @@ class NavModel(nn.Module):
         return Fn.dropout(x, p, self.training, m)
 
     def _i32(self, t):
-        return torch.as_tensor(t).to(device=self.device, dtype=torch.int32).contiguous()
+        return ops.h2d(t, self.device, torch.int32).contiguous()
 
     # ------------------------------------------------------------------ forward dispatch (nav_model.py:96-126)
     def forward(self, mode, batch, **kwargs):
@@ -239,19 +239,19 @@ class NavModel(nn.Module):
                                   obj_lens=None, obj_loc_fts=None):
         cfg = self.cfg
         e = "img_embeddings"
-        view_img_fts = view_img_fts.to(self.device, F32)
+        view_img_fts = ops.h2d(view_img_fts, self.device, F32)
         B, N, _ = view_img_fts.shape
         h = cfg.enc_hidden_size
         x = self._ln(self._lin(view_img_fts, e + ".img_linear"), e + ".img_layer_norm", 1e-12)
         if loc_fts is None:
             loc_fts = torch.zeros((B, N, 7), dtype=F32, device=self.device)
-        x = Fn.add(x, self._ln(self._lin(loc_fts.to(self.device, F32), e + ".loc_linear"), e + ".loc_layer_norm", 1e-12))
+        x = Fn.add(x, self._ln(self._lin(ops.h2d(loc_fts, self.device, F32), e + ".loc_linear"), e + ".loc_layer_norm", 1e-12))
         if nav_types is None:
             nav_types = torch.ones((B, N), dtype=torch.int32, device=self.device)
         x = Fn.EmbedAddF32.apply(self.P(e + ".nav_type_embedding.weight"), self._i32(nav_types).view(-1), x)
         x = self._ln(x, e + ".layer_norm", 1e-12)
         x = self._drop(x, cfg.enc_dropout, "emb.drop")
-        lens_dev = torch.as_tensor(view_lens).to(self.device)
+        lens_dev = ops.h2d(view_lens, self.device)
         pano_masks = torch.arange(N, device=self.device).unsqueeze(0) < lens_dev.unsqueeze(1)
         lens_i32 = lens_dev.to(torch.int32).contiguous()
         heads, hd = cfg.enc_num_heads, h // cfg.enc_num_heads
@@ -273,8 +273,8 @@ class NavModel(nn.Module):
         x = Fn.RowScaleF32.apply(x, pano_masks.to(F32).view(-1).contiguous()).view(B, N, cfg.hidden_size)
         ret = {"pano_embeds": x, "pano_masks": pano_masks}
         if obj_img_fts is not None and obj_img_fts.shape[1] > 0:
-            oe = self._seq2(obj_img_fts.to(self.device, F32), e + ".obj_projector")
-            ol = torch.as_tensor(obj_lens).to(self.device)
+            oe = self._seq2(ops.h2d(obj_img_fts, self.device, F32), e + ".obj_projector")
+            ol = ops.h2d(obj_lens, self.device)
             obj_masks = torch.arange(obj_img_fts.shape[1], device=self.device).unsqueeze(0) < ol.unsqueeze(1)
             assert oe.shape[:2] == obj_loc_fts.shape[:2], \
                 f"shape of obj_embeds {oe.shape[:2]} must equal to shape of obj_loc_fts {obj_loc_fts.shape[:2]}"
@@ -309,13 +309,13 @@ class NavModel(nn.Module):
             parts.append(vis.to(F32))
             off += loc.numel()
         vis_all = torch.cat(parts, 0).contiguous() if parts else None
-        vis_rows = torch.cat(rows).to(self.device) if rows else None
+        vis_rows = ops.h2d(torch.cat(rows), self.device) if rows else None
         am = am_cpu.bool()
         kv_start = (am.int().cumsum(1) == 0).sum(1).to(torch.int32)
         assert bool((am == (torch.arange(S)[None] >= kv_start[:, None])).all()), "attention_mask must be left padding"
         E = Fn.EmbedVis.apply(vis_all, self._anchor if torch.is_grad_enabled() else None, self,
-                              flat.to(torch.int32).to(self.device), vis_idx.to(self.device), vis_rows, flat)
-        return Fn.LlamaStack.apply(E, self, B, S, kv_start.to(self.device))
+                              ops.h2d(flat, self.device, torch.int32), ops.h2d(vis_idx, self.device), vis_rows, flat)
+        return Fn.LlamaStack.apply(E, self, B, S, ops.h2d(kv_start, self.device))
 
     def _lm_loss(self, Hs, ids_cpu, labels_cpu):
         """shifted mean CE over labels != -100 (modified_lm.py:126-137)."""
@@ -323,7 +323,7 @@ class NavModel(nn.Module):
         shift = torch.full((B, S), -100, dtype=torch.int64)
         shift[:, :-1] = labels_cpu[:, 1:]
         n_valid = int((shift != -100).sum())
-        return Fn.LMHeadLoss.apply(Hs, self, shift.view(-1).to(torch.int32).to(self.device), n_valid)
+        return Fn.LMHeadLoss.apply(Hs, self, ops.h2d(shift.view(-1), self.device, torch.int32), n_valid)
 
     @staticmethod
     def _stack_hist(hist_vis):
@@ -332,7 +332,7 @@ class NavModel(nn.Module):
 
     def _cls_rows(self, ids_cpu):
         loc = torch.nonzero(ids_cpu.reshape(-1) == self.cfg.cls_token_ids[0]).view(-1)
-        return loc.to(torch.int32).to(self.device)
+        return ops.h2d(loc, self.device, torch.int32)
 
     # ------------------------------------------------------------------ navigation (nav_model.py:129-247)
     def forward_navigation(self, mode, batch, training=True, **kwargs):
@@ -349,13 +349,13 @@ class NavModel(nn.Module):
         g_vpids, vp_cand_vpids = batch["gmap_vpids"], batch["vp_cand_vpids"]
 
         # global branch (:146-150) and local branch (:159-162)
-        gmap = Fn.EmbedAddF32.apply(self.P("gmap_step_embeddings.weight"), self._i32(g_step).view(-1), g_img.to(dev, F32))
-        gmap = Fn.add(gmap, self._seq2(g_pos.to(dev, F32), "gmap_pos_embeddings"))
-        vp = Fn.add(vp_img, self._seq2(batch["vp_pos_fts"].to(dev, F32), "vp_pos_embeddings"))
+        gmap = Fn.EmbedAddF32.apply(self.P("gmap_step_embeddings.weight"), self._i32(g_step).view(-1), ops.h2d(g_img, dev, F32))
+        gmap = Fn.add(gmap, self._seq2(ops.h2d(g_pos, dev, F32), "gmap_pos_embeddings"))
+        vp = Fn.add(vp_img, self._seq2(ops.h2d(batch["vp_pos_fts"], dev, F32), "vp_pos_embeddings"))
         keep_g = (gm_cpu & ~gv_cpu)
-        keep_g_dev = keep_g.to(F32).view(-1).to(dev)
+        keep_g_dev = ops.h2d(keep_g.view(-1), dev, F32)
         gmap = Fn.RowScaleF32.apply(gmap.view(B * G, d), keep_g_dev)
-        pm = torch.as_tensor(batch["pano_masks"]).to(dev).to(F32).view(-1).contiguous()
+        pm = ops.h2d(batch["pano_masks"], dev).to(F32).view(-1).contiguous()
         vp = Fn.RowScaleF32.apply(vp.view(B * Nv, d), pm)
 
         # host: which current-view candidate feeds which map slot (:174-190)
@@ -375,8 +375,8 @@ class NavModel(nn.Module):
                         inv[i * Nv + tmp[v]] = i * G + j
                     else:
                         ttype[i * G + j] = 1
-        fuse = Fn.GatherRowsF32.apply(vp, src.to(dev), inv.to(dev), gmap)
-        fuse = Fn.EmbedAddF32.apply(self.P("token_type_embeddings.weight"), ttype.to(dev), fuse)
+        fuse = Fn.GatherRowsF32.apply(vp, ops.h2d(src, dev), ops.h2d(inv, dev), gmap)
+        fuse = Fn.EmbedAddF32.apply(self.P("token_type_embeddings.weight"), ops.h2d(ttype, dev), fuse)
         fuse = Fn.RowScaleF32.apply(fuse, keep_g_dev)                       # [B*G, d]
 
         cand_masks = keep_g
@@ -392,7 +392,7 @@ class NavModel(nn.Module):
             for s in slots[rp].tolist():
                 inv_sel[b * G + s] = len(sel)
                 sel.append(b * G + s)
-        cand_embeds = Fn.GatherRowsF32.apply(fuse, torch.tensor(sel, dtype=torch.int32, device=dev), inv_sel.to(dev), None)
+        cand_embeds = Fn.GatherRowsF32.apply(fuse, ops.h2d(torch.tensor(sel, dtype=torch.int32), dev), ops.h2d(inv_sel, dev), None)
 
         hist_vis = self._stack_hist(batch["hist_vis"])
         ids, am, _ = self._tokens(batch, batch["prompts"])
@@ -406,7 +406,7 @@ class NavModel(nn.Module):
             n = int(cand_nums[b])
             col[b, slots[0]] = 0
             col[b, slots[1:]] = 1 + inv_perms[b][: n - 1]
-        logits = torch.gather(pred, 1, col.to(dev)).masked_fill(cand_masks.logical_not().to(dev), float("-inf"))
+        logits = torch.gather(pred, 1, ops.h2d(col, dev)).masked_fill(ops.h2d(cand_masks.logical_not(), dev), float("-inf"))
         return {"fuse_embeds": fuse.detach().view(B, G, d), "fuse_logits": logits}
 
     # ------------------------------------------------------------------ object grounding (nav_model.py:407-451)
@@ -414,17 +414,17 @@ class NavModel(nn.Module):
         dev, d = self.device, self.cfg.hidden_size
         obj_embeds, obj_masks = batch["obj_embeds"], torch.as_tensor(batch["obj_masks"]).cpu().bool()
         B, O, _ = obj_embeds.shape
-        oe = Fn.add(obj_embeds, self._seq2(batch["obj_loc_fts"].to(dev, F32), "obj_pos_embeddings")).view(B * O, d)
+        oe = Fn.add(obj_embeds, self._seq2(ops.h2d(batch["obj_loc_fts"], dev, F32), "obj_pos_embeddings")).view(B * O, d)
         cand_nums = obj_masks.sum(1) + 1
         sel = torch.nonzero(obj_masks.view(-1)).view(-1).to(torch.int32)
         inv = torch.full((B * O,), -1, dtype=torch.int32)
         inv[sel.long()] = torch.arange(sel.numel(), dtype=torch.int32)
-        cand_vis = Fn.GatherRowsF32.apply(oe, sel.to(dev), inv.to(dev), None) if sel.numel() else None
+        cand_vis = Fn.GatherRowsF32.apply(oe, ops.h2d(sel, dev), ops.h2d(inv, dev), None) if sel.numel() else None
         ids, am, _ = self._tokens(batch, batch["prompts"])
         Hs = self._lm(ids, am, cand_vis=cand_vis, hist_vis=self._stack_hist(batch["hist_vis"]))
         pred = Fn.HeadBF16.apply(Fn.GatherRowsBF16.apply(Hs, self._cls_rows(ids)), self, "out_head.0")
         dead = torch.arange(pred.shape[1])[None] >= cand_nums[:, None]
-        return {"obj_logits": pred.masked_fill(dead.to(dev), float("-inf"))}
+        return {"obj_logits": pred.masked_fill(ops.h2d(dead, dev), float("-inf"))}
 
     # ------------------------------------------------------------------ LM-loss modes, training branches
     def _zero_pose_type0(self, rows):
@@ -437,7 +437,7 @@ class NavModel(nn.Module):
         if not training:
             raise NotImplementedError("3dqa generation path: SURVEY.md §8f item 2 (next)")
         dev, d = self.device, self.cfg.hidden_size
-        feats = [f.to(dev, F32) for f in batch["features"]]
+        feats = [ops.h2d(f, dev, F32) for f in batch["features"]]
         B = len(feats)
         N = max(f.shape[0] for f in feats)
         vf = torch.zeros((B, N, feats[0].shape[1]), dtype=F32, device=dev)
@@ -450,7 +450,7 @@ class NavModel(nn.Module):
         sel = torch.nonzero(pm.view(-1)).view(-1).to(torch.int32)
         inv = torch.full((B * N,), -1, dtype=torch.int32)
         inv[sel.long()] = torch.arange(sel.numel(), dtype=torch.int32)
-        cand_vis = Fn.GatherRowsF32.apply(pe, sel.to(dev), inv.to(dev), None)
+        cand_vis = Fn.GatherRowsF32.apply(pe, ops.h2d(sel, dev), ops.h2d(inv, dev), None)
         if batch.get("input_ids") is None:
             eos = self.lang_model.tokenizer.eos_token
             text = [[batch["prompts"][bn], batch["answers"][bn][0] + f"{eos}"] for bn in range(B)]
@@ -474,7 +474,7 @@ class NavModel(nn.Module):
         sel = torch.nonzero(nav_masks.reshape(-1)).view(-1).to(torch.int32)
         inv = torch.full((B * N,), -1, dtype=torch.int32)
         inv[sel.long()] = torch.arange(sel.numel(), dtype=torch.int32)
-        cand_vis = Fn.GatherRowsF32.apply(x, sel.to(dev), inv.to(dev), None) if sel.numel() else None
+        cand_vis = Fn.GatherRowsF32.apply(x, ops.h2d(sel, dev), ops.h2d(inv, dev), None) if sel.numel() else None
         if batch.get("input_ids") is None:
             eos = self.lang_model.tokenizer.eos_token
             dt = batch["data_type"][0]

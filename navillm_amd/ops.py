@@ -25,6 +25,19 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+def h2d(t, device, dtype=None):
+    """host -> device copy that does not stall the host: a pageable-memory copy blocks until the stream has
+    drained (i.e. until the previous step's backward is done), which serialises the host-side input building
+    with the GPU.  Staging through torch's cached pinned pool makes the copy asynchronous and stream-ordered."""
+    t = torch.as_tensor(t)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    device = torch.device(device)
+    if t.device.type == "cpu" and device.type == "cuda":
+        return t.contiguous().pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
 def _chk2d(t, dt):
     assert t.is_cuda and t.dtype == dt and t.dim() == 2 and t.stride(1) == 1, (t.shape, t.dtype, t.stride())
 
@@ -210,13 +223,14 @@ def head_bwd(dy, x, W, gW, gb):
     return dx
 
 
-def action_ce(logits, targets_i64, gscale=1.0, want_grad=True):
+def action_ce(logits, targets_i64, gscale=1.0, want_grad=True, gscale_dev=None):
+    """gscale_dev: optional 1-element fp32 DEVICE tensor multiplied into gscale (keeps the coefficient off the host)."""
     B, G = logits.shape
     logits = logits.contiguous()
     loss_rows = torch.empty((B,), dtype=F32, device=logits.device)
     dl = torch.empty_like(logits) if want_grad else None
     _lib.check(_L().nv_action_ce_bf16(logits.data_ptr(), targets_i64.data_ptr(), loss_rows.data_ptr(), _p(dl), B, G, gscale,
-                                      _st()), "nv_action_ce_bf16")
+                                      _p(gscale_dev), _st()), "nv_action_ce_bf16")
     return loss_rows, dl
 
 

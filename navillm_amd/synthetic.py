@@ -123,8 +123,8 @@ class SyntheticEpisodes:
             nav[b, :k] = 1
             cand_vpids.append([c["viewpointId"] for c in ob["candidate"]])
         d = self.device
-        return {"view_img_fts": x.to(d), "loc_fts": self.loc_fts.unsqueeze(0).repeat(B, 1, 1).to(d),
-                "nav_types": nav.to(d), "view_lens": torch.full((B,), N, dtype=torch.int64).to(d),
+        return {"view_img_fts": ops.h2d(x, d), "loc_fts": ops.h2d(self.loc_fts.unsqueeze(0).repeat(B, 1, 1), d),
+                "nav_types": ops.h2d(nav, d), "view_lens": ops.h2d(torch.full((B,), N, dtype=torch.int64), d),
                 "cand_vpids": cand_vpids}
 
     def update_maps(self, pano_embeds, pano_masks, cand_vpids):
@@ -172,9 +172,9 @@ class SyntheticEpisodes:
             sf = gmap.get_pos_fts(self.cur[b], [gmap.start_vp], self.heading[b], 0.0)
             vp_pos[b, :, :7] = sf
             vp_pos[b, 1:len(cf) + 1, 7:] = cf
-        return {"gmap_vpids": vpids, "gmap_img_embeds": gimg, "gmap_step_ids": gstep.to(dev), "gmap_pos_fts": gpos.to(dev),
-                "gmap_visited_masks": gvis.to(dev), "gmap_masks": gmask.to(dev), "vp_img_embeds": vp_img,
-                "pano_masks": pm, "vp_pos_fts": torch.from_numpy(vp_pos).to(dev),
+        return {"gmap_vpids": vpids, "gmap_img_embeds": gimg, "gmap_step_ids": ops.h2d(gstep, dev), "gmap_pos_fts": ops.h2d(gpos, dev),
+                "gmap_visited_masks": ops.h2d(gvis, dev), "gmap_masks": ops.h2d(gmask, dev), "vp_img_embeds": vp_img,
+                "pano_masks": pm, "vp_pos_fts": ops.h2d(torch.from_numpy(vp_pos), dev),
                 "vp_nav_masks": torch.ones(B, Nv, dtype=torch.bool, device=dev),
                 "vp_cand_vpids": [[None] + x for x in cand_vpids], "hist_vis": self.hist_vis, "history": self.history,
                 "data_type": ["r2r"] * B, "instruction": ["{INSTR}"] * B,
@@ -238,7 +238,7 @@ def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accu
         targets = ep.teacher_targets(nav, last)
         loss = None
         if train:
-            loss = criterion(logits, targets.to(logits.device)) * loss_weight / ep.B / accum
+            loss = criterion(logits, ops.h2d(targets, logits.device)) * loss_weight / ep.B / accum
             loss.backward()
             actions = targets
         else:
