@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--feat", type=int, default=768, help="view feature size (768 per BASELINE.json, 1024 = EVA-CLIP-L)")
     ap.add_argument("--instr-len", type=int, default=512)
     ap.add_argument("--lr", type=float, default=3e-5)
+    ap.add_argument("--prewarm", type=int, default=6, help="untimed setup steps before the W warmup steps (one full episode: "
+                    "first-use kernel/attribute/allocator/RCCL initialisation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch GEMM event timing")
     return ap.parse_args()
@@ -159,6 +161,9 @@ def main():
             ep.reset()
         return loss
 
+    for i in range(a.prewarm):          # setup, not part of the protocol's W/K accounting
+        one_step(i)
+    ep.reset()
     for i in range(a.warmup):
         one_step(i)
     if not a.no_profile:

@@ -91,6 +91,10 @@ class NavDataParallel(torch.nn.Module):
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             for t in self.module.store.param.values():
                 dist.broadcast(t, src=0, group=self.group)
+            # touch the all-reduce path once (communicator/channel setup) so the first synced backward
+            # does not pay for it
+            probe = torch.zeros(1024, dtype=torch.float32, device=self.module.store.device)
+            dist.all_reduce(probe, group=self.group)
 
     @contextlib.contextmanager
     def no_sync(self):

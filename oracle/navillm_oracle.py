@@ -320,6 +320,20 @@ def qa_3d_loss(P, cfg, features, input_ids, attention_mask, token_type_ids):
     return loss
 
 
+def summarization_loss(P, cfg, vp_img_embeds, vp_nav_masks, hist_vis, input_ids, attention_mask, token_type_ids):
+    """NavModel.forward_summarization training branch (also mode 'embodied_qa'), nav_model.py:251-319."""
+    x = vp_img_embeds[:, 1:, :]
+    nm = vp_nav_masks[:, 1:].bool()
+    x = x + _seq2(torch.zeros(x.shape[:2] + (14,)), P, "vp_pos_embeddings")
+    x = x + P["token_type_embeddings.weight"][0]
+    hv = [v for vis in hist_vis for v in vis]
+    hist = torch.stack(hv, 0) if hv else None
+    labels = input_ids.clone()
+    labels[token_type_ids == 0] = -100
+    loss, _, _ = lm_forward(P, cfg, input_ids, attention_mask, labels=labels, cand_vis=x[nm], hist_vis=hist)
+    return loss
+
+
 def action_loss(logits, targets):
     """train.py:229 criterion: CrossEntropyLoss(ignore_index=-100, reduction='sum')."""
     return F.cross_entropy(logits, targets, ignore_index=-100, reduction="sum")

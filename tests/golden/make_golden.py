@@ -327,6 +327,40 @@ def gen_precision(prec, seed=11):
          hist_vis_flat=torch.stack([v for vis in hv for v in vis], 0), obj_embeds=po["obj_embeds"],
          obj_logits=oo["obj_logits"], meta=np.array(json.dumps(dict(hist_t=hist_t5, prompts=oprompts))))
 
+    # ---- G5s summarization / embodied_qa(fgr2r) training losses (nav_model.py:251-319; on the training path
+    #      with --enable_summarize / --enable_fgr2r, mp3d_agent.py:845-909)
+    with torch.no_grad():
+        pin_s, cand_k_s = pano_inputs(cfg, g5, B, N)
+        ps = model("panorama", dict(pin_s))
+        vp_img = torch.cat([torch.zeros_like(ps["pano_embeds"][:, :1]), ps["pano_embeds"]], 1)
+        nav_masks = torch.cat([torch.ones(B, 1, dtype=torch.bool), pin_s["nav_types"] == 1], 1)
+        hist_ts = [2, 1, 0]
+        hvs = [[torch.randn(cfg.hidden_size, generator=g5) for _ in range(hist_ts[b])] for b in range(B)]
+        cn = nav_masks[:, 1:].sum(1)
+        out_s = {}
+        for mode, dtype_, answers in (("summarization", "r2r", ["", "", ""]),
+                                      ("embodied_qa", "fgr2r", ["turn left at the door", "go up the stairs", "wait near the sofa"])):
+            instr = INSTR if mode == "summarization" else ["where are we going with direction (1) ?"] * B
+            hv_m = hvs if mode == "summarization" else [[] for _ in range(B)]
+            hist_n = hist_ts if mode == "summarization" else [0] * B
+            fn = R2RAgent.get_summarization_prompt if mode == "summarization" else R2RAgent.get_embodied_qa_prompt
+            prompts_s = [fn(None, instr[b], hist_n[b], int(cn[b])) for b in range(B)]
+            sb = dict(vp_img_embeds=vp_img.clone(), vp_pos_fts=torch.zeros(B, N + 1, 14), vp_nav_masks=nav_masks,
+                      vp_cand_vpids=[[None]] * B, instruction=instr, answer=answers, history=[["<hist>"] * t for t in hist_n],
+                      hist_vis=hv_m, data_type=[dtype_] * B, prompts=prompts_s)
+            o = model(mode, sb, training=True)
+            labels_txt = [(answers[b] if dtype_ in ("eqa", "fgr2r") else instr[b]) + lm.tokenizer.eos_token for b in range(B)]
+            tk = lm.tokenize([[prompts_s[b], labels_txt[b]] for b in range(B)])
+            out_s[mode] = (o["loss"], tk, prompts_s, labels_txt)
+    hv_flat = torch.stack([v for vis in hvs for v in vis], 0)
+    save(f"g5_sum_{tag}.npz", **pin_s, vp_nav_masks=nav_masks, hist_vis_flat=hv_flat,
+         sum_input_ids=out_s["summarization"][1]["input_ids"], sum_attention_mask=out_s["summarization"][1]["attention_mask"],
+         sum_token_type_ids=out_s["summarization"][1]["token_type_ids"], sum_loss=out_s["summarization"][0],
+         qa_input_ids=out_s["embodied_qa"][1]["input_ids"], qa_attention_mask=out_s["embodied_qa"][1]["attention_mask"],
+         qa_token_type_ids=out_s["embodied_qa"][1]["token_type_ids"], qa_loss=out_s["embodied_qa"][0],
+         meta=np.array(json.dumps(dict(hist_t=hist_ts, sum_prompts=out_s["summarization"][2], sum_labels=out_s["summarization"][3],
+                                       qa_prompts=out_s["embodied_qa"][2], qa_labels=out_s["embodied_qa"][3]))))
+
     feats = [torch.randn(n, cfg.image_feat_size, generator=g5) for n in (6, 4, 5)]
     qprompts = ["### Question: what color is the chair ? ### Answer: ",
                 "### Question: what is near the window ? ### Answer: ",

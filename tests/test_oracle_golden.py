@@ -124,6 +124,24 @@ def test_g5_object_grounding_and_qa(tag):
     close(loss, q["loss"], 1e-5 if tag == "fp32" else 2e-2, what="3dqa loss")
 
 
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_g5_summarization_and_fgr2r_losses(tag):
+    z = gold(f"g5_sum_{tag}.npz")
+    cfg, P = tiny_weights(tag)
+    m = meta_of(z)
+    with torch.no_grad():
+        ps = O.scene_encoder(P, cfg, T(z["view_img_fts"]), T(z["view_lens"]), T(z["loc_fts"]), T(z["nav_types"]))
+        vp = torch.cat([torch.zeros_like(ps["pano_embeds"][:, :1]), ps["pano_embeds"]], 1)
+        hv = hist_lists(T(z["hist_vis_flat"]), m["hist_t"])
+        ls = O.summarization_loss(P, cfg, vp, T(z["vp_nav_masks"]), hv, T(z["sum_input_ids"]), T(z["sum_attention_mask"]),
+                                  T(z["sum_token_type_ids"]))
+        lq = O.summarization_loss(P, cfg, vp, T(z["vp_nav_masks"]), [[] for _ in m["hist_t"]], T(z["qa_input_ids"]),
+                                  T(z["qa_attention_mask"]), T(z["qa_token_type_ids"]))
+    tol = 1e-5 if tag == "fp32" else 4e-2
+    close(ls, z["sum_loss"], tol, what="summarization loss")
+    close(lq, z["qa_loss"], tol, what="fgr2r loss")
+
+
 def test_g8_clip_adamw():
     z = gold("g8_adamw.npz")
     ps = [T(z[f"p0_{i}"]) for i in range(3)]

@@ -164,6 +164,26 @@ def test_g5_object_grounding_and_qa_vs_reference():
     assert abs(float(out.loss) - float(q["loss"])) <= 0.04
 
 
+def test_g5_summarization_and_fgr2r_losses_vs_reference():
+    z = gold("g5_sum_bf16.npz")
+    m = build(tiny_cfg("bf16"))
+    meta = meta_of(z)
+    B = len(meta["hist_t"])
+    with torch.no_grad():
+        ps = m("panorama", pano_batch(z))
+        vp = torch.cat([torch.zeros_like(ps["pano_embeds"][:, :1]), ps["pano_embeds"]], 1)
+        hv = hist_lists(dev(z["hist_vis_flat"]), meta["hist_t"])
+        common = dict(vp_img_embeds=vp, vp_nav_masks=T(z["vp_nav_masks"]), instruction=["x"] * B, answer=["y"] * B)
+        o1 = m("summarization", dict(common, hist_vis=hv, data_type=["r2r"] * B, input_ids=T(z["sum_input_ids"]),
+                                     attention_mask=T(z["sum_attention_mask"]), token_type_ids=T(z["sum_token_type_ids"])),
+               training=True)
+        o2 = m("embodied_qa", dict(common, hist_vis=[[] for _ in range(B)], data_type=["fgr2r"] * B,
+                                   input_ids=T(z["qa_input_ids"]), attention_mask=T(z["qa_attention_mask"]),
+                                   token_type_ids=T(z["qa_token_type_ids"])), training=True)
+    assert abs(float(o1["loss"]) - float(z["sum_loss"])) <= 0.04      # bf16 scalar: 1 ulp at ~5.5 = 0.03125
+    assert abs(float(o2["loss"]) - float(z["qa_loss"])) <= 0.04
+
+
 def test_tokenizer_path_matches_fixture_ids():
     """drop-in tokenisation: the attached LlamaTokenizer reproduces the reference's ids."""
     import os
