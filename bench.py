@@ -69,20 +69,35 @@ class GemmTimer:
             e1.record()
             M, N = r.shape
             K = A.shape[1] if layout != 2 else A.shape[0]
-            timer.recs.append((2.0 * M * N * K, e0, e1))
+            timer.recs.append((2.0 * M * N * K, e0, e1, layout))
             return r
         ops.gemm_bf16 = timed
 
     def uninstall(self):
         self.ops.gemm_bf16 = self.orig
 
-    def summary(self):
-        if not self.recs:
+    def summary(self, layouts=(0,)):
+        """Forward GEMMs (layout NT) run alone on the stream, so event brackets are kernel durations.  The
+        backward's dgrad (NN) and wgrad (TN) GEMMs run CONCURRENTLY on two streams (navillm_amd/functions.py):
+        their brackets overlap and are reported separately, not as the roofline number."""
+        recs = [r for r in self.recs if r[3] in layouts]
+        if not recs:
             return None
-        fl = sum(r[0] for r in self.recs)
-        sec = sum(r[1].elapsed_time(r[2]) for r in self.recs) * 1e-3
-        return {"launches": len(self.recs), "flops_per_launch": fl / len(self.recs),
-                "avg_launch_ms": sec / len(self.recs) * 1e3, "tflops": fl / sec / 1e12, "gemm_seconds": sec}
+        fl = sum(r[0] for r in recs)
+        sec = sum(r[1].elapsed_time(r[2]) for r in recs) * 1e-3
+        return {"launches": len(recs), "flops_per_launch": fl / len(recs),
+                "avg_launch_ms": sec / len(recs) * 1e3, "tflops": fl / sec / 1e12, "gemm_seconds": sec}
+
+
+def gemm_traffic_from_profile():
+    """HBM bytes per forward-GEMM launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2
+    per the gfx950 correction + WRITE_SIZE; separate --pmc runs of this same command); None if absent."""
+    pth = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+    try:
+        with open(pth) as f:
+            return json.load(f)["hbm_bytes_per_forward_gemm_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(a, cfg, seed):
@@ -202,12 +217,17 @@ def main():
                        "parallelism": f"dp{world}", "loss": float(loss.detach()) if loss is not None else None},
         }
         if g is not None:
+            allg = timer.summary(layouts=(0, 1, 2))
             line["roofline"] = {"bound": "mfma", "achieved": round(g["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(g["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-                                "kernel": "gemm_bf16_kernel (NT/NN/TN, 256x256x64 tiles)", "launches": g["launches"],
-                                "avg_launch_ms": round(g["avg_launch_ms"], 4),
+                                "unit": "TFLOP/s", "frac": round(g["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+                                "traffic": gemm_traffic_from_profile(),
+                                "kernel": "gemm_bf16_kernel<256,256,2,4,64,2,true,true,*,4> (forward y = x W^T launches: qkv, o, "
+                                          "gate|up, down of every layer; they run alone on the stream)",
+                                "launches": g["launches"], "avg_launch_ms": round(g["avg_launch_ms"], 4),
                                 "flops_per_launch": g["flops_per_launch"],
-                                "gemm_share_of_step": round(g["gemm_seconds"] / dt, 3)}
+                                "all_gemm_flops_per_step": allg["flops_per_launch"] * allg["launches"] / a.steps,
+                                "note": "dgrad/wgrad GEMMs overlap on two HIP streams; their per-launch brackets are not "
+                                        "kernel durations and are excluded here (rocprof per-kernel stats: profiles/)"}
         if not a.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(a, cfg, 1234)

@@ -48,33 +48,36 @@ __device__ __forceinline__ int mn_key(int krow) { return (krow & 3) | (((krow >>
 template <int BKT>
 __device__ __forceinline__ int km_swz(int row) { return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
+// One wave-instruction of an operand tile's DMA: fills LDS bytes [chunk*1024, +1024) of the [R x BKT] image.
+template <int R, bool KMAJ, int NT, int BKT>
+__device__ __forceinline__ void stage_piece(const u32x4& desc, uint32_t lds, int row0, int k0, int ld, int tid, int it) {
+    const int wave = tid >> 6, lane = tid & 63;
+    const int chunk = it * (NT / 64) + wave;
+    uint32_t voff;
+    if (KMAJ) {
+        constexpr int SLOTS = BKT / 8;                     // 16-B slots per row
+        constexpr int RPK = 64 / SLOTS;                    // rows per KiB
+        const int row = chunk * RPK + lane / SLOTS;
+        const int slot = (lane % SLOTS) ^ km_swz<BKT>(row);  // logical slot living at this phys slot
+        voff = (uint32_t)(((long)(row0 + row) * ld + k0 + slot * 8) * 2);
+    } else {
+        constexpr int SLOTS = R / 8;                       // 16-B slots per k-row
+        constexpr int ROWS_PER_KIB = 64 / SLOTS;
+        const int krow = chunk * ROWS_PER_KIB + lane / SLOTS;
+        const int slot = (lane % SLOTS) ^ (mn_key(krow) << 1);
+        voff = (uint32_t)(((long)(k0 + krow) * ld + row0 + slot * 8) * 2);
+    }
+    dma16(desc, __builtin_amdgcn_readfirstlane(lds + chunk * 1024), voff);
+}
+
 // Issue the loads of one [R x BKT] operand tile into LDS (all NT threads cooperate).
 template <int R, bool KMAJ, int NT, int BKT>
 __device__ __forceinline__ void stage_tile(const u32x4& desc, uint32_t lds, int row0, int k0, int ld, int tid) {
     constexpr int TILE_BYTES = R * BKT * 2;
     constexpr int ITERS = TILE_BYTES / (NT * 16);
     static_assert(TILE_BYTES % (NT * 16) == 0, "tile/threads mismatch");
-    const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        // this wave-instruction fills LDS bytes [chunk*1024, chunk*1024+1024)
-        const int chunk = it * (NT / 64) + wave;
-        uint32_t voff;
-        if (KMAJ) {
-            constexpr int SLOTS = BKT / 8;                     // 16-B slots per row
-            constexpr int RPK = 64 / SLOTS;                    // rows per KiB
-            const int row = chunk * RPK + lane / SLOTS;
-            const int slot = (lane % SLOTS) ^ km_swz<BKT>(row);  // logical slot living at this phys slot
-            voff = (uint32_t)(((long)(row0 + row) * ld + k0 + slot * 8) * 2);
-        } else {
-            constexpr int SLOTS = R / 8;                       // 16-B slots per k-row
-            constexpr int ROWS_PER_KIB = 64 / SLOTS;
-            const int krow = chunk * ROWS_PER_KIB + lane / SLOTS;
-            const int slot = (lane % SLOTS) ^ (mn_key(krow) << 1);
-            voff = (uint32_t)(((long)(k0 + krow) * ld + row0 + slot * 8) * 2);
-        }
-        dma16(desc, __builtin_amdgcn_readfirstlane(lds + chunk * 1024), voff);
-    }
+    for (int it = 0; it < ITERS; ++it) stage_piece<R, KMAJ, NT, BKT>(desc, lds, row0, k0, ld, tid, it);
 }
 
 // One MFMA operand fragment (16 rows x 32 k) from an LDS tile.
@@ -250,6 +253,55 @@ void gemm_bf16_kernel(GemmArgs p) {
         if (KT > 1) { stage(1, 1); wait_vmcnt<LOADS>(); } else { wait_vmcnt<0>(); }
         __builtin_amdgcn_s_barrier();
         ldfr(0, 0, fa0, fb0);
+        if constexpr (PIPE == 4) {
+            // Hand-interleaved schedule: every non-MFMA instruction of a phase is slotted between groups of 4
+            // MFMAs (an MFMA occupies the pipe for ~16 cycles but only one issue slot), so the matrix pipe never
+            // waits for 12 ds_reads + 8 DMA issues to be pushed out first.  sched_barrier(0) after each group
+            // keeps hipcc from regrouping them.
+            static_assert(TM == 8 && TN == 4 && LOADS == 8, "interleave written for 128x64 wave tiles, 8 DMA/thread");
+            constexpr int A_IT = A_BYTES / (NT * 16);
+            for (int kt = 0; kt < KT; ++kt) {
+                const int buf = kt & 1;
+                LDS_PTR(char) sa = smem + buf * (A_BYTES + B_BYTES);
+                LDS_PTR(char) sb = sa + A_BYTES;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {                 // phase 1: MFMAs of k-step 0, loads of k-step 1
+                    fa1[c] = fa_addr.load(sa, c, 1);
+                    if (c < 4) fb1[c] = fb_addr.load(sb, c, 1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = c >> 1, j = (c & 1) * 4 + e;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[i], fa0[j], acc[i][j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                const bool more1 = kt + 1 < KT, more2 = kt + 2 < KT;
+                LDS_PTR(char) na = smem + (buf ^ 1) * (A_BYTES + B_BYTES);
+                LDS_PTR(char) nb = na + A_BYTES;
+                const uint32_t da = smem_addr + buf * (A_BYTES + B_BYTES);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {                 // phase 2: MFMAs of k-step 1, next tile's k-step 0 + DMA
+                    if (more1) {
+                        fa0[c] = fa_addr.load(na, c, 0);
+                        if (c < 4) fb0[c] = fb_addr.load(nb, c, 0);
+                    }
+                    if (more2) {
+                        if (c < A_IT) stage_piece<BM, A_KMAJ, NT, BKT>(ra, da, m0, (kt0 + kt + 2) * BKT, p.lda, tid, c);
+                        else stage_piece<BN, B_KMAJ, NT, BKT>(rb, da + A_BYTES, n0, (kt0 + kt + 2) * BKT, p.ldb, tid, c - A_IT);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = c >> 1, j = (c & 1) * 4 + e;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[i], fa1[j], acc[i][j], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
         for (int kt = 0; kt < KT; ++kt) {
             const int buf = kt & 1;
             ldfr(buf, 1, fa1, fb1);
@@ -265,6 +317,7 @@ void gemm_bf16_kernel(GemmArgs p) {
             if (kt + 1 < KT) ldfr(buf ^ 1, 0, fa0, fb0);
             mma(fa1, fb1);
             __builtin_amdgcn_sched_barrier(0);
+        }
         }
     } else {
     // ---- NSTAGE-deep DMA pipeline: stages kt+1 .. kt+NSTAGE-1 are in flight while kt is computed.
@@ -414,7 +467,9 @@ int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
         // measured on MI355X (profiles/r01_gemm_probe*.txt): the 256x256 tile wins from ~1.4 rounds
         // of the 256 CUs upward, in all three layouts
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        tile_cfg = (t256 >= 128) ? 6 : 1;
+        // forward / dgrad: hand-interleaved schedule (8); wgrad (both operands through transposing reads, at the
+        // VGPR limit): compiler-scheduled pipelined loop (6) -- measured, profiles/r01_gemm_probe_v6.txt
+        tile_cfg = (t256 >= 128) ? (A_KMAJ ? 8 : 6) : 1;
     }
     switch (tile_cfg) {
         case 1: return launch<128, 128, 2, 2, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
@@ -423,6 +478,7 @@ int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
         case 4: return launch<256, 256, 2, 4, 32, 4, A_KMAJ, B_KMAJ, EPI>(p, st);
         case 6: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 1>(p, st);   // software-pipelined fragments
         case 7: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 2>(p, st);   // + s_setprio around the MFMA clusters
+        case 8: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4>(p, st);   // hand-interleaved phases
     }
     return NV_ERR_ARG;
 }

@@ -59,6 +59,16 @@ __device__ __forceinline__ void dma16(const u32x4& desc, uint32_t lds_addr_unifo
         : "v"(voff), "s"(lds_addr_uniform), "s"(desc)
         : "memory");
 }
+// 4 bytes per lane into a scratch LDS area: used as an L2 PREFETCH (the data is never read; the request
+// pulls the 128-B line into this XCD's L2 ahead of the real DMA). Same vmcnt queue as dma16.
+__device__ __forceinline__ void dma4(const u32x4& desc, uint32_t lds_addr_uniform, uint32_t voff) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(lds_addr_uniform), "s"(desc)
+        : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -349,6 +349,37 @@ class LlamaStack(torch.autograd.Function):
                              out=sc["dxa"])
         nxt = sc["dxb"]
         model._dp_begin_backward()
+
+        # Two HIP streams: the dgrad chain (critical path) stays on the current stream; every wgrad GEMM goes to
+        # a side stream.  A wgrad has no consumer before the optimizer / the DP all-reduce, so it can trail the
+        # chain by a layer: its blocks fill the CUs that a dgrad GEMM's last, partial round leaves idle, and it
+        # overlaps the HBM-bound kernels of the chain (RMSNorm/SwiGLU/RoPE backward) that cannot feed the MFMAs.
+        # Hazards are on the scratch buffers only (dY tensors are recycled one layer later): `last_read[buf]` is
+        # the side-stream event after which `buf` may be overwritten by the chain.
+        main = torch.cuda.current_stream()
+        side = model.wgrad_stream() if model.overlap_wgrad else None
+        last_read = {}
+
+        def wgrad(dy_name, dy, act, gout):
+            if side is None:
+                ops.gemm_bf16(ops.TN, dy, act, out=gout, epilogue=ops.EPI_ACCUM)
+                return None
+            e = torch.cuda.Event()
+            e.record(main)
+            side.wait_event(e)
+            with torch.cuda.stream(side):
+                ops.gemm_bf16(ops.TN, dy, act, out=gout, epilogue=ops.EPI_ACCUM)
+                done = torch.cuda.Event()
+                done.record(side)
+            last_read[dy_name] = done
+            return done
+
+        def before_write(name):
+            ev = last_read.pop(name, None)
+            if ev is not None:
+                main.wait_event(ev)
+
+        dx_name, nxt_name = "dxa", "dxb"
         for i in reversed(range(L)):
             p = f"lang_model.model.layers.{i}."
             a = ar.layers[i]
@@ -357,23 +388,31 @@ class LlamaStack(torch.autograd.Function):
             lse = a["lse"][:M * H].view(B, H, S)
             Wd, Wo = st.p(p + "mlp.down_proj.weight"), st.p(p + "self_attn.o_proj.weight")
             dh = ops.gemm_bf16(ops.NN, dx, Wd, out=sc["dh"])
-            ops.gemm_bf16(ops.TN, dx, h, out=st.g(p + "mlp.down_proj.weight"), epilogue=ops.EPI_ACCUM)
+            ev = [wgrad(dx_name, dx, h, st.g(p + "mlp.down_proj.weight"))]
+            before_write("dgu")
             dgu = ops.swiglu_bwd(gu, dh, out=sc["dgu"])
             dn2 = ops.gemm_bf16(ops.NN, dgu, st.gate_up(i), out=sc["dn2"])
-            ops.gemm_bf16(ops.TN, dgu, n2, out=st.gate_up(i, grad=True), epilogue=ops.EPI_ACCUM)
+            ev.append(wgrad("dgu", dgu, n2, st.gate_up(i, grad=True)))
+            before_write("dx1")
             dx1 = ops.rmsnorm_bwd(dn2, x1, st.p(p + "post_attention_layernorm.weight"), a["rstd2"][:M],
                                   st.g(p + "post_attention_layernorm.weight"), resid_grad=dx, out=sc["dx1"])
             dattn = ops.gemm_bf16(ops.NN, dx1, Wo, out=sc["dattn"])
-            ops.gemm_bf16(ops.TN, dx1, attn, out=st.g(p + "self_attn.o_proj.weight"), epilogue=ops.EPI_ACCUM)
+            ev.append(wgrad("dx1", dx1, attn, st.g(p + "self_attn.o_proj.weight")))
+            before_write("dqkv")
             dqkv = ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd, dqkv=sc["dqkv"])
             ops.rope_(dqkv, model.rope_cos, model.rope_sin, S, H, hd, backward=True)
             dn1 = ops.gemm_bf16(ops.NN, dqkv, st.qkv(i), out=sc["dn1"])
-            ops.gemm_bf16(ops.TN, dqkv, n1, out=st.qkv(i, grad=True), epilogue=ops.EPI_ACCUM)
+            ev.append(wgrad("dqkv", dqkv, n1, st.qkv(i, grad=True)))
+            before_write(nxt_name)
             ndx = ops.rmsnorm_bwd(dn1, x, st.p(p + "input_layernorm.weight"), a["rstd1"][:M], st.g(p + "input_layernorm.weight"),
                                   resid_grad=dx1, out=nxt)
             dx, nxt = ndx, dx
-            model._dp_layer_done(i)
-        return dx.clone(), None, None, None, None
+            dx_name, nxt_name = nxt_name, dx_name
+            model._dp_layer_done(i, [e_ for e_ in ev if e_ is not None])
+        out = dx.clone()
+        if side is not None:
+            main.wait_stream(side)      # weight gradients complete before anything downstream (optimizer, next forward)
+        return out, None, None, None, None
 
 
 class GatherRowsBF16(torch.autograd.Function):

@@ -128,6 +128,8 @@ class NavModel(nn.Module):
         self.rope_sin = emb.sin().to(BF16).to(self.device).contiguous()
         self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
         self.arena = Fn.ActivationArena(cfg, self.device)
+        self.overlap_wgrad = True
+        self._wgrad_stream = None
         self._dp = None
         self.drop_env_p = cfg.feat_dropout
         self.injected_dropout = None   # tests: dict of keep masks
@@ -187,9 +189,14 @@ class NavModel(nn.Module):
         if self._dp is not None:
             self._dp.on_backward_begin()
 
-    def _dp_layer_done(self, i):
+    def _dp_layer_done(self, i, events=()):
         if self._dp is not None:
-            self._dp.on_layer_done(i)
+            self._dp.on_layer_done(i, events)
+
+    def wgrad_stream(self):
+        if self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(device=self.device)
+        return self._wgrad_stream
 
     # ------------------------------------------------------------------ small helpers
     def P(self, name):

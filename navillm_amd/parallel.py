@@ -114,16 +114,19 @@ class NavDataParallel(torch.nn.Module):
         self._queued = True
         torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
-    def on_layer_done(self, i):
+    def on_layer_done(self, i, events=()):
         if not self._active() or not self.overlap:
             return
-        self._launch(self.slices.layer[i])
+        self._launch(self.slices.layer[i], events)
 
-    def _launch(self, t):
+    def _launch(self, t, events=()):
         """all-reduce slice `t` on the side stream, ordered after everything enqueued so far on the compute
-        stream (the wgrad GEMMs that produced it); the host does not block."""
+        stream and after `events` (the wgrad GEMMs of that layer, which run on their own stream); the host
+        does not block."""
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
+            for e in events:
+                self._comm_stream.wait_event(e)
             with torch.cuda.stream(self._comm_stream):
                 _allreduce_mean_(t, self.group)
         else:

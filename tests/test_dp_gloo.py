@@ -47,7 +47,7 @@ class _Backward(torch.autograd.Function):
             s, e = st.layer_slice(i)
             st.grad["lm"][s:e] += ctx.scale * (ctx.rank + 1) * (i + 1)
             if m._dp is not None:
-                m._dp.on_layer_done(i)
+                m._dp.on_layer_done(i, [])
         st.grad["f32"] += ctx.scale * (ctx.rank + 1) * 0.5
         first = st.layer_slice(0)[0]
         st.grad["lm"][:first] += ctx.scale * (ctx.rank + 1) * 7.0
