@@ -31,6 +31,7 @@ struct GemmArgs {
     int lda, ldb, ldc, ldr;
     uint32_t a_bytes, b_bytes;
     int group_m;            // tile-order super-row height (L2 reuse), >= 1
+    int col_strips;         // 1: walk column strips of 8 tiles (XCDs partition B), 0: row groups (XCDs partition A)
     // split-K tail (see launch()): blocks >= full_blocks are K-slices of the last, partial round of tiles
     int full_blocks, rem, split;
     float* slabs;           // [rem*split][BM*BN] fp32 partials
@@ -177,10 +178,23 @@ void gemm_bf16_kernel(GemmArgs p) {
         nsplit = p.split;
     }
     const int t = xcd_remap(tile_b, tiles_m * tiles_n);
-    const int per_group = p.group_m * tiles_n;
-    const int grp = t / per_group, within = t % per_group;
-    const int rows_here = min(p.group_m, tiles_m - grp * p.group_m);
-    const int tm = grp * p.group_m + within % rows_here, tn = within / rows_here;
+    int tm, tn;
+    if (p.col_strips) {
+        // strips of 8 tile-columns, rows walked inside a strip: an XCD's contiguous chunk is then a range of
+        // COLUMNS over all rows -> each B (weight) panel is pulled through the fabric by one XCD instead of eight
+        constexpr int GN = 8;
+        const int per_strip = GN * tiles_m;
+        const int strip = t / per_strip, within = t % per_strip;
+        const int cols_here = min(GN, tiles_n - strip * GN);
+        tn = strip * GN + within % cols_here;
+        tm = within / cols_here;
+    } else {
+        const int per_group = p.group_m * tiles_n;
+        const int grp = t / per_group, within = t % per_group;
+        const int rows_here = min(p.group_m, tiles_m - grp * p.group_m);
+        tm = grp * p.group_m + within % rows_here;
+        tn = within / rows_here;
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const u32x4 ra = make_desc(p.A, p.a_bytes);
@@ -527,6 +541,9 @@ extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C
         const char* e = getenv("NV_GEMM_GROUP_M");   // tuning knob; default 4 (4 x 8 patch per XCD)
         p.group_m = e ? atoi(e) : 4;
         if (p.group_m < 1) p.group_m = 1;
+        // partition the LARGER operand across the 8 XCD L2s (read once), replicate the smaller one
+        const char* o = getenv("NV_GEMM_ORDER");         // tuning knob: 0 rows, 1 column strips, unset = by operand size
+        p.col_strips = o ? atoi(o) : ((long)N > (long)M ? 1 : 0);
     }
     hipStream_t st = (hipStream_t)stream;
     switch (layout) {

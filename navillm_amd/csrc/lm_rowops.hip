@@ -345,14 +345,15 @@ int nv_rmsnorm_fwd_bf16(const void* x, const void* w, void* y, float* rstd, int 
 }
 
 // workspace: nv_rmsnorm_bwd_workspace_bytes(d) bytes of fp32 partials
-size_t nv_rmsnorm_bwd_workspace_bytes(int d) { return (size_t)512 * d * sizeof(float); }
+size_t nv_rmsnorm_bwd_workspace_bytes(int d) { return (size_t)1024 * d * sizeof(float); }
 
 int nv_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const float* rstd, const void* resid_grad, void* dx,
                         void* gw, void* workspace, int M, int d, void* stream) {
     if (!dy || !x || !w || !rstd || !dx || !gw || !workspace || (d & 7)) return NV_ERR_ARG;
     if (d > 4 * 256 * 8) return NV_ERR_SHAPE;  // VEC=4 covers d <= 8192
     if (M == 0) return NV_OK;
-    const int P = M < 256 ? M : 256;
+    // 4 blocks per CU: the kernel is HBM-bound and needs the occupancy to cover latency (88 -> ~45 us at M=5152)
+    const int P = M < 1024 ? M : 1024;
     NV_LAUNCH((rmsnorm_bwd_kernel<4, 4>), dim3(P), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)resid_grad, (bf16_t*)dx, (float*)workspace, M,
                        d);

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     # cheap calls that do not touch a device
-    assert L.nv_rmsnorm_bwd_workspace_bytes(4096) == 256 * 0 + 512 * 4096 * 4
+    assert L.nv_rmsnorm_bwd_workspace_bytes(4096) == 1024 * 4096 * 4
     assert L.nv_attn_bwd_workspace_bytes(2, 10, 3) == 2 * 10 * 3 * 4
     assert L.nv_layernorm_bwd_workspace_bytes(1024) == 2 * 128 * 1024 * 4
     # argument validation happens before any launch

@@ -25,7 +25,7 @@ def bench(fns, iters=12, warm=3):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     cold = "--cold" in sys.argv
-    tiles = (3,) if "--t3" in sys.argv else ((6, 8) if "--t68" in sys.argv else (1, 2, 3, 4, 6))
+    tiles = (0,) if "--t0" in sys.argv else (3,) if "--t3" in sys.argv else ((6, 8) if "--t68" in sys.argv else (1, 2, 3, 4, 6))
     M = int(args[0]) if args else 5600
     nset = 12 if cold else 1
     dev = torch.device("cuda:0")
