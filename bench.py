@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--lr", type=float, default=3e-5)
     ap.add_argument("--prewarm", type=int, default=6, help="untimed setup steps before the W warmup steps (one full episode: "
                     "first-use kernel/attribute/allocator/RCCL initialisation)")
+    ap.add_argument("--infer-steps", type=int, default=4, help="extra, untimed-for-`value` forward-only steps reported aside")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch GEMM event timing")
     return ap.parse_args()
@@ -202,6 +203,23 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # ---- untimed extra: the same nav step without loss/backward (validation rollout, mp3d_agent.py:530-590)
+    infer = None
+    if a.infer_steps > 0:
+        model.eval()
+        ep.reset()
+        with torch.no_grad():
+            for i in range(2):
+                nav_step(wrapped, crit, ep, train=False)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(a.infer_steps):
+                nav_step(wrapped, crit, ep, train=False)
+            torch.cuda.synchronize()
+        infer = {"nav_steps_per_s_per_gpu": round(a.batch * a.infer_steps / (time.perf_counter() - t1), 2),
+                 "steps": a.infer_steps, "what": "panorama + navigation forward only, argmax actions, eval mode"}
+        model.train()
+
     if rank == 0:
         value = a.batch * a.steps * world / dt
         g = timer.summary()
@@ -216,6 +234,8 @@ def main():
                        "global_batch": a.batch * world, "seq_len": int(max(ep.S_hist)) if ep.S_hist else None,
                        "parallelism": f"dp{world}", "loss": float(loss.detach()) if loss is not None else None},
         }
+        if infer is not None:
+            line["inference_forward_only"] = infer
         if g is not None:
             allg = timer.summary(layouts=(0, 1, 2))
             line["roofline"] = {"bound": "mfma", "achieved": round(g["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,

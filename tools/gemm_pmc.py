@@ -10,7 +10,7 @@ W = (torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16()
 dY = torch.randn(M, N, device=dev, generator=g).bfloat16()
 G = torch.zeros(N, K, device=dev, dtype=torch.bfloat16)
 for _ in range(3):
-    ops.gemm_bf16(0, X, W, tile_cfg=3)
-    ops.gemm_bf16(1, dY, W, tile_cfg=3)
-    ops.gemm_bf16(2, dY, X, out=G, epilogue=1, tile_cfg=3)
+    ops.gemm_bf16(0, X, W, tile_cfg=0)
+    ops.gemm_bf16(1, dY, W, tile_cfg=0)
+    ops.gemm_bf16(2, dY, X, out=G, epilogue=1, tile_cfg=0)
 torch.cuda.synchronize()
