@@ -8,7 +8,7 @@ touch (`.lang_model.cls_token`, `.lang_model.tokenizer`, `.lang_model.cls_token_
 tokenisation, vpid matching (nav_model.py:174-190), candidate permutation (:216-223).
 
 Not mirrored (raise NotImplementedError): `generate()` paths of summarization/3dqa/embodied_qa
-inference (SURVEY.md §8f "next"), fp32 LM, OPT LMs, fuse_obj=True.
+inference (SURVEY.md §8f "next"), fp32 LM, OPT LMs.
 """
 import collections
 import math
@@ -90,8 +90,6 @@ class NavModel(nn.Module):
         if not cfg.lm_is_bf16:
             raise NotImplementedError("the MI355X path implements the reference's amp_bf16 mode (bf16 LM + heads, fp32 "
                                       "encoder); precision='fp32' has no HIP LM")
-        if cfg.fuse_obj:
-            raise NotImplementedError("fuse_obj=True is not built yet (default configs use False)")
         if cfg.head_dim != 128:
             raise NotImplementedError("attention kernels are built for head_dim 128 (Llama/Vicuna 7B/13B)")
         if device is None:
@@ -260,7 +258,58 @@ class NavModel(nn.Module):
         x = self._drop(x, cfg.enc_dropout, "emb.drop")
         lens_dev = ops.h2d(view_lens, self.device)
         pano_masks = torch.arange(N, device=self.device).unsqueeze(0) < lens_dev.unsqueeze(1)
-        lens_i32 = lens_dev.to(torch.int32).contiguous()
+        if cfg.num_pano_layers > 0:
+            if cfg.fuse_obj:
+                # object tokens join the encoder sequence (image_embedding.py:78-94): per sample
+                # [views[:len_v] ; objects[:len_o]], padded to the batch max, view part sliced back afterwards.
+                # The ragged concat / slice-back are host-built row tables (lens are host data in the agent).
+                vl = torch.as_tensor(view_lens).cpu().long()
+                olh = torch.as_tensor(obj_lens).cpu().long()
+                O = obj_img_fts.shape[1]
+                o = self._seq2(ops.h2d(obj_img_fts, self.device, F32), e + ".obj_linear")
+                o = Fn.add(o, self._ln(self._lin(ops.h2d(obj_loc_fts, self.device, F32), e + ".loc_linear"),
+                                       e + ".loc_layer_norm", 1e-12))
+                o = Fn.add(o.view(B * O, h), self.P(e + ".nav_type_embedding.weight")[2])
+                T_ = int((vl + olh).max())
+                src_v = torch.full((B * T_,), -1, dtype=torch.int32)
+                src_o = torch.full((B * T_,), -1, dtype=torch.int32)
+                inv_v = torch.full((B * N,), -1, dtype=torch.int32)
+                inv_o = torch.full((B * O,), -1, dtype=torch.int32)
+                back = torch.full((B * N,), -1, dtype=torch.int32)
+                back_inv = torch.full((B * T_,), -1, dtype=torch.int32)
+                for b in range(B):
+                    for j in range(int(vl[b])):
+                        src_v[b * T_ + j] = b * N + j
+                        inv_v[b * N + j] = b * T_ + j
+                        back[b * N + j] = b * T_ + j
+                        back_inv[b * T_ + j] = b * N + j
+                    for j in range(int(olh[b])):
+                        src_o[b * T_ + int(vl[b]) + j] = b * O + j
+                        inv_o[b * O + j] = b * T_ + int(vl[b]) + j
+                fuse = Fn.GatherRowsF32.apply(x.view(B * N, h), ops.h2d(src_v, self.device), ops.h2d(inv_v, self.device), None)
+                fuse = Fn.GatherRowsF32.apply(o, ops.h2d(src_o, self.device), ops.h2d(inv_o, self.device), fuse)
+                fuse = self._pano_encoder(fuse.view(B, T_, h), ops.h2d(vl + olh, self.device, torch.int32))
+                x = Fn.GatherRowsF32.apply(fuse.view(B * T_, h), ops.h2d(back, self.device), ops.h2d(back_inv, self.device),
+                                           None).view(B, N, h)
+            else:
+                x = self._pano_encoder(x, lens_dev.to(torch.int32).contiguous())
+        x = self._lin(x, e + ".mapper")
+        x = Fn.RowScaleF32.apply(x, pano_masks.to(F32).view(-1).contiguous()).view(B, N, cfg.hidden_size)
+        ret = {"pano_embeds": x, "pano_masks": pano_masks}
+        if obj_img_fts is not None and obj_img_fts.shape[1] > 0:
+            oe = self._seq2(ops.h2d(obj_img_fts, self.device, F32), e + ".obj_projector")
+            ol = ops.h2d(obj_lens, self.device)
+            obj_masks = torch.arange(obj_img_fts.shape[1], device=self.device).unsqueeze(0) < ol.unsqueeze(1)
+            assert oe.shape[:2] == obj_loc_fts.shape[:2], \
+                f"shape of obj_embeds {oe.shape[:2]} must equal to shape of obj_loc_fts {obj_loc_fts.shape[:2]}"
+            ret.update({"obj_embeds": oe, "obj_loc_fts": obj_loc_fts, "obj_masks": obj_masks})
+        return ret
+
+    def _pano_encoder(self, x, lens_i32):
+        """pre-norm TransformerEncoder + final LayerNorm(1e-12) (detr_transformer.py:71-89,170-182; ops.py:6-18)"""
+        cfg = self.cfg
+        e = "img_embeddings"
+        B, N, h = x.shape
         heads, hd = cfg.enc_num_heads, h // cfg.enc_num_heads
         for i in range(cfg.num_pano_layers):
             p = f"{e}.pano_encoder.layers.{i}"
@@ -274,19 +323,7 @@ class NavModel(nn.Module):
             y = self._drop(y, cfg.enc_dropout, f"l{i}.drop")
             y = self._lin(y, p + ".linear2")
             x = Fn.add(x, self._drop(y, cfg.enc_dropout, f"l{i}.drop2"))
-        if cfg.num_pano_layers > 0:
-            x = self._ln(x, e + ".pano_encoder.norm", 1e-12)
-        x = self._lin(x, e + ".mapper")
-        x = Fn.RowScaleF32.apply(x, pano_masks.to(F32).view(-1).contiguous()).view(B, N, cfg.hidden_size)
-        ret = {"pano_embeds": x, "pano_masks": pano_masks}
-        if obj_img_fts is not None and obj_img_fts.shape[1] > 0:
-            oe = self._seq2(ops.h2d(obj_img_fts, self.device, F32), e + ".obj_projector")
-            ol = ops.h2d(obj_lens, self.device)
-            obj_masks = torch.arange(obj_img_fts.shape[1], device=self.device).unsqueeze(0) < ol.unsqueeze(1)
-            assert oe.shape[:2] == obj_loc_fts.shape[:2], \
-                f"shape of obj_embeds {oe.shape[:2]} must equal to shape of obj_loc_fts {obj_loc_fts.shape[:2]}"
-            ret.update({"obj_embeds": oe, "obj_loc_fts": obj_loc_fts, "obj_masks": obj_masks})
-        return ret
+        return self._ln(x, e + ".pano_encoder.norm", 1e-12)
 
     # ------------------------------------------------------------------ the visual-token LM (modified_lm.py:89-146)
     def _tokens(self, batch, text):

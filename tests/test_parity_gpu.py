@@ -66,6 +66,15 @@ def test_g1_scene_encoder_vs_reference():
     assert maxerr(nop["pano_embeds"], z["nopose_pano_embeds"]) < 2e-5
 
 
+def test_g1_scene_encoder_fuse_obj_vs_reference():
+    z = gold("g1_encoder_fuseobj.npz")
+    m = build(tiny_cfg("bf16", fuse_obj=True))
+    with torch.no_grad():
+        out = m("panorama", pano_batch(z, True))
+    assert maxerr(out["pano_embeds"], z["pano_embeds"]) < 2e-5
+    assert maxerr(out["obj_embeds"], z["obj_embeds"]) < 2e-5
+
+
 def test_g2_visual_token_lm_vs_reference():
     zb, zf = gold("g2_lm_bf16.npz"), gold("g2_lm_fp32.npz")
     m = build(tiny_cfg("bf16"))
