@@ -77,11 +77,13 @@ int nv_scatter_rows_bf16(const void* src, const int* rows, void* dst, int n, int
 /* ---- K7b: causal + left-pad attention of HF LlamaAttention (head_dim 128), flash style.
  *   qkv [B*S, 3*H*128] post-RoPE, out [B*S, H*128], lse2 [B,H,S] (log2 domain, +inf for fully
  *   masked rows), kv_start[b] = number of left-pad positions of sample b. */
+/*   q_row_min (multiple of 128, 0 = all): only query rows >= q_row_min of every sample are computed (forward) or
+ *   carry gradient (backward; dQ rows below it are left untouched) -- the navigation modes read one row. */
 int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, int B, int S, int H, int head_dim,
-                     void* stream);
+                     int q_row_min, void* stream);
 size_t nv_attn_bwd_workspace_bytes(int B, int S, int H);
 int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
-                     void* workspace, int B, int S, int H, int head_dim, void* stream);
+                     void* workspace, int B, int S, int H, int head_dim, int q_row_min, void* stream);
 
 /* ---- K10: action / object head Linear(d -> N<=128) in the LM dtype, models/nav_model.py:237,445 */
 int nv_head_fwd_bf16(const void* x, const void* W, const void* bias, void* y, int B, int d, int N, void* stream);

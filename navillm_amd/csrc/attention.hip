@@ -82,6 +82,7 @@ struct AttnArgs {
     const bf16_t* dout; const float* dsum; bf16_t* dqkv; // bwd
     const int* kv_start;
     int B, S, H, ld;       // ld = 3*H*HD (qkv row stride), out row stride = H*HD
+    int q_row_min;         // only queries >= q_row_min are computed / differentiated (multiple of 128; 0 = all)
     float scale2;          // head_dim^-0.5 * log2(e)
     float scale;           // head_dim^-0.5
 };
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int S = p.S, ld = p.ld;
-    const int q0 = blockIdx.x * 128;
+    const int q0 = p.q_row_min + blockIdx.x * 128;
     const int kvs = p.kv_start[b];
     const int qi = lane & 15, g = lane >> 4;
     const bf16_t* base = p.qkv + (long)b * S * ld;
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     for (int dt = 0; dt < 8; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     // queries that can see this key block: q >= kblk (causal), q >= kvs (pad queries have p=0 anyway)
-    const int qt_beg = kblk / 32, qt_end = (S - 1) / 32;
+    const int qt_lo = p.q_row_min / 32;
+    const int qt_beg = kblk / 32 > qt_lo ? kblk / 32 : qt_lo, qt_end = (S - 1) / 32;
     auto stage = [&](int qt, int buf) {
         stage_rows<32, 256>(rq, smem + buf * 2 * TILE, qt * 32, h * HD, ld, tid);
         stage_rows<32, 256>(rdo, smem + buf * 2 * TILE + TILE, qt * 32, h * HD, od, tid);
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int S = p.S, ld = p.ld;
-    const int q0 = blockIdx.x * 64;
+    const int q0 = p.q_row_min + blockIdx.x * 64;
     const int kvs = p.kv_start[b];
     const int qi = lane & 15, g = lane >> 4;
     const int q = q0 + wave * 16 + qi;
@@ -454,17 +456,17 @@ int set_lds(const void* fn, int bytes) {
 extern "C" {
 
 int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, int B, int S, int H, int head_dim,
-                     void* stream) {
+                     int q_row_min, void* stream) {
     if (!qkv || !out || !lse2 || !kv_start) return NV_ERR_ARG;
-    if (head_dim != HD) return NV_ERR_SHAPE;
+    if (head_dim != HD || (q_row_min & 127) || q_row_min < 0 || (S > 0 && q_row_min >= S)) return NV_ERR_SHAPE;
     if (B == 0 || S == 0) return NV_OK;
     static bool once = false;
     if (!once) { if (set_lds((const void*)attn_fwd_kernel, 65536)) return NV_ERR_LAUNCH; once = true; }
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = kv_start;
-    p.B = B; p.S = S; p.H = H; p.ld = 3 * H * HD;
+    p.B = B; p.S = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
-    NV_LAUNCH(attn_fwd_kernel, dim3((S + 127) / 128, B * H), dim3(256), 65536, (hipStream_t)stream, p);
+    NV_LAUNCH(attn_fwd_kernel, dim3((S - q_row_min + 127) / 128, B * H), dim3(256), 65536, (hipStream_t)stream, p);
     return nv_check_launch();
 }
 
@@ -472,9 +474,9 @@ int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_star
 size_t nv_attn_bwd_workspace_bytes(int B, int S, int H) { return (size_t)B * S * H * sizeof(float); }
 
 int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
-                     void* workspace, int B, int S, int H, int head_dim, void* stream) {
+                     void* workspace, int B, int S, int H, int head_dim, int q_row_min, void* stream) {
     if (!qkv || !out || !dout || !lse2 || !kv_start || !dqkv || !workspace) return NV_ERR_ARG;
-    if (head_dim != HD) return NV_ERR_SHAPE;
+    if (head_dim != HD || (q_row_min & 127) || q_row_min < 0 || (S > 0 && q_row_min >= S)) return NV_ERR_SHAPE;
     if (B == 0 || S == 0) return NV_OK;
     static bool once = false;
     if (!once) {
@@ -489,10 +491,12 @@ int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const f
                        (const bf16_t*)out, dsum, B, S, H);
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.lse2 = (float*)lse2; p.dsum = dsum; p.dqkv = (bf16_t*)dqkv;
-    p.kv_start = kv_start; p.B = B; p.S = S; p.H = H; p.ld = 3 * H * HD;
+    p.kv_start = kv_start; p.B = B; p.S = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
+    // with q_row_min > 0 only those query rows carry gradient: dK/dV still cover every key, dQ rows below
+    // q_row_min are NOT written (the caller zero-fills them)
     NV_LAUNCH(attn_bwd_dkv_kernel, dim3((S + 63) / 64, B * H), dim3(256), 32768, st, p);
-    NV_LAUNCH(attn_bwd_dq_kernel, dim3((S + 63) / 64, B * H), dim3(256), 65536, st, p);
+    NV_LAUNCH(attn_bwd_dq_kernel, dim3((S - q_row_min + 63) / 64, B * H), dim3(256), 65536, st, p);
     return nv_check_launch();
 }
 

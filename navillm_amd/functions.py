@@ -307,14 +307,20 @@ class LlamaStack(torch.autograd.Function):
     live in the model's ActivationArena."""
 
     @staticmethod
-    def forward(ctx, E, model, B, S, kv_start_i32):
+    def forward(ctx, E, model, B, S, kv_start_i32, tail_rows=None):
+        """tail_rows (int32 device tensor, one row per sample, each the LAST position of its sample) switches on
+        the pruned last layer: only those rows are consumed downstream (nav_model.py:237 reads the <cls_1> row), so
+        after the last layer's K/V projection everything -- attention queries, o_proj, MLP, final norm -- is
+        computed for B rows instead of B*S.  Returns [B, d] then.  (Same spirit as skipping lm_head in navigation
+        mode: work the reference does and never reads.)"""
         cfg, st, ar = model.cfg, model.store, model.arena
         H, hd, eps = cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps
         M = B * S
         ar.reserve(M)
         ar.generation += 1
         x = E
-        for i in range(cfg.num_layers):
+        L_full = cfg.num_layers - (1 if tail_rows is not None else 0)
+        for i in range(L_full):
             p = f"lang_model.model.layers.{i}."
             a = ar.layers[i]
             n1, rstd1 = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps, out=a["n1"][:M], rstd=a["rstd1"][:M])
@@ -327,6 +333,25 @@ class LlamaStack(torch.autograd.Function):
             gu = ops.gemm_bf16(ops.NT, n2, st.gate_up(i), out=a["gu"][:M])
             h = ops.swiglu_fwd(gu, out=a["h"][:M])
             x = ops.gemm_bf16(ops.NT, h, st.p(p + "mlp.down_proj.weight"), out=a["x2"][:M], R=x1, epilogue=ops.EPI_RESID)
+        ctx.tail = None
+        if tail_rows is not None:
+            i = cfg.num_layers - 1
+            p = f"lang_model.model.layers.{i}."
+            a = ar.layers[i]
+            qmin = ((S - 1) // 128) * 128
+            n1, _ = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps, out=a["n1"][:M], rstd=a["rstd1"][:M])
+            qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i), out=a["qkv"][:M])
+            ops.rope_(qkv, model.rope_cos, model.rope_sin, S, H, hd)
+            attn, _ = ops.attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=a["attn"][:M], lse2=a["lse"][:M * H].view(B, H, S),
+                                   q_row_min=qmin)
+            attn_r = ops.gather_rows_bf16(attn, tail_rows)
+            x_r = ops.gather_rows_bf16(x, tail_rows)
+            x1_r = ops.gemm_bf16(ops.NT, attn_r, st.p(p + "self_attn.o_proj.weight"), R=x_r, epilogue=ops.EPI_RESID)
+            n2_r, rstd2_r = ops.rmsnorm_fwd(x1_r, st.p(p + "post_attention_layernorm.weight"), eps)
+            gu_r = ops.gemm_bf16(ops.NT, n2_r, st.gate_up(i))
+            h_r = ops.swiglu_fwd(gu_r)
+            x = ops.gemm_bf16(ops.NT, h_r, st.p(p + "mlp.down_proj.weight"), R=x1_r, epilogue=ops.EPI_RESID)
+            ctx.tail = (tail_rows, qmin, attn_r, x1_r, rstd2_r, n2_r, gu_r, h_r, x)
         Hs, rstdf = ops.rmsnorm_fwd(x, st.p("lang_model.model.norm.weight"), eps)
         ctx.model, ctx.E, ctx.rstdf = model, E, rstdf
         ctx.dims = (B, S, kv_start_i32)
@@ -344,11 +369,49 @@ class LlamaStack(torch.autograd.Function):
         M = B * S
         H, hd, L = cfg.num_heads, cfg.head_dim, cfg.num_layers
         sc = {k: v[:M] for k, v in ar.scratch.items()}
-        xL = ar.layers[L - 1]["x2"][:M]
-        dx = ops.rmsnorm_bwd(_c(dH), xL, st.p("lang_model.model.norm.weight"), ctx.rstdf, st.g("lang_model.model.norm.weight"),
-                             out=sc["dxa"])
-        nxt = sc["dxb"]
         model._dp_begin_backward()
+        L_full = L
+        if ctx.tail is not None:
+            # pruned last layer: B-row backward of final norm / MLP / o_proj, then the full-size K/V side
+            rows, qmin, attn_r, x1_r, rstd2_r, n2_r, gu_r, h_r, x2_r = ctx.tail
+            i = L - 1
+            L_full = L - 1
+            p = f"lang_model.model.layers.{i}."
+            a = ar.layers[i]
+            x = ctx.E if i == 0 else ar.layers[i - 1]["x2"][:M]
+            n1, qkv, attn = a["n1"][:M], a["qkv"][:M], a["attn"][:M]
+            lse = a["lse"][:M * H].view(B, H, S)
+            dx2_r = ops.rmsnorm_bwd(_c(dH), x2_r, st.p("lang_model.model.norm.weight"), ctx.rstdf,
+                                    st.g("lang_model.model.norm.weight"))
+            dh_r = ops.gemm_bf16(ops.NN, dx2_r, st.p(p + "mlp.down_proj.weight"))
+            ops.gemm_bf16(ops.TN, dx2_r, h_r, out=st.g(p + "mlp.down_proj.weight"), epilogue=ops.EPI_ACCUM)
+            dgu_r = ops.swiglu_bwd(gu_r, dh_r)
+            dn2_r = ops.gemm_bf16(ops.NN, dgu_r, st.gate_up(i))
+            ops.gemm_bf16(ops.TN, dgu_r, n2_r, out=st.gate_up(i, grad=True), epilogue=ops.EPI_ACCUM)
+            dx1_r = ops.rmsnorm_bwd(dn2_r, x1_r, st.p(p + "post_attention_layernorm.weight"), rstd2_r,
+                                    st.g(p + "post_attention_layernorm.weight"), resid_grad=dx2_r)
+            dattn_r = ops.gemm_bf16(ops.NN, dx1_r, st.p(p + "self_attn.o_proj.weight"))
+            ops.gemm_bf16(ops.TN, dx1_r, attn_r, out=st.g(p + "self_attn.o_proj.weight"), epilogue=ops.EPI_ACCUM)
+            dattn = sc["dattn"]
+            dattn.zero_()
+            ops.scatter_rows_bf16_(dattn_r, rows, dattn)
+            dqkv = sc["dqkv"]
+            dqkv.zero_()                       # dQ rows below qmin are not written by the kernel
+            ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd, dqkv=dqkv, q_row_min=qmin)
+            ops.rope_(dqkv, model.rope_cos, model.rope_sin, S, H, hd, backward=True)
+            dn1 = ops.gemm_bf16(ops.NN, dqkv, st.qkv(i), out=sc["dn1"])
+            ops.gemm_bf16(ops.TN, dqkv, n1, out=st.qkv(i, grad=True), epilogue=ops.EPI_ACCUM)
+            resid = sc["dx1"]
+            resid.zero_()
+            ops.scatter_rows_bf16_(dx1_r, rows, resid)
+            dx = ops.rmsnorm_bwd(dn1, x, st.p(p + "input_layernorm.weight"), a["rstd1"][:M], st.g(p + "input_layernorm.weight"),
+                                 resid_grad=resid, out=sc["dxa"])
+            model._dp_layer_done(i, [])
+        else:
+            xL = ar.layers[L - 1]["x2"][:M]
+            dx = ops.rmsnorm_bwd(_c(dH), xL, st.p("lang_model.model.norm.weight"), ctx.rstdf,
+                                 st.g("lang_model.model.norm.weight"), out=sc["dxa"])
+        nxt = sc["dxb"]
 
         # Two HIP streams: the dgrad chain (critical path) stays on the current stream; every wgrad GEMM goes to
         # a side stream.  A wgrad has no consumer before the optimizer / the DP all-reduce, so it can trail the
@@ -380,7 +443,7 @@ class LlamaStack(torch.autograd.Function):
                 main.wait_event(ev)
 
         dx_name, nxt_name = "dxa", "dxb"
-        for i in reversed(range(L)):
+        for i in reversed(range(L_full)):
             p = f"lang_model.model.layers.{i}."
             a = ar.layers[i]
             x = ctx.E if i == 0 else ar.layers[i - 1]["x2"][:M]
@@ -412,7 +475,7 @@ class LlamaStack(torch.autograd.Function):
         out = dx.clone()
         if side is not None:
             main.wait_stream(side)      # weight gradients complete before anything downstream (optimizer, next forward)
-        return out, None, None, None, None
+        return out, None, None, None, None, None
 
 
 class GatherRowsBF16(torch.autograd.Function):

@@ -30,9 +30,9 @@ SIGNATURES = {
     "nv_scale_bf16": (i, [vp, vp, l, f, vp]),
     "nv_gather_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
     "nv_scatter_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
-    "nv_attn_fwd_bf16": (i, [vp, vp, fp, ip, i, i, i, i, vp]),
+    "nv_attn_fwd_bf16": (i, [vp, vp, fp, ip, i, i, i, i, i, vp]),
     "nv_attn_bwd_workspace_bytes": (sz, [i, i, i]),
-    "nv_attn_bwd_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, vp]),
+    "nv_attn_bwd_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, i, vp]),
     "nv_head_fwd_bf16": (i, [vp, vp, vp, vp, i, i, i, vp]),
     "nv_head_bwd_bf16": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
     "nv_action_ce_bf16": (i, [vp, lp, fp, vp, i, i, f, fp, vp]),

@@ -127,6 +127,7 @@ class NavModel(nn.Module):
         self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
         self.arena = Fn.ActivationArena(cfg, self.device)
         self.overlap_wgrad = True
+        self.prune_last_layer = True     # navigation/grounding: last decoder layer computed for the <cls_1> rows only
         self._wgrad_stream = None
         self._dp = None
         self.drop_env_p = cfg.feat_dropout
@@ -335,8 +336,9 @@ class NavModel(nn.Module):
         tok = self.lang_model.tokenize(text)
         return tok["input_ids"], tok["attention_mask"], tok.get("token_type_ids")
 
-    def _lm(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None):
-        """-> hidden states [B*S, d] bf16 (post final RMSNorm)."""
+    def _lm(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None, cls_tail=False):
+        """-> hidden states [B*S, d] bf16 (post final RMSNorm); with cls_tail and every <cls_1> at the last position
+        (always true for the left-padded navigation / grounding prompts): only those B rows, [B, d]."""
         cfg = self.cfg
         B, S = ids_cpu.shape
         flat = ids_cpu.reshape(-1)
@@ -359,7 +361,14 @@ class NavModel(nn.Module):
         assert bool((am == (torch.arange(S)[None] >= kv_start[:, None])).all()), "attention_mask must be left padding"
         E = Fn.EmbedVis.apply(vis_all, self._anchor if torch.is_grad_enabled() else None, self,
                               ops.h2d(flat, self.device, torch.int32), ops.h2d(vis_idx, self.device), vis_rows, flat)
-        return Fn.LlamaStack.apply(E, self, B, S, ops.h2d(kv_start, self.device))
+        tail = None
+        if cls_tail and self.prune_last_layer and bool((ids_cpu[:, -1] == cfg.cls_token_ids[0]).all()) \
+                and int((ids_cpu == cfg.cls_token_ids[0]).sum()) == B:
+            tail = ops.h2d(torch.arange(B, dtype=torch.int32) * S + (S - 1), self.device)
+        Hs = Fn.LlamaStack.apply(E, self, B, S, ops.h2d(kv_start, self.device), tail)
+        if cls_tail and tail is None:
+            Hs = Fn.GatherRowsBF16.apply(Hs, self._cls_rows(ids_cpu))
+        return Hs
 
     def _lm_loss(self, Hs, ids_cpu, labels_cpu):
         """shifted mean CE over labels != -100 (modified_lm.py:126-137)."""
@@ -440,8 +449,8 @@ class NavModel(nn.Module):
 
         hist_vis = self._stack_hist(batch["hist_vis"])
         ids, am, _ = self._tokens(batch, batch["prompts"])
-        Hs = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis)
-        pred = Fn.HeadBF16.apply(Fn.GatherRowsBF16.apply(Hs, self._cls_rows(ids)), self, "out_head.0")   # [B,100]
+        Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)
+        pred = Fn.HeadBF16.apply(Hs_cls, self, "out_head.0")   # [B,100]
 
         # fuse_logits[b][cand slots] = [pred[b,0], pred[b,1:n][inv_perm]] ; -inf elsewhere (:234-242)
         col = torch.zeros((B, G), dtype=torch.int64)
@@ -465,8 +474,8 @@ class NavModel(nn.Module):
         inv[sel.long()] = torch.arange(sel.numel(), dtype=torch.int32)
         cand_vis = Fn.GatherRowsF32.apply(oe, ops.h2d(sel, dev), ops.h2d(inv, dev), None) if sel.numel() else None
         ids, am, _ = self._tokens(batch, batch["prompts"])
-        Hs = self._lm(ids, am, cand_vis=cand_vis, hist_vis=self._stack_hist(batch["hist_vis"]))
-        pred = Fn.HeadBF16.apply(Fn.GatherRowsBF16.apply(Hs, self._cls_rows(ids)), self, "out_head.0")
+        Hs_cls = self._lm(ids, am, cand_vis=cand_vis, hist_vis=self._stack_hist(batch["hist_vis"]), cls_tail=True)
+        pred = Fn.HeadBF16.apply(Hs_cls, self, "out_head.0")
         dead = torch.arange(pred.shape[1])[None] >= cand_nums[:, None]
         return {"obj_logits": pred.masked_fill(ops.h2d(dead, dev), float("-inf"))}
 

@@ -185,22 +185,23 @@ def scatter_rows_bf16_(src, rows_i32, dst):
 
 
 # ------------------------------------------------------------------ attention
-def attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=None, lse2=None):
+def attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=None, lse2=None, q_row_min=0):
     if out is None:
         out = torch.empty((B * S, H * hd), dtype=BF16, device=qkv.device)
     if lse2 is None:
         lse2 = torch.empty((B, H, S), dtype=F32, device=qkv.device)
-    rc = _L().nv_attn_fwd_bf16(qkv.data_ptr(), out.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(), B, S, H, hd, _st())
+    rc = _L().nv_attn_fwd_bf16(qkv.data_ptr(), out.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(), B, S, H, hd, q_row_min,
+                               _st())
     _lib.check(rc, "nv_attn_fwd_bf16")
     return out, lse2
 
 
-def attn_bwd(qkv, out, dout, lse2, kv_start_i32, B, S, H, hd, dqkv=None):
+def attn_bwd(qkv, out, dout, lse2, kv_start_i32, B, S, H, hd, dqkv=None, q_row_min=0):
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
     ws = _workspace(_L().nv_attn_bwd_workspace_bytes(B, S, H), qkv.device, "attn")
     rc = _L().nv_attn_bwd_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(),
-                               dqkv.data_ptr(), ws.data_ptr(), B, S, H, hd, _st())
+                               dqkv.data_ptr(), ws.data_ptr(), B, S, H, hd, q_row_min, _st())
     _lib.check(rc, "nv_attn_bwd_bf16")
     return dqkv
 

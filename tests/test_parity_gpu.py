@@ -255,3 +255,51 @@ def test_midsize_navigation_vs_oracle(B, S_instr):
         assert e_hip <= 1.5 * e_ref + 3e-3 and gap <= 2.5 * e_ref + 3e-3
         targets = ep.teacher_targets(nav, last=False)
         ep.advance(nav, targets, out["fuse_embeds"])
+
+
+def test_pruned_last_layer_matches_full_path():
+    """navigation reads only the <cls_1> rows: the pruned last layer (B rows through o_proj/MLP/final norm, attention
+    queries of the last 128-block only) must give the same logits and the same gradients as the full computation.
+    S > 256 so that q_row_min > 0 is exercised in forward AND backward."""
+    from navillm_amd import config as nvcfg
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.synthetic import SyntheticEpisodes
+    from navillm_amd.losses import CrossEntropyLoss
+    cfg = nvcfg.NavConfig(hidden_size=512, num_layers=2, num_heads=4, intermediate_size=1408, base_vocab_size=1000,
+                          enc_hidden_size=256, enc_num_heads=4, enc_intermediate_size=512, image_feat_size=768)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=6)
+    m.eval()
+    crit = CrossEntropyLoss()
+    res = {}
+    for prune in (True, False):
+        m.prune_last_layer = prune
+        m.zero_grad()
+        ep = SyntheticEpisodes(cfg, 3, seed=21, instr_len=260, device=torch.device(DEV))
+        pin = ep.panorama_inputs()
+        pano = m("panorama", pin)
+        ep.update_maps(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+        nav = ep.nav_inputs(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+        nav["input_ids"], nav["attention_mask"] = ep.tokenise(nav, "<cls_1>")
+        assert nav["input_ids"].shape[1] > 300
+        torch.manual_seed(3)
+        out = m("navigation", nav)
+        tg = ep.teacher_targets(nav, last=False)
+        (crit(out["fuse_logits"], tg.to(DEV)) / 3).backward()
+        torch.cuda.synchronize()
+        res[prune] = (out["fuse_logits"].detach().float().cpu(), {g: t.detach().float().cpu().clone() for g, t in m.store.grad.items()})
+    lp, lf = res[True][0], res[False][0]
+    fin = torch.isfinite(lf)
+    assert torch.equal(torch.isfinite(lp), fin) and (lp[fin] - lf[fin]).abs().max().item() < 4e-3
+    for g in ("lm", "f32"):
+        a, b = res[True][1][g], res[False][1][g]
+        rel = ((a - b).norm() / (b.norm() + 1e-20)).item()
+        assert rel < 2e-2, (g, rel)
+    # per-tensor check on the tensors the pruning touches most
+    st = m.store
+    for n in ("lang_model.model.layers.1.mlp.down_proj.weight", "lang_model.model.layers.1.self_attn.o_proj.weight",
+              "lang_model.model.layers.1.self_attn.q_proj.weight", "lang_model.model.layers.1.self_attn.k_proj.weight",
+              "lang_model.model.layers.0.mlp.gate_proj.weight", "lang_model.model.embed_tokens.weight"):
+        o, k = st.offsets[n], st.sizes[n]
+        a, b = res[True][1]["lm"][o:o + k], res[False][1]["lm"][o:o + k]
+        rel = ((a - b).norm() / (b.norm() + 1e-20)).item()
+        assert rel < 3e-2, (n, rel)
