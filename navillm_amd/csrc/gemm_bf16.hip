@@ -18,6 +18,8 @@
 // MFMA operands are swapped (D[n][m]) so each lane ends with 4 consecutive n: 8-byte stores
 // and room for fused row-wise epilogues.
 #include "nv_common.h"
+#include <type_traits>
+#include <utility>
 #include <stdlib.h>
 
 namespace {
@@ -36,6 +38,8 @@ struct GemmArgs {
     int full_blocks, rem, split;
     float* slabs;           // [rem*split][BM*BN] fp32 partials
     unsigned* counters;     // [rem] arrival tickets, zero between launches
+    int debug;              // NV_GEMM_DEBUG (measurement only): bit0 skip the C stores, bit1 skip the K loop,
+                            // bit2 no DMA wait (wrong results), bit3 no DMA at all (wrong results)
 };
 
 // ---- LDS images (BKT = K extent of a stage, 64 or 32) -----------------------------------
@@ -49,26 +53,30 @@ __device__ __forceinline__ int mn_key(int krow) { return (krow & 3) | (((krow >>
 template <int BKT>
 __device__ __forceinline__ int km_swz(int row) { return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
 
-// One wave-instruction of an operand tile's DMA: fills LDS bytes [chunk*1024, +1024) of the [R x BKT] image.
+// Source byte offset (from the operand base) of the 16 B this lane moves in wave-instruction `it` of an operand
+// tile's DMA; that instruction fills LDS bytes [chunk*1024, +1024) of the [R x BKT] image, chunk = it*(NT/64)+wave.
 template <int R, bool KMAJ, int NT, int BKT>
-__device__ __forceinline__ void stage_piece(const u32x4& desc, uint32_t lds, int row0, int k0, int ld, int tid, int it) {
+__device__ __forceinline__ uint32_t piece_voff(int row0, int k0, int ld, int tid, int it) {
     const int wave = tid >> 6, lane = tid & 63;
     const int chunk = it * (NT / 64) + wave;
-    uint32_t voff;
     if (KMAJ) {
         constexpr int SLOTS = BKT / 8;                     // 16-B slots per row
         constexpr int RPK = 64 / SLOTS;                    // rows per KiB
         const int row = chunk * RPK + lane / SLOTS;
         const int slot = (lane % SLOTS) ^ km_swz<BKT>(row);  // logical slot living at this phys slot
-        voff = (uint32_t)(((long)(row0 + row) * ld + k0 + slot * 8) * 2);
+        return (uint32_t)(((long)(row0 + row) * ld + k0 + slot * 8) * 2);
     } else {
         constexpr int SLOTS = R / 8;                       // 16-B slots per k-row
         constexpr int ROWS_PER_KIB = 64 / SLOTS;
         const int krow = chunk * ROWS_PER_KIB + lane / SLOTS;
         const int slot = (lane % SLOTS) ^ (mn_key(krow) << 1);
-        voff = (uint32_t)(((long)(k0 + krow) * ld + row0 + slot * 8) * 2);
+        return (uint32_t)(((long)(k0 + krow) * ld + row0 + slot * 8) * 2);
     }
-    dma16(desc, __builtin_amdgcn_readfirstlane(lds + chunk * 1024), voff);
+}
+template <int R, bool KMAJ, int NT, int BKT>
+__device__ __forceinline__ void stage_piece(const u32x4& desc, uint32_t lds, int row0, int k0, int ld, int tid, int it) {
+    const int chunk = it * (NT / 64) + (tid >> 6);
+    dma16_nosave(desc, __builtin_amdgcn_readfirstlane(lds + chunk * 1024), piece_voff<R, KMAJ, NT, BKT>(row0, k0, ld, tid, it));
 }
 
 // Issue the loads of one [R x BKT] operand tile into LDS (all NT threads cooperate).
@@ -140,6 +148,51 @@ struct FragAddr {
     }
 };
 
+// The same for the interleaved loop, with the LDS stage folded into the per-lane address: `off` addresses the stage
+// being READ NEXT for k-step 0 / CURRENTLY for k-step 1 (see the loop), and flip() toggles it with one v_xor per
+// address register per K-tile -- all the vector ALU work that is left in that loop.  Every read is then
+// `ds_read vdst, vaddr offset:imm`.  asm("" : "+v") pins each address in its own VGPR (hipcc otherwise re-derives
+// them with v_add chains inside the loop).
+template <int R, bool KMAJ, int NF, int STAGE_STRIDE>
+struct FragAddr2 {
+    static_assert((STAGE_STRIDE & (STAGE_STRIDE - 1)) == 0, "stage stride must be a power of two (xor toggle)");
+    uint32_t off[KMAJ ? 2 : NF];
+    __device__ __forceinline__ void init(int w0, int lane, uint32_t region) {   // region: LDS byte address of this operand's stage 0
+        FragAddr<R, KMAJ, NF> f;
+        f.init(w0, lane);
+#pragma unroll
+        for (int q = 0; q < (KMAJ ? 2 : NF); ++q) {
+            off[q] = region + f.off[q];
+            asm volatile("" : "+v"(off[q]));
+        }
+    }
+    __device__ __forceinline__ void flip() {
+#pragma unroll
+        for (int q = 0; q < (KMAJ ? 2 : NF); ++q) {
+            off[q] ^= STAGE_STRIDE;
+            asm volatile("" : "+v"(off[q]));
+        }
+    }
+    __device__ __forceinline__ bf16x8 load(int j, int kk) const {
+        if (KMAJ) {
+            return *(LDS_PTR(bf16x8))(uintptr_t)(off[KMAJ ? kk : 0] + j * 2048);
+        } else {
+            const uint32_t q = off[KMAJ ? 0 : j] + kk * (32 * R * 2);
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(uintptr_t)q);
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(uintptr_t)(q + 4 * R * 2));
+            s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, v);
+        }
+    }
+};
+
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 template <int LOADS, int MAXT>
 __device__ __forceinline__ void wait_tiles(int tiles) {
     if (MAXT >= 3 && tiles >= 3) wait_vmcnt<3 * LOADS>();
@@ -209,12 +262,15 @@ void gemm_bf16_kernel(GemmArgs p) {
 
     const int KT_all = (p.K + BKT - 1) / BKT;
     const int kt0 = (int)(((long)KT_all * ks) / nsplit);
-    const int KT = (int)(((long)KT_all * (ks + 1)) / nsplit) - kt0;       // this block's K-tiles: kt0 .. kt0+KT-1
+    const int KT = (p.debug & 2) ? 0 : (int)(((long)KT_all * (ks + 1)) / nsplit) - kt0;   // this block's K-tiles: kt0 .. kt0+KT-1
     auto stage = [&](int kt_local, int buf) {
         const int kt = kt0 + kt_local;
-        const uint32_t sa = smem_addr + buf * (A_BYTES + B_BYTES);
+        // LDS layout: [A|B] per stage, except for the interleaved loop (PIPE 4): [A0][A1][B0][B1], so that the
+        // stage index fits in the 16-bit immediate of its ds_reads
+        const uint32_t sa = smem_addr + (PIPE == 4 ? buf * A_BYTES : buf * (A_BYTES + B_BYTES));
+        const uint32_t sb = smem_addr + (PIPE == 4 ? NSTAGE * A_BYTES + buf * B_BYTES : buf * (A_BYTES + B_BYTES) + A_BYTES);
         stage_tile<BM, A_KMAJ, NT, BKT>(ra, sa, m0, kt * BKT, p.lda, tid);
-        stage_tile<BN, B_KMAJ, NT, BKT>(rb, sa + A_BYTES, n0, kt * BKT, p.ldb, tid);
+        stage_tile<BN, B_KMAJ, NT, BKT>(rb, sb, n0, kt * BKT, p.ldb, tid);
     };
     auto compute = [&](int buf) {
         LDS_PTR(char) sa = smem + buf * (A_BYTES + B_BYTES);
@@ -235,7 +291,7 @@ void gemm_bf16_kernel(GemmArgs p) {
     };
 
     if constexpr (PIPE >= 1) {
-        // ---- software-pipelined main loop (2 LDS stages, BK=64 = 2 k-steps of 32) ----------------------
+                // ---- software-pipelined main loop (2 LDS stages, BK=64 = 2 k-steps of 32) ----------------------
         // Fragment registers are double-buffered: the ds_reads of k-step 1 are in flight under the MFMAs of
         // k-step 0, and the ds_reads of the NEXT tile's k-step 0 under the MFMAs of k-step 1.  One barrier
         // per K-tile, in the middle: it publishes tile kt+1 (DMA'd a full iteration earlier) and retires every
@@ -247,21 +303,19 @@ void gemm_bf16_kernel(GemmArgs p) {
         fb_addr.init(wn * WTN, lane);
         bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
         auto ldfr = [&](int buf, int kk, bf16x8(&fa)[TM], bf16x8(&fb)[TN]) {
-            LDS_PTR(char) sa = smem + buf * (A_BYTES + B_BYTES);
-            LDS_PTR(char) sb = sa + A_BYTES;
+            LDS_PTR(char) sa = smem + (PIPE == 4 ? buf * A_BYTES : buf * (A_BYTES + B_BYTES));
+            LDS_PTR(char) sb = smem + (PIPE == 4 ? NSTAGE * A_BYTES + buf * B_BYTES : buf * (A_BYTES + B_BYTES) + A_BYTES);
 #pragma unroll
             for (int j = 0; j < TM; ++j) fa[j] = fa_addr.load(sa, j, kk);
 #pragma unroll
             for (int i = 0; i < TN; ++i) fb[i] = fb_addr.load(sb, i, kk);
         };
         auto mma = [&](bf16x8(&fa)[TM], bf16x8(&fb)[TN]) {
-            if (PIPE == 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
-            if (PIPE == 2) __builtin_amdgcn_s_setprio(0);
         };
         stage(0, 0);
         if (KT > 1) { stage(1, 1); wait_vmcnt<LOADS>(); } else { wait_vmcnt<0>(); }
@@ -272,16 +326,51 @@ void gemm_bf16_kernel(GemmArgs p) {
             // MFMAs (an MFMA occupies the pipe for ~16 cycles but only one issue slot), so the matrix pipe never
             // waits for 12 ds_reads + 8 DMA issues to be pushed out first.  sched_barrier(0) after each group
             // keeps hipcc from regrouping them.
+            // The steady-state loop is unrolled over the two stages and carries NO vector ALU work besides the MFMAs:
+            // LDS addresses are per-stage VGPR constants + immediates (FragAddr2), the DMA source offsets are 2
+            // loop-invariant VGPRs + scalar offsets, the K advance lives in the buffer descriptors (SALU: base += step, num_records -=
+            // step, so the hardware bounds check still zero-fills ragged edges), the LDS destination of each DMA is
+            // M0 = scalar base + immediate.  Ordinary VALU ops share the issue port with MFMA: the ~40 per K-step the
+            // compiler-generated addressing cost were ~15% of the loop (tools/ubench/mix_rate.hip vs this kernel).
             static_assert(TM == 8 && TN == 4 && LOADS == 8, "interleave written for 128x64 wave tiles, 8 DMA/thread");
             constexpr int A_IT = A_BYTES / (NT * 16);
-            for (int kt = 0; kt < KT; ++kt) {
-                const int buf = kt & 1;
-                LDS_PTR(char) sa = smem + buf * (A_BYTES + B_BYTES);
-                LDS_PTR(char) sb = sa + A_BYTES;
+            static_assert(NSTAGE == 2 && 2 * A_BYTES <= 65536 && 2 * B_BYTES <= 65536, "stage offset must fit the ds_read immediate");
+            FragAddr2<BM, A_KMAJ, TM, A_BYTES> fa2;
+            FragAddr2<BN, B_KMAJ, TN, B_BYTES> fb2;
+            fa2.init(wm * WTM, lane, smem_addr);
+            fb2.init(wn * WTN, lane, smem_addr + 2 * A_BYTES);
+            // DMA source offsets: piece q of an operand = piece 0 + q * (a uniform number of bytes) -- the LDS swizzles
+            // repeat every 8 KiB of image -- so ONE VGPR per operand plus a scalar offset per piece (the buffer bounds
+            // check includes soffset on gfx950: tools/ubench/soffset_oob.hip).
+            uint32_t pva = piece_voff<BM, A_KMAJ, NT, BKT>(m0, 0, p.lda, tid, 0);
+            uint32_t pvb = piece_voff<BN, B_KMAJ, NT, BKT>(n0, 0, p.ldb, tid, 0);
+            asm volatile("" : "+v"(pva));
+            asm volatile("" : "+v"(pvb));
+            // rows (K-major) or k-rows (MN-major) covered by one piece = 8 KiB of LDS image
+            const uint32_t a_piece = (uint32_t)((A_KMAJ ? (NT / 64) * (1024 / (BKT * 2)) : (NT / 64) * (1024 / (BM * 2))) * 2) * (uint32_t)p.lda;
+            const uint32_t b_piece = (uint32_t)((B_KMAJ ? (NT / 64) * (1024 / (BKT * 2)) : (NT / 64) * (1024 / (BN * 2))) * 2) * (uint32_t)p.ldb;
+            const uint32_t m0base = __builtin_amdgcn_readfirstlane(smem_addr + wave * 1024);
+            const uint32_t a_step = A_KMAJ ? BKT * 2 : (uint32_t)(BKT * 2) * (uint32_t)p.lda;   // bytes per K-tile
+            const uint32_t b_step = B_KMAJ ? BKT * 2 : (uint32_t)(BKT * 2) * (uint32_t)p.ldb;
+            uint64_t a_base = (uint64_t)p.A + (uint64_t)a_step * (kt0 + 2), b_base = (uint64_t)p.B + (uint64_t)b_step * (kt0 + 2);
+            // bytes still addressable from the advanced base.  A DMA is only issued for K-tiles < KT_all, whose advance
+            // is < the operand's span, so this never wraps while it is in use (plain SALU subtract, no clamp).
+            uint32_t a_left = p.a_bytes - a_step * (uint32_t)(kt0 + 2), b_left = p.b_bytes - b_step * (uint32_t)(kt0 + 2);
+            // K-major kk addressing: off[kk] of stage `cur`.  Phase 1 reads k-step 1 of the current stage, phase 2
+            // reads k-step 0 of the other one: off[1] always points at the current stage, off[0] at the next.
+            if (A_KMAJ) { fa2.off[0] ^= A_BYTES; } else { /* MN-major: one set of addresses, flipped twice per tile */ }
+            if (B_KMAJ) { fb2.off[0] ^= B_BYTES; }
+            uint32_t m0cur = m0base;                          // LDS address (wave's 1 KiB slice) of the current stage's A image
+            const uint32_t m0sum = 2 * m0base + A_BYTES;
+            if (smem_addr & 0xffffu) __builtin_trap();        // the xor stage toggles assume the dynamic LDS block starts 64 KiB-aligned (it starts at 0)
+            auto body = [&](auto FULLC, bool more1, bool more2) {
+                constexpr bool FULL = decltype(FULLC)::value;
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {                 // phase 1: MFMAs of k-step 0, loads of k-step 1
-                    fa1[c] = fa_addr.load(sa, c, 1);
-                    if (c < 4) fb1[c] = fb_addr.load(sb, c, 1);
+                    // the 12 fragment reads go out in the first 6 groups, so the last one has two groups of MFMAs
+                    // to land before the lgkmcnt(0) + barrier below (and before the loop-top wait of the next tile)
+                    if (c < 4) { fa1[c] = fa2.load(c, 1); fb1[c] = fb2.load(c, 1); }
+                    else if (c < 6) { fa1[2 * c - 4] = fa2.load(2 * c - 4, 1); fa1[2 * c - 3] = fa2.load(2 * c - 3, 1); }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = c >> 1, j = (c & 1) * 4 + e;
@@ -293,19 +382,19 @@ void gemm_bf16_kernel(GemmArgs p) {
                 wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                const bool more1 = kt + 1 < KT, more2 = kt + 2 < KT;
-                LDS_PTR(char) na = smem + (buf ^ 1) * (A_BYTES + B_BYTES);
-                LDS_PTR(char) nb = na + A_BYTES;
-                const uint32_t da = smem_addr + buf * (A_BYTES + B_BYTES);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {                 // phase 2: MFMAs of k-step 1, next tile's k-step 0 + DMA
-                    if (more1) {
-                        fa0[c] = fa_addr.load(na, c, 0);
-                        if (c < 4) fb0[c] = fb_addr.load(nb, c, 0);
+                if (!A_KMAJ) fa2.flip();                      // MN-major: now address the next stage (k-step 0 reads)
+                if (!B_KMAJ) fb2.flip();
+                const u32x4 da = make_desc((const void*)a_base, a_left);
+                const u32x4 db = make_desc((const void*)b_base, b_left);
+                static_for<8>([&](auto CC) {                  // phase 2: MFMAs of k-step 1, next tile's k-step 0 + DMA
+                    constexpr int c = decltype(CC)::value;
+                    if (FULL || more1) {
+                        if constexpr (c < 4) { fa0[c] = fa2.load(c, 0); fb0[c] = fb2.load(c, 0); }
+                        else if constexpr (c < 6) { fa0[2 * c - 4] = fa2.load(2 * c - 4, 0); fa0[2 * c - 3] = fa2.load(2 * c - 3, 0); }
                     }
-                    if (more2) {
-                        if (c < A_IT) stage_piece<BM, A_KMAJ, NT, BKT>(ra, da, m0, (kt0 + kt + 2) * BKT, p.lda, tid, c);
-                        else stage_piece<BN, B_KMAJ, NT, BKT>(rb, da + A_BYTES, n0, (kt0 + kt + 2) * BKT, p.ldb, tid, c - A_IT);
+                    if (FULL || more2) {   // one DMA piece of tile kt+2 per group (bunching them earlier measured 3-8% slower)
+                        if constexpr (c < A_IT) dma16_m0imm<c * (NT / 64) * 1024>(da, m0cur, pva, a_piece * c);
+                        else dma16_m0imm<2 * A_BYTES + (c - A_IT) * (NT / 64) * 1024>(db, m0cur, pvb, b_piece * (c - A_IT));
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -313,8 +402,18 @@ void gemm_bf16_kernel(GemmArgs p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[i], fa1[j], acc[i][j], 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+                });
+                a_base += a_step; a_left -= a_step;
+                b_base += b_step; b_left -= b_step;
+                m0cur = m0sum - m0cur;                        // other stage (A_BYTES == B_BYTES: one toggle serves both images)
+                if (A_KMAJ) { fa2.flip(); }                   // K-major: both k-step addresses move to the other stage
+                if (B_KMAJ) { fb2.flip(); }
+            };
+            static_assert(A_BYTES == B_BYTES, "one xor toggles both stage images");
+            using std::integral_constant;
+            int kt = 0;
+            for (; kt + 2 < KT; ++kt) body(integral_constant<bool, true>{}, true, true);
+            for (; kt < KT; ++kt) body(integral_constant<bool, false>{}, kt + 1 < KT, kt + 2 < KT);
         } else {
         for (int kt = 0; kt < KT; ++kt) {
             const int buf = kt & 1;
@@ -392,30 +491,58 @@ void gemm_bf16_kernel(GemmArgs p) {
     }
 
     // ---- epilogue: lane holds D[n = g*4+r][m = lane&15] per 16x16 tile ----
+    if (p.debug & 1) return;
     const int g = lane >> 4, mi = lane & 15;
-    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldc & 3) == 0) && ((((uintptr_t)p.C) & 7) == 0) &&
-                          (EPI != EPI_RESID || (((p.ldr & 3) == 0) && ((((uintptr_t)p.R) & 7) == 0)));
-    if (interior) {
+    // Staged path: the C tile goes through LDS so that the global side is row-contiguous -- one store instruction
+    // covers 1 KiB of whole 128-B lines (2 rows x 512 B for BN=256) instead of 16 rows x 32 B straight from the MFMA
+    // register image.  Measured on MI355X (tools/ubench/store_rate.hip): 2.4 us vs 6.9 us per round of 256 tiles.
+    // LDS image: [BM][BN] bf16, 16-B slot s of row m at s ^ (m & 15)  (conflict-free for the 8-B transposed writes
+    // and the 16-B row reads).  Needs 16-B aligned rows; anything else takes the element-wise path below.
+    static_assert(BM * BN * 2 <= NSTAGE * (BM + BN) * BKT * 2, "C tile image must fit in the stage buffers");
+    const bool staged = ((p.ldc & 7) == 0) && ((p.N & 7) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
+                        (EPI != EPI_RESID || (((p.ldr & 7) == 0) && ((((uintptr_t)p.R) & 15) == 0))) &&
+                        (EPI != EPI_BIAS || ((((uintptr_t)p.R) & 7) == 0));
+    if (staged) {
+        __syncthreads();                                  // every wave is done with the operand stages
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
-            const int m = m0 + wm * WTM + j * 16 + mi;
+            const int ml = wm * WTM + j * 16 + mi;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                const int n = n0 + wn * WTN + i * 16 + g * 4;
+                const int nl = wn * WTN + i * 16 + g * 4;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                bf16_t* cp = p.C + (long)m * p.ldc + n;
                 if (EPI == EPI_BIAS) {
-                    const u32x2 bb = *(const u32x2*)(p.R + n);
-                    v[0] += __uint_as_float(bb[0] << 16); v[1] += __uint_as_float(bb[0] & 0xffff0000u);
-                    v[2] += __uint_as_float(bb[1] << 16); v[3] += __uint_as_float(bb[1] & 0xffff0000u);
-                } else if (EPI == EPI_ACCUM || EPI == EPI_RESID) {
-                    const bf16_t* rp = (EPI == EPI_ACCUM) ? cp : p.R + (long)m * p.ldr + n;
-                    const u32x2 rr = *(const u32x2*)rp;
-                    v[0] = __uint_as_float(rr[0] << 16) + rbf(v[0]); v[1] = __uint_as_float(rr[0] & 0xffff0000u) + rbf(v[1]);
-                    v[2] = __uint_as_float(rr[1] << 16) + rbf(v[2]); v[3] = __uint_as_float(rr[1] & 0xffff0000u) + rbf(v[3]);
+                    const int n = n0 + nl;
+                    if (n < p.N) {                        // N % 8 == 0 and n % 4 == 0: the 4 columns are in or out together
+                        const u32x2 bb = *(const u32x2*)(p.R + n);
+                        v[0] += __uint_as_float(bb[0] << 16); v[1] += __uint_as_float(bb[0] & 0xffff0000u);
+                        v[2] += __uint_as_float(bb[1] << 16); v[3] += __uint_as_float(bb[1] & 0xffff0000u);
+                    }
                 }
-                u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                *(u32x2*)cp = o;
+                const u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                *(LDS_PTR(u32x2))(smem + ml * (BN * 2) + ((((nl >> 3) ^ (ml & 15))) << 4) + ((nl >> 2) & 1) * 8) = o;
+            }
+        }
+        __syncthreads();
+        constexpr int SLOTS = BN / 8;                     // 16-B slots per C row
+        constexpr int ROWS_PER_PASS = NT / SLOTS;
+        const int c16 = tid % SLOTS, r_in = tid / SLOTS;
+        const int n = n0 + c16 * 8;
+        if (n < p.N) {
+#pragma unroll 4
+            for (int pass = 0; pass < BM / ROWS_PER_PASS; ++pass) {
+                const int ml = pass * ROWS_PER_PASS + r_in, m = m0 + ml;
+                if (m >= p.M) break;
+                u32x4 t = *(LDS_PTR(u32x4))(smem + ml * (BN * 2) + ((c16 ^ (ml & 15)) << 4));
+                bf16_t* cp = p.C + (long)m * p.ldc + n;
+                if (EPI == EPI_ACCUM || EPI == EPI_RESID) {    // torch: out = resid + bf16(acc)  /  grad += bf16(dW)
+                    const u32x4 rr = *(const u32x4*)((EPI == EPI_ACCUM) ? cp : p.R + (long)m * p.ldr + n);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        t[q] = pack2bf(__uint_as_float(rr[q] << 16) + __uint_as_float(t[q] << 16),
+                                       __uint_as_float(rr[q] & 0xffff0000u) + __uint_as_float(t[q] & 0xffff0000u));
+                }
+                *(u32x4*)cp = t;
             }
         }
         return;
@@ -475,23 +602,20 @@ int launch(const GemmArgs& p, hipStream_t st) {
 
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
 int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
-    // tile_cfg: 0 = auto, 1 = 128x128x64 2-stage (4 waves), 2 = 256x128x64 3-stage (8 waves),
-    //           3 = 256x256x64 2-stage (8 waves), 4 = 256x256x32 4-stage (8 waves)
+    // tile_cfg: 0 = auto, 1 = 128x128x64 2-stage (4 waves), 3 = 256x256x64 2-stage (8 waves), 6 = 3 with software-
+    //           pipelined fragments, 8 = 3 with the hand-interleaved, VALU-free main loop
     if (tile_cfg == 0) {
         // measured on MI355X (profiles/r01_gemm_probe*.txt): the 256x256 tile wins from ~1.4 rounds
         // of the 256 CUs upward, in all three layouts
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        // forward / dgrad: hand-interleaved schedule (8); wgrad (both operands through transposing reads, at the
-        // VGPR limit): compiler-scheduled pipelined loop (6) -- measured, profiles/r01_gemm_probe_v6.txt
-        tile_cfg = (t256 >= 128) ? (A_KMAJ ? 8 : 6) : 1;
+        // hand-interleaved schedule (8) in all three layouts: since its addressing moved to SGPRs/immediates the
+        // wgrad (TN) instance no longer spills and beats the compiler-scheduled loop (6) by ~15%
+        tile_cfg = (t256 >= 128) ? 8 : 1;
     }
     switch (tile_cfg) {
         case 1: return launch<128, 128, 2, 2, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
-        case 2: return launch<256, 128, 4, 2, 64, 3, A_KMAJ, B_KMAJ, EPI>(p, st);
         case 3: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
-        case 4: return launch<256, 256, 2, 4, 32, 4, A_KMAJ, B_KMAJ, EPI>(p, st);
         case 6: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 1>(p, st);   // software-pipelined fragments
-        case 7: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 2>(p, st);   // + s_setprio around the MFMA clusters
         case 8: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4>(p, st);   // hand-interleaved phases
     }
     return NV_ERR_ARG;
@@ -538,6 +662,8 @@ extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C
     p.slabs = workspace ? (float*)((char*)workspace + 4096) : nullptr;
     p.full_blocks = 0; p.rem = 1; p.split = 1;
     {
+        const char* dbg = getenv("NV_GEMM_DEBUG");
+        p.debug = dbg ? atoi(dbg) : 0;
         const char* e = getenv("NV_GEMM_GROUP_M");   // tuning knob; default 4 (4 x 8 patch per XCD)
         p.group_m = e ? atoi(e) : 4;
         if (p.group_m < 1) p.group_m = 1;

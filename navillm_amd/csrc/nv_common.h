@@ -69,6 +69,26 @@ __device__ __forceinline__ void dma4(const u32x4& desc, uint32_t lds_addr_unifor
         : "v"(voff), "s"(lds_addr_uniform), "s"(desc)
         : "memory");
 }
+// variant that leaves M0 overwritten (declared as a clobber, so hipcc re-materialises M0 itself in the rare
+// places it needs it): saves two SALU ops per DMA in the GEMM main loop, measured +1..3% there.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void dma16_nosave(const u32x4& desc, uint32_t lds_addr_uniform, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                 :
+                 : "v"(voff), "s"(lds_addr_uniform), "s"(desc)
+                 : "memory", "m0");
+}
+// LDS destination = scalar base + compile-time offset, formed straight into M0 (one SALU op, no VALU); source
+// offset = voff + soff (soff uniform; it takes part in the hardware bounds check like voff does)
+template <int IMM>
+__device__ __forceinline__ void dma16_m0imm(const u32x4& desc, uint32_t lds_base_uniform, uint32_t voff, uint32_t soff) {
+    asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %4 offen lds"
+                 :
+                 : "v"(voff), "s"(lds_base_uniform), "s"(desc), "n"(IMM), "s"(soff)
+                 : "memory", "m0", "scc");
+}
+#pragma clang diagnostic pop
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

@@ -12,9 +12,11 @@ def bench(fn, iters=20, warm=5):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-for tiles_m, tiles_n in ((16, 16), (16, 32)):
+LAYOUTS = [int(x) for x in os.environ.get('KS_LAYOUTS', '0,1,2').split(',')]
+SHAPES = ((16, 16), (16, 32)) if not os.environ.get('KS_ONE') else ((16, 16),)
+for tiles_m, tiles_n in SHAPES:
     M, N = tiles_m * 256, tiles_n * 256
-    for layout in (0, 1, 2):
+    for layout in LAYOUTS:
         res = []
         for K in (512, 1024, 2048, 4096, 8192):
             nset = 6
@@ -31,7 +33,7 @@ for tiles_m, tiles_n in ((16, 16), (16, 32)):
             it = [0]
             def run():
                 i = it[0] % nset; it[0] += 1
-                ops.gemm_bf16(layout, A[i], B[i], out=C, tile_cfg=6)
+                ops.gemm_bf16(layout, A[i], B[i], out=C, tile_cfg=int(os.environ.get("KS_CFG", "0")))
             t = bench(run)
             res.append((K, t))
             del A, B
