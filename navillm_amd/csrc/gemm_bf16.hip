@@ -38,8 +38,7 @@ struct GemmArgs {
     int full_blocks, rem, split;
     float* slabs;           // [rem*split][BM*BN] fp32 partials
     unsigned* counters;     // [rem] arrival tickets, zero between launches
-    int debug;              // NV_GEMM_DEBUG (measurement only): bit0 skip the C stores, bit1 skip the K loop,
-                            // bit2 no DMA wait (wrong results), bit3 no DMA at all (wrong results)
+    int debug;              // NV_GEMM_DEBUG (measurement only): bit0 skip the C stores, bit1 skip the K loop
 };
 
 // ---- LDS images (BKT = K extent of a stage, 64 or 32) -----------------------------------
@@ -662,14 +661,14 @@ extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C
     p.slabs = workspace ? (float*)((char*)workspace + 4096) : nullptr;
     p.full_blocks = 0; p.rem = 1; p.split = 1;
     {
-        const char* dbg = getenv("NV_GEMM_DEBUG");
-        p.debug = dbg ? atoi(dbg) : 0;
-        const char* e = getenv("NV_GEMM_GROUP_M");   // tuning knob; default 4 (4 x 8 patch per XCD)
-        p.group_m = e ? atoi(e) : 4;
-        if (p.group_m < 1) p.group_m = 1;
-        // partition the LARGER operand across the 8 XCD L2s (read once), replicate the smaller one
-        const char* o = getenv("NV_GEMM_ORDER");         // tuning knob: 0 rows, 1 column strips, unset = by operand size
-        p.col_strips = o ? atoi(o) : ((long)N > (long)M ? 1 : 0);
+        // tuning / measurement knobs, read once per process
+        static const int env_debug = [] { const char* e = getenv("NV_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
+        static const int env_group = [] { const char* e = getenv("NV_GEMM_GROUP_M"); return e ? atoi(e) : 4; }();   // 4 x 8 patch per XCD
+        static const int env_order = [] { const char* e = getenv("NV_GEMM_ORDER"); return e ? atoi(e) : -1; }();    // 0 rows, 1 column strips
+        p.debug = env_debug;
+        p.group_m = env_group < 1 ? 1 : env_group;
+        // default: partition the LARGER operand across the 8 XCD L2s (read once), replicate the smaller one
+        p.col_strips = env_order >= 0 ? env_order : ((long)N > (long)M ? 1 : 0);
     }
     hipStream_t st = (hipStream_t)stream;
     switch (layout) {

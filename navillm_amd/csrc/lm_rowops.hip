@@ -177,19 +177,30 @@ __global__ __launch_bounds__(NW * 64) void rmsnorm_bwd_kernel(const bf16_t* __re
     }
 }
 
-// gw[c] = bf16( gw[c] + bf16( sum_p part[p,c] ) ) ; block = 64 columns x 4 row slices
+// gw[c] = bf16( gw[c] + bf16( sum_p part[p,c] ) ) ; block = 16 columns x 16 row slices (d/16 blocks: one per CU at
+// d = 4096; the 64-column x 4-slice form had only 64 blocks and took longer than the backward kernel itself)
 __global__ __launch_bounds__(256) void dw_reduce_bf16_kernel(const float* __restrict__ part, bf16_t* __restrict__ gw, int P,
                                                              int d) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    float s = 0.f;
-    if (c < d)
-        for (int p = sl; p < P; p += 4) s += part[(long)p * d + c];
-    red[sl][cl] = s;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < d) {
+        int p = sl;
+        for (; p + 48 < P; p += 64) {
+            s0 += part[(long)p * d + c];
+            s1 += part[(long)(p + 16) * d + c];
+            s2 += part[(long)(p + 32) * d + c];
+            s3 += part[(long)(p + 48) * d + c];
+        }
+        for (; p < P; p += 16) s0 += part[(long)p * d + c];
+    }
+    red[sl][cl] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sl == 0 && c < d) {
-        s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][cl];
         gw[c] = f2bf(bf2f(gw[c]) + rbf(s));
     }
 }
@@ -357,7 +368,7 @@ int nv_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const floa
     NV_LAUNCH((rmsnorm_bwd_kernel<4, 4>), dim3(P), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, (const bf16_t*)w, rstd, (const bf16_t*)resid_grad, (bf16_t*)dx, (float*)workspace, M,
                        d);
-    NV_LAUNCH(dw_reduce_bf16_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+    NV_LAUNCH(dw_reduce_bf16_kernel, dim3((d + 15) / 16), dim3(256), 0, (hipStream_t)stream,
                        (const float*)workspace, (bf16_t*)gw, P, d);
     return nv_check_launch();
 }

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(512) void k_contig(const char* buf, size_t bytes, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 // BK = 64 or 32; RING = LDS slots of [512 rows x BK] (A and B slabs together); KEEP = steps left in flight at the wait
-template <int BK, int RING, int KEEP>
+template <int BK, int RING, int KEEP, bool SWZ = false>
 __global__ __launch_bounds__(512) void k_gemm(const char* A, const char* B, int M, int N, int K, int iters) {
     extern __shared__ char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -58,8 +58,11 @@ __global__ __launch_bounds__(512) void k_gemm(const char* A, const char* B, int 
             const bool isB = chunk >= (256 * ROWB / 1024);
             const int c2 = isB ? chunk - 256 * ROWB / 1024 : chunk;
             const int row = c2 * RPC + lane / (ROWB / 16);
-            const uint32_t voff = (uint32_t)(((size_t)((isB ? tn : tm) * 256 + row) * K + (size_t)kt * BK) * 2 + (lane % (ROWB / 16)) * 16);
-            dma16(isB ? db : da, lbase + slot * STEP_BYTES + chunk * 1024, voff);
+            const int sl = lane % (ROWB / 16);
+            const int slot = SWZ ? (sl ^ ((row >> 1) & (ROWB / 16 - 1))) : sl;    // the GEMM's XOR swizzle: lanes of a row fetch its 16-B pieces permuted
+            const uint32_t voff = (uint32_t)(((size_t)((isB ? tn : tm) * 256 + row) * K + (size_t)kt * BK) * 2 + slot * 16);
+            const uint32_t l = __builtin_amdgcn_readfirstlane(lbase + slot * STEP_BYTES + chunk * 1024);
+            if (p * 8 >= 256 * ROWB / 1024) dma16(db, l, voff); else dma16(da, l, voff);
         }
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP * PIECES) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -94,14 +97,14 @@ int main() {
     }
     const int M = 16 * 256, N = 16 * 256, K = 4096;                 // 4x4 XCD grid of 4x8-tile patches: 16 x 16 tiles
     char *A = buf, *B = buf + (1ull << 30);
-#define RUN(BK, RING, KEEP)                                                                                               \
+#define RUN(BK, RING, KEEP, ...)                                                                                             \
     {                                                                                                                     \
-        SETSMEM((k_gemm<BK, RING, KEEP>));                                                                                \
+        SETSMEM((k_gemm<BK, RING, KEEP, ##__VA_ARGS__>));                                                                              \
         const int n = iters * (64 / BK);                                                                                  \
-        float ms = time_ms([&] { hipLaunchKernelGGL((k_gemm<BK, RING, KEEP>), dim3(256), dim3(512), 512 * BK * 2 * RING, 0, A, B, M, N, K, n); }); \
-        printf("gemm-shaped BK=%d ring=%d keep=%d steps in flight: %6.1f B/ns/CU, %7.1f ns per 64-K of a 256x256 tile\n", BK, RING, KEEP,  \
+        float ms = time_ms([&] { hipLaunchKernelGGL((k_gemm<BK, RING, KEEP, ##__VA_ARGS__>), dim3(256), dim3(512), 512 * BK * 2 * RING, 0, A, B, M, N, K, n); }); \
+        printf("gemm-shaped%s BK=%d ring=%d keep=%d steps in flight: %6.1f B/ns/CU, %7.1f ns per 64-K of a 256x256 tile\n", sizeof(#__VA_ARGS__) > 1 ? " swizzled" : "", BK, RING, KEEP,  \
                n * 512.0 * BK * 2 / (ms * 1e6), ms * 1e6 / iters);                                                        \
     }
-    RUN(64, 2, 0) RUN(64, 2, 1) RUN(32, 4, 1) RUN(32, 4, 2) RUN(32, 4, 3) RUN(32, 5, 3) RUN(32, 5, 4)
+    RUN(64, 2, 0) RUN(64, 2, 1) RUN(64, 2, 0, true) RUN(64, 2, 1, true) RUN(32, 4, 1) RUN(32, 4, 2) RUN(32, 4, 3) RUN(32, 5, 3) RUN(32, 5, 4)
     return 0;
 }

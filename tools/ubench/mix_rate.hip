@@ -15,7 +15,7 @@ __device__ __forceinline__ u32x4 mkdesc(const void* p, size_t bytes) {
     const uint64_t a = (uint64_t)p;
     return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)bytes, 0x00020000u};
 }
-template <bool DMA, bool RD, bool MMA, int KEEP, bool BAR>
+template <bool DMA, bool RD, bool MMA, int KEEP, bool BAR, bool RND = false>
 __global__ __launch_bounds__(512) void k_mix(const char* A, const char* B, int K, int iters, float* out) {
     extern __shared__ char smem[];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -28,10 +28,23 @@ __global__ __launch_bounds__(512) void k_mix(const char* A, const char* B, int K
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[8], fb[4];
+    // RND: operands = pseudo-random bf16 in (-2, 2) (N(0,1)-like bit activity) instead of zeros: MFMA power, hence the
+    // sustained clock, depends on the data
+    unsigned h = (threadIdx.x + 1u) * 2654435761u ^ (blockIdx.x * 40503u);
+    auto rnd8 = [&]() {
+        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+        u4 w;
+        for (int q = 0; q < 4; ++q) {
+            h = h * 1664525u + 1013904223u;
+            const unsigned lo = 0x3f00u | ((h >> 8) & 0x80ffu), hi = 0x3f00u | ((h >> 16) & 0x80ffu);   // sign + 0.5..2 magnitude
+            w[q] = RND ? (lo | (hi << 16)) : 0u;
+        }
+        return __builtin_bit_cast(bf16x8, w);
+    };
 #pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = bf16x8{};
+    for (int i = 0; i < 8; ++i) fa[i] = rnd8();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fb[i] = bf16x8{};
+    for (int i = 0; i < 4; ++i) fb[i] = rnd8();
     typedef __attribute__((address_space(3))) bf16x8* lp;
     for (int it = 0; it < iters; ++it) {
         const int kt = it % KT;
@@ -89,13 +102,15 @@ int main() {
     float* out; (void)hipMalloc(&out, 4096);
     const int K = 4096, iters = 2000;
     char *A = buf, *B = buf + (1ull << 30);
-#define RUN(DMA, RD, MMA, KEEP, BAR, label)                                                                        \
+#define RUN(DMA, RD, MMA, KEEP, BAR, label, ...)                                                                     \
     {                                                                                                              \
-        (void)hipFuncSetAttribute((const void*)k_mix<DMA, RD, MMA, KEEP, BAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
-        float ms = time_ms([&] { hipLaunchKernelGGL((k_mix<DMA, RD, MMA, KEEP, BAR>), dim3(256), dim3(512), 131072, 0, A, B, K, iters, out); }); \
+        (void)hipFuncSetAttribute((const void*)k_mix<DMA, RD, MMA, KEEP, BAR, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+        float ms = time_ms([&] { hipLaunchKernelGGL((k_mix<DMA, RD, MMA, KEEP, BAR, ##__VA_ARGS__>), dim3(256), dim3(512), 131072, 0, A, B, K, iters, out); }); \
         printf("%-44s %7.1f ns per K-step  (= %6.0f TF if it were a GEMM)\n", label, ms * 1e6 / iters, 256.0 * 2 * 256 * 256 * 64 / (ms * 1e6 / iters) / 1e3); \
     }
-    RUN(false, false, true, 0, false, "MFMA only")
+    RUN(false, false, true, 0, false, "MFMA only (zero operands)")
+    RUN(false, false, true, 0, false, "MFMA only (random operands)", true)
+    RUN(false, false, true, 0, true, "MFMA + barrier (random operands)", true)
     RUN(false, true, true, 0, false, "MFMA + ds_read")
     RUN(false, true, true, 0, true, "MFMA + ds_read + barrier")
     RUN(true, false, false, 0, true, "DMA only, wait all at mid + barrier")
