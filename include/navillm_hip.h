@@ -127,6 +127,22 @@ int nv_gather_add_f32(const float* src, const int* idx, const float* base, float
 int nv_index_sum_f32(const float* src, const int* idx, float* dst, int n, int R, int d, int accumulate, void* stream);
 int nv_masked_mean_f32(const float* x, const float* mask, float* out, int B, int N, int d, void* stream);
 
+/* ---- data-parallel exchange over RCCL (C0-C3): replaces the DDP gradient all-reduce behind tools/optims.py:52-54
+ *      (+ its initial parameter broadcast) and the task-id broadcast of tasks/loaders.py:176-179.
+ *      One communicator per process/GPU; RCCL is bound at run time (the copy torch loaded, else /opt/rocm's).
+ *      Collectives are in place, stream-ordered, never allocate.  Returns NV_OK, NV_ERR_ARG (-1) or -4 (RCCL failure
+ *      / librccl not found). */
+typedef struct nv_ctx nv_ctx;
+int nv_comm_unique_id_bytes(void);                       /* 128 */
+int nv_comm_unique_id(void* id_out);                     /* rank 0; ship the bytes to the other ranks out of band */
+int nv_comm_init(nv_ctx** out, const void* id, int rank, int world);   /* collective; current HIP device */
+int nv_comm_rank(const nv_ctx* c);
+int nv_comm_world(const nv_ctx* c);
+int nv_comm_allreduce_bf16(nv_ctx* c, void* buf, long count, int average, void* stream);
+int nv_comm_allreduce_f32(nv_ctx* c, void* buf, long count, int average, void* stream);
+int nv_comm_broadcast(nv_ctx* c, void* buf, long bytes, int root, void* stream);
+int nv_comm_destroy(nv_ctx* c);
+
 #ifdef __cplusplus
 }
 #endif

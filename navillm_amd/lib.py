@@ -55,6 +55,16 @@ SIGNATURES = {
     "nv_gather_add_f32": (i, [fp, ip, fp, fp, l, i, vp]),
     "nv_index_sum_f32": (i, [fp, ip, fp, i, i, i, i, vp]),
     "nv_masked_mean_f32": (i, [fp, fp, fp, i, i, i, vp]),
+    # data-parallel exchange over RCCL (nv_ctx* travels as void*)
+    "nv_comm_unique_id_bytes": (i, []),
+    "nv_comm_unique_id": (i, [vp]),
+    "nv_comm_init": (i, [C.POINTER(C.c_void_p), vp, i, i]),
+    "nv_comm_rank": (i, [vp]),
+    "nv_comm_world": (i, [vp]),
+    "nv_comm_allreduce_bf16": (i, [vp, vp, l, i, vp]),
+    "nv_comm_allreduce_f32": (i, [vp, vp, l, i, vp]),
+    "nv_comm_broadcast": (i, [vp, vp, l, i, vp]),
+    "nv_comm_destroy": (i, [vp]),
 }
 
 _lib = None

@@ -41,6 +41,58 @@ def init_distributed_device(backend=None):
     return device, rank, world
 
 
+class RcclComm:
+    """The C-ABI communicator (`nv_comm_*`, include/navillm_hip.h) for hosts that do not want torch.distributed in
+    the data path: rank 0 draws the RCCL unique id, the other ranks receive it through `exchange` (any
+    `bytes -> bytes` broadcast: a TCPStore, a file, MPI); collectives run on the CURRENT torch stream, in place.
+
+    `NavDataParallel(model, comm=RcclComm(...))` or `NAVILLM_COMM=rccl` selects it; the default exchange uses a
+    `torch.distributed.TCPStore` on MASTER_PORT+1 (control plane only)."""
+
+    def __init__(self, rank, world, exchange=None):
+        import ctypes
+        from . import lib as _lib
+        self._lib, self._L = _lib, _lib.load()
+        self.rank, self.world = rank, world
+        n = self._L.nv_comm_unique_id_bytes()
+        uid = ctypes.create_string_buffer(n)
+        if rank == 0:
+            _lib.check(self._L.nv_comm_unique_id(uid), "nv_comm_unique_id")
+        if world > 1:
+            exchange = exchange or self._tcp_exchange
+            raw = exchange(uid.raw if rank == 0 else None)
+            uid = ctypes.create_string_buffer(raw, n)
+        self._ctx = ctypes.c_void_p()
+        _lib.check(self._L.nv_comm_init(ctypes.byref(self._ctx), uid, rank, world), "nv_comm_init")
+
+    def _tcp_exchange(self, payload):
+        store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 1,
+                              self.world, self.rank == 0)
+        if self.rank == 0:
+            store.set("nv_comm_uid", payload)
+            return payload
+        return store.get("nv_comm_uid")
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def allreduce_mean_(self, t):
+        fn = {torch.bfloat16: self._L.nv_comm_allreduce_bf16, torch.float32: self._L.nv_comm_allreduce_f32}[t.dtype]
+        self._lib.check(fn(self._ctx, t.data_ptr(), t.numel(), 1, self._stream()), "nv_comm_allreduce")
+        return t
+
+    def broadcast_(self, t, root=0):
+        self._lib.check(self._L.nv_comm_broadcast(self._ctx, t.data_ptr(), t.numel() * t.element_size(), root, self._stream()),
+                        "nv_comm_broadcast")
+        return t
+
+    def close(self):
+        if self._ctx:
+            self._L.nv_comm_destroy(self._ctx)
+            self._ctx = None
+
+
 def _allreduce_mean_(t, group=None):
     """In-place mean over ranks, enqueued on the CURRENT stream (SUM collective, then a 1/world scale:
     the plainest RCCL call there is; for bf16 the scale is our own HIP kernel)."""
@@ -70,10 +122,14 @@ class GradSlices:
 
 
 class NavDataParallel(torch.nn.Module):
-    def __init__(self, module, group=None, overlap=True):
+    def __init__(self, module, group=None, overlap=True, comm=None):
         super().__init__()
         self.module = module
         self.group = group
+        if comm is None and os.environ.get("NAVILLM_COMM") == "rccl" and module.store.device.type == "cuda":
+            _, rank, world = world_info_from_env()
+            comm = RcclComm(rank, world)
+        self.comm = comm                 # None: torch.distributed (RCCL through ProcessGroupNCCL); else the C-ABI communicator
         self.overlap = overlap
         self.require_sync = True
         self.slices = GradSlices(module.store)
@@ -88,6 +144,11 @@ class NavDataParallel(torch.nn.Module):
     @torch.no_grad()
     def broadcast_parameters(self):
         """DDP's initial rank-0 broadcast."""
+        if self.comm is not None:
+            if self.comm.world > 1:
+                for t in self.module.store.param.values():
+                    self.comm.broadcast_(t, 0)
+            return
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             for t in self.module.store.param.values():
                 dist.broadcast(t, src=0, group=self.group)
@@ -105,8 +166,19 @@ class NavDataParallel(torch.nn.Module):
             self.require_sync = old
 
     # ---- hooks called from LlamaStack.backward
+    def _world(self):
+        if self.comm is not None:
+            return self.comm.world
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _reduce(self, t):
+        if self.comm is not None:
+            self.comm.allreduce_mean_(t)
+        else:
+            _allreduce_mean_(t, self.group)
+
     def _active(self):
-        return self.require_sync and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return self.require_sync and self._world() > 1
 
     def on_backward_begin(self):
         if not self._active() or self._queued:
@@ -128,9 +200,9 @@ class NavDataParallel(torch.nn.Module):
             for e in events:
                 self._comm_stream.wait_event(e)
             with torch.cuda.stream(self._comm_stream):
-                _allreduce_mean_(t, self.group)
+                self._reduce(t)
         else:
-            _allreduce_mean_(t, self.group)
+            self._reduce(t)
 
     def _finalize(self):
         """end of the autograd pass: reduce what is left, then join the side stream."""
@@ -145,9 +217,9 @@ class NavDataParallel(torch.nn.Module):
     def sync_gradients(self):
         """Explicit one-shot reduction (e.g. once per optimizer step instead of per synced backward;
         mathematically the same mean)."""
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if self._world() > 1:
             for t in self.slices.all_slices():
-                _allreduce_mean_(t, self.group)
+                self._reduce(t)
 
 
 def broadcast_task_id(task_id, device, group=None):

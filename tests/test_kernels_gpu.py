@@ -441,3 +441,21 @@ def test_small_f32_ops():
     mk = (torch.arange(36, device=dev())[None] < torch.tensor([36, 20, 1, 30], device=dev())[:, None]).float()
     want = (xm * mk[..., None]).sum(1) / mk.sum(1, keepdim=True)
     assert_close(ops.masked_mean_f32(xm, mk), want, 1e-5, 1e-6, "masked mean")
+
+
+@pytest.mark.gpu
+def test_nv_comm_single_rank_roundtrip():
+    """nv_comm_* over RCCL with a world of one (the box has one GPU): init, mean all-reduce and broadcast leave the
+    data unchanged, destroy succeeds.  The multi-rank wiring is covered on CPU by tests/test_dp_gloo.py."""
+    from navillm_amd.parallel import RcclComm
+    comm = RcclComm(0, 1)
+    x = torch.randn(4096 + 24, device="cuda").bfloat16()
+    y = x.clone()
+    comm.allreduce_mean_(y)
+    f = torch.randn(1000, device="cuda")
+    g = f.clone()
+    comm.allreduce_mean_(g)
+    comm.broadcast_(g, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(x, y) and torch.equal(f, g)
+    comm.close()

@@ -207,26 +207,23 @@ def test_tokenizer_path_matches_fixture_ids():
     assert torch.equal(t["input_ids"], T(z["input_ids"])) and torch.equal(t["attention_mask"], T(z["attention_mask"]))
 
 
-@pytest.mark.parametrize("B,S_instr", [(4, 200)])
-def test_midsize_navigation_vs_oracle(B, S_instr):
-    """multi-tile sizes (d=512, 4 heads, ff=1408, 3 layers, 36 views, S~300): HIP vs the CPU oracle run in
-    bf16 and in fp32 on the same seeded weights and inputs, through the synthetic episode driver."""
+def _nav_vs_oracle(cfg, B, S_instr, steps, tag, expect_S=None):
+    """HIP vs the CPU oracle run in bf16 and in fp32 on the same seeded weights and inputs, through the synthetic
+    episode driver (panorama -> map update -> navigation per step)."""
     from navillm_amd import config as nvcfg
     from navillm_amd.nav_model import NavModel
     from navillm_amd.params import synth_state_dict
     from navillm_amd.synthetic import SyntheticEpisodes
-    from navillm_amd.losses import CrossEntropyLoss
     O = load_oracle()
-    cfg = nvcfg.NavConfig(hidden_size=512, num_layers=3, num_heads=4, intermediate_size=1408, base_vocab_size=1000,
-                          enc_hidden_size=256, enc_num_heads=4, enc_intermediate_size=512, image_feat_size=768)
     m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=5)
     m.eval()
     P16 = synth_state_dict(cfg, 5)
+    with torch.no_grad():
+        assert m.load_reference_state_dict(P16) == len(P16)      # (large models draw their own weights on the device)
     cfg32 = nvcfg.NavConfig(**{**cfg.__dict__, "precision": "fp32"})
     P32 = {k: v.float() for k, v in P16.items()}
     ep = SyntheticEpisodes(cfg, B, seed=77, instr_len=S_instr, device=torch.device(DEV))
-    crit = CrossEntropyLoss()
-    for step in range(3):
+    for step in range(steps):
         pin = ep.panorama_inputs()
         with torch.no_grad():
             pano = m("panorama", pin)
@@ -236,6 +233,8 @@ def test_midsize_navigation_vs_oracle(B, S_instr):
         ep.update_maps(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
         nav = ep.nav_inputs(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
         ids, am = ep.tokenise(nav, "<cls_1>")
+        if expect_S is not None:
+            assert ids.shape[1] == expect_S, ids.shape
         nav["input_ids"], nav["attention_mask"] = ids, am
         torch.manual_seed(100 + step)
         with torch.no_grad():
@@ -243,18 +242,48 @@ def test_midsize_navigation_vs_oracle(B, S_instr):
         cpu = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in nav.items()}
         cpu["hist_vis"] = [[v.cpu() for v in vis] for vis in nav["hist_vis"]]
         outs = {}
-        for tag, P, c in (("bf16", P16, cfg), ("fp32", P32, cfg32)):
+        for prec, P, c in (("bf16", P16, cfg), ("fp32", P32, cfg32)):
             torch.manual_seed(100 + step)
             with torch.no_grad():
-                outs[tag] = O.navigation(P, c, cpu, ids, am)
+                outs[prec] = O.navigation(P, c, cpu, ids, am)
         assert maxerr(out["fuse_embeds"], outs["fp32"]["fuse_embeds"]) < 1e-4
         lg = out["fuse_logits"]
         gap, e_hip, e_ref = maxerr(lg, outs["bf16"]["fuse_logits"]), maxerr(lg, outs["fp32"]["fuse_logits"]), \
             maxerr(outs["bf16"]["fuse_logits"], outs["fp32"]["fuse_logits"])
-        print(f"[mid step {step}] S={ids.shape[1]} logits |hip-orc16|={gap:.5f} |hip-orc32|={e_hip:.5f} |orc16-orc32|={e_ref:.5f}")
+        print(f"[{tag} step {step}] S={ids.shape[1]} logits |hip-orc16|={gap:.5f} |hip-orc32|={e_hip:.5f} |orc16-orc32|={e_ref:.5f}")
         assert e_hip <= 1.5 * e_ref + 3e-3 and gap <= 2.5 * e_ref + 3e-3
         targets = ep.teacher_targets(nav, last=False)
         ep.advance(nav, targets, out["fuse_embeds"])
+    del m
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("B,S_instr", [(4, 200)])
+def test_midsize_navigation_vs_oracle(B, S_instr):
+    """multi-tile sizes (d=512, 4 heads, ff=1408, 3 layers, 36 views, S~300)."""
+    from navillm_amd import config as nvcfg
+    cfg = nvcfg.NavConfig(hidden_size=512, num_layers=3, num_heads=4, intermediate_size=1408, base_vocab_size=1000,
+                          enc_hidden_size=256, enc_num_heads=4, enc_intermediate_size=512, image_feat_size=768)
+    _nav_vs_oracle(cfg, B, S_instr, 3, "mid")
+
+
+def test_long_horizon_truncation_limit_vs_oracle():
+    """SURVEY.md §8d config 4 (long-horizon, S at the 1024-token left-truncation limit of modified_lm.py:77-87): the
+    prompt is longer than 1024 tokens, so the tokeniser side truncates from the left and every attention tile /
+    split path runs at the maximum sequence length."""
+    from navillm_amd import config as nvcfg
+    cfg = nvcfg.NavConfig(hidden_size=512, num_layers=2, num_heads=4, intermediate_size=1408, base_vocab_size=1000,
+                          enc_hidden_size=256, enc_num_heads=4, enc_intermediate_size=512, image_feat_size=768)
+    _nav_vs_oracle(cfg, 2, 1000, 2, "long", expect_S=1024)
+
+
+def test_13b_shaped_layer_vs_oracle():
+    """SURVEY.md §8d config 5 shapes (Vicuna-13B: d=5120, 40 heads, ff=13824) on one decoder layer: tile counts that are
+    not powers of two (20 / 54 / 108 column tiles), 40 heads in the attention grid."""
+    from navillm_amd import config as nvcfg
+    cfg = nvcfg.NavConfig(hidden_size=5120, num_layers=1, num_heads=40, intermediate_size=13824, base_vocab_size=1000,
+                          enc_hidden_size=256, enc_num_heads=4, enc_intermediate_size=512, image_feat_size=768)
+    _nav_vs_oracle(cfg, 2, 150, 1, "13b-layer")
 
 
 def test_pruned_last_layer_matches_full_path():
