@@ -218,6 +218,21 @@ def main():
             torch.cuda.synchronize()
         infer = {"nav_steps_per_s_per_gpu": round(a.batch * a.infer_steps / (time.perf_counter() - t1), 2),
                  "steps": a.infer_steps, "what": "panorama + navigation forward only, argmax actions, eval mode"}
+        # the same rollout with prompt-prefix K/V reuse: one warm episode, one timed episode
+        model.enable_kv_cache(a.batch, capacity=1024)
+        with torch.no_grad():
+            for rep in range(2):
+                ep.reset()
+                model.reset_kv_cache()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(STEPS_PER_EPISODE):
+                    nav_step(wrapped, crit, ep, train=False)
+                torch.cuda.synchronize()
+        infer_kv = {"nav_steps_per_s_per_gpu": round(a.batch * STEPS_PER_EPISODE / (time.perf_counter() - t1), 2),
+                    "steps": STEPS_PER_EPISODE, "last_step_new_tokens": model.kv.last_stats["new"],
+                    "what": "one whole episode (first step = full prefill), K/V of the prompt prefix reused from step to step"}
+        model.kv = None
         model.train()
 
     if rank == 0:
@@ -236,6 +251,7 @@ def main():
         }
         if infer is not None:
             line["inference_forward_only"] = infer
+            line["inference_prefix_kv_reuse"] = infer_kv
         if g is not None:
             allg = timer.summary(layouts=(0, 1, 2))
             line["roofline"] = {"bound": "mfma", "achieved": round(g["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,

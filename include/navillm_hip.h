@@ -65,6 +65,8 @@ int nv_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const floa
  *      backward != 0 applies the transpose */
 int nv_rope_bf16(void* qkv, const void* cos_t, const void* sin_t, int M, int S, int H, int hd, int ld, int backward,
                  void* stream);
+/*   per-row positions pos[m] (forward only): the position_ids of HF's generation path (left-aligned per-sample frames) */
+int nv_rope_rows_bf16(void* qkv, const void* cos_t, const void* sin_t, const int* pos, int M, int H, int hd, int ld, void* stream);
 
 /* ---- HF LlamaMLP activation on packed gate|up [M, 2*ff]: h = bf16(bf16(silu(g)) * u) */
 int nv_swiglu_fwd_bf16(const void* gu, void* h, int M, int ff, void* stream);
@@ -81,6 +83,10 @@ int nv_scatter_rows_bf16(const void* src, const int* rows, void* dst, int n, int
  *   carry gradient (backward; dQ rows below it are left untouched) -- the navigation modes read one row. */
 int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, int B, int S, int H, int head_dim,
                      int q_row_min, void* stream);
+/*   KV-cache layout (inference; SURVEY.md §8f items 1-2, HF generation path reached from models/modified_lm.py:184-199):
+ *   sample b's rows start at b*S_stride in qkv, out and lse2; S = longest valid length. */
+int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, int B, int S, int S_stride, int H,
+                             int head_dim, int q_row_min, void* stream);
 size_t nv_attn_bwd_workspace_bytes(int B, int S, int H);
 int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
                      void* workspace, int B, int S, int H, int head_dim, int q_row_min, void* stream);

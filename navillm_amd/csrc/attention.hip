@@ -82,6 +82,7 @@ struct AttnArgs {
     const bf16_t* dout; const float* dsum; bf16_t* dqkv; // bwd
     const int* kv_start;
     int B, S, H, ld;       // ld = 3*H*HD (qkv row stride), out row stride = H*HD
+    int Sst;               // rows between consecutive samples in qkv/out/lse2 (= S, or a KV cache's capacity >= S)
     int q_row_min;         // only queries >= q_row_min are computed / differentiated (multiple of 128; 0 = all)
     float scale2;          // head_dim^-0.5 * log2(e)
     float scale;           // head_dim^-0.5
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const int q0 = p.q_row_min + blockIdx.x * 128;
     const int kvs = p.kv_start[b];
     const int qi = lane & 15, g = lane >> 4;
-    const bf16_t* base = p.qkv + (long)b * S * ld;
+    const bf16_t* base = p.qkv + (long)b * p.Sst * ld;
     const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
     const u32x4 rs = make_desc(base, span);
     const int kcol = p.H * HD + h * HD, vcol = 2 * p.H * HD + h * HD;
@@ -212,13 +213,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         const bool valid = qpos[j] < S;
         const float inv = lt > 0.f ? 1.f / lt : 0.f;
         if (valid) {
-            bf16_t* op = p.out + ((long)b * S + qpos[j]) * (p.H * HD) + h * HD + g * 4;
+            bf16_t* op = p.out + ((long)b * p.Sst + qpos[j]) * (p.H * HD) + h * HD + g * 4;
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
                 u32x2 w = {pack2bf(o[dt][j][0] * inv, o[dt][j][1] * inv), pack2bf(o[dt][j][2] * inv, o[dt][j][3] * inv)};
                 *(u32x2*)(op + dt * 16) = w;
             }
-            if (g == 0) p.lse2[((long)b * p.H + h) * S + qpos[j]] = lt > 0.f ? m2[j] + log2f(lt) : INFINITY;
+            if (g == 0) p.lse2[((long)b * p.H + h) * p.Sst + qpos[j]] = lt > 0.f ? m2[j] + log2f(lt) : INFINITY;
         }
     }
 }
@@ -464,7 +465,24 @@ int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_star
     if (!once) { if (set_lds((const void*)attn_fwd_kernel, 65536)) return NV_ERR_LAUNCH; once = true; }
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = kv_start;
-    p.B = B; p.S = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
+    p.B = B; p.S = S; p.Sst = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
+    p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
+    NV_LAUNCH(attn_fwd_kernel, dim3((S - q_row_min + 127) / 128, B * H), dim3(256), 65536, (hipStream_t)stream, p);
+    return nv_check_launch();
+}
+
+// The same forward over a KV-cache layout: sample b's rows start at b*S_stride (S_stride >= S = the longest valid
+// length); out and lse2 use the same sample stride.  Inference only (prefix reuse / generation).
+int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, int B, int S, int S_stride, int H,
+                             int head_dim, int q_row_min, void* stream) {
+    if (!qkv || !out || !lse2 || !kv_start) return NV_ERR_ARG;
+    if (head_dim != HD || (q_row_min & 127) || q_row_min < 0 || (S > 0 && q_row_min >= S) || S_stride < S) return NV_ERR_SHAPE;
+    if (B == 0 || S == 0) return NV_OK;
+    static bool once = false;
+    if (!once) { if (set_lds((const void*)attn_fwd_kernel, 65536)) return NV_ERR_LAUNCH; once = true; }
+    AttnArgs p{};
+    p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = kv_start;
+    p.B = B; p.S = S; p.Sst = S_stride; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
     NV_LAUNCH(attn_fwd_kernel, dim3((S - q_row_min + 127) / 128, B * H), dim3(256), 65536, (hipStream_t)stream, p);
     return nv_check_launch();
@@ -491,7 +509,7 @@ int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const f
                        (const bf16_t*)out, dsum, B, S, H);
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.lse2 = (float*)lse2; p.dsum = dsum; p.dqkv = (bf16_t*)dqkv;
-    p.kv_start = kv_start; p.B = B; p.S = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
+    p.kv_start = kv_start; p.B = B; p.S = S; p.Sst = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
     // with q_row_min > 0 only those query rows carry gradient: dK/dV still cover every key, dQ rows below
     // q_row_min are NOT written (the caller zero-fills them)

@@ -210,9 +210,11 @@ __global__ __launch_bounds__(256) void dw_reduce_bf16_kernel(const float* __rest
 // including left padding).  cs: [maxS, hd] bf16 cos | [maxS, hd] bf16 sin rows as HF
 // builds them (halves duplicated).  out = bf16( bf16(x*cos) + bf16(rot_half(x)*sin) );
 // sign=-1 gives the transpose (backward).
+// With `pos` (int32 [M]) the position of row m is pos[m] instead (KV-cache inference: left-aligned per-sample
+// frames, the position_ids of HF's generation path).
 __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cos_t,
-                                                   const bf16_t* __restrict__ sin_t, int M, int S, int H, int hd, int ld,
-                                                   float sign) {
+                                                   const bf16_t* __restrict__ sin_t, const int* __restrict__ pos, int M, int S,
+                                                   int H, int hd, int ld, float sign) {
     const int half = hd / 2;
     const int per_head = half / 8;                 // 8-wide vectors in the first half
     const long total = (long)M * 2 * H * per_head;  // q and k heads
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, con
         long r = i / per_head;
         const int head = (int)(r % (2 * H));       // 0..H-1 = q heads, H..2H-1 = k heads
         const int m = (int)(r / (2 * H));
-        const int s = m % S;
+        const int s = pos ? pos[m] : m % S;
         bf16_t* base = qkv + (long)m * ld + (long)head * hd + v * 8;
         float a[8], b[8], c[8], sn[8];
         ld8(base, a);
@@ -378,7 +380,16 @@ int nv_rope_bf16(void* qkv, const void* cos_t, const void* sin_t, int M, int S, 
     if (!qkv || !cos_t || !sin_t || (hd & 15) || S <= 0) return NV_ERR_ARG;
     if (M == 0) return NV_OK;
     NV_LAUNCH(rope_kernel, dim3(grid_for((long)M * 2 * H * hd / 16)), dim3(256), 0, (hipStream_t)stream,
-                       (bf16_t*)qkv, (const bf16_t*)cos_t, (const bf16_t*)sin_t, M, S, H, hd, ld, backward ? -1.f : 1.f);
+                       (bf16_t*)qkv, (const bf16_t*)cos_t, (const bf16_t*)sin_t, (const int*)nullptr, M, S, H, hd, ld,
+                       backward ? -1.f : 1.f);
+    return nv_check_launch();
+}
+
+int nv_rope_rows_bf16(void* qkv, const void* cos_t, const void* sin_t, const int* pos, int M, int H, int hd, int ld, void* stream) {
+    if (!qkv || !cos_t || !sin_t || !pos || (hd & 15)) return NV_ERR_ARG;
+    if (M == 0) return NV_OK;
+    NV_LAUNCH(rope_kernel, dim3(grid_for((long)M * 2 * H * hd / 16)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)qkv, (const bf16_t*)cos_t, (const bf16_t*)sin_t, pos, M, 1, H, hd, ld, 1.f);
     return nv_check_launch();
 }
 

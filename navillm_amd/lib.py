@@ -25,12 +25,14 @@ SIGNATURES = {
     "nv_rmsnorm_bwd_workspace_bytes": (sz, [i]),
     "nv_rmsnorm_bwd_bf16": (i, [vp, vp, vp, fp, vp, vp, vp, vp, i, i, vp]),
     "nv_rope_bf16": (i, [vp, vp, vp, i, i, i, i, i, i, vp]),
+    "nv_rope_rows_bf16": (i, [vp, vp, vp, ip, i, i, i, i, vp]),
     "nv_swiglu_fwd_bf16": (i, [vp, vp, i, i, vp]),
     "nv_swiglu_bwd_bf16": (i, [vp, vp, vp, i, i, vp]),
     "nv_scale_bf16": (i, [vp, vp, l, f, vp]),
     "nv_gather_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
     "nv_scatter_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
     "nv_attn_fwd_bf16": (i, [vp, vp, fp, ip, i, i, i, i, i, vp]),
+    "nv_attn_fwd_strided_bf16": (i, [vp, vp, fp, ip, i, i, i, i, i, i, vp]),
     "nv_attn_bwd_workspace_bytes": (sz, [i, i, i]),
     "nv_attn_bwd_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, i, vp]),
     "nv_head_fwd_bf16": (i, [vp, vp, vp, vp, i, i, i, vp]),

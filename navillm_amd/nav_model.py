@@ -7,8 +7,9 @@ touch (`.lang_model.cls_token`, `.lang_model.tokenizer`, `.lang_model.cls_token_
 (navillm_amd/functions.py); the host only does what the reference also does on the host:
 tokenisation, vpid matching (nav_model.py:174-190), candidate permutation (:216-223).
 
-Not mirrored (raise NotImplementedError): `generate()` paths of summarization/3dqa/embodied_qa
-inference (SURVEY.md §8f "next"), fp32 LM, OPT LMs.
+Inference extras (SURVEY.md §8f): `enable_kv_cache()` = prompt-prefix K/V reuse across no-grad navigation steps;
+`training=False` in the LM-loss modes = greedy generation (navillm_amd/kvcache.py).
+Not mirrored (raise NotImplementedError): sampling generation, fp32 LM, OPT LMs.
 """
 import collections
 import math
@@ -128,6 +129,7 @@ class NavModel(nn.Module):
         self.arena = Fn.ActivationArena(cfg, self.device)
         self.overlap_wgrad = True
         self.prune_last_layer = True     # navigation/grounding: last decoder layer computed for the <cls_1> rows only
+        self.kv = None                   # KVCacheLM (enable_kv_cache): prefix reuse across no-grad navigation steps + generation
         self._wgrad_stream = None
         self._dp = None
         self.drop_env_p = cfg.feat_dropout
@@ -172,6 +174,19 @@ class NavModel(nn.Module):
     def reserve_activations(self, batch, seq_len):
         """size the LM activation arena once, up front (B*S rows)"""
         self.arena.reserve(batch * seq_len)
+
+    def enable_kv_cache(self, batch_size, capacity=1024):
+        """Inference: keep every decoder layer's K/V of the prompts seen last.  Under
+        `torch.no_grad()` the navigation / object-grounding modes then run only the tokens that differ from the previous
+        call of the same batch slot (the prompt prefix up to the last <hist> repeats from step to step).  Call
+        `reset_kv_cache()` at episode boundaries (a mismatching prompt is detected anyway and simply recomputed)."""
+        from .kvcache import KVCacheLM
+        self.kv = KVCacheLM(self, batch_size, capacity)
+        return self.kv
+
+    def reset_kv_cache(self):
+        if self.kv is not None:
+            self.kv.reset()
 
     def zero_grad(self, set_to_none=False):
         self.store.zero_grad()
@@ -370,6 +385,62 @@ class NavModel(nn.Module):
             Hs = Fn.GatherRowsBF16.apply(Hs, self._cls_rows(ids_cpu))
         return Hs
 
+    def _vis_layout(self, ids_cpu, am_cpu, cand_vis, hist_vis, obj_vis, hist_keys=None):
+        """per-sample unpadded ids + visual-row indices (rows of cat(cand, hist, obj), the order of modified_lm.py:100-110)
+        + one reuse key per visual row (`False`: recompute every call)."""
+        cfg = self.cfg
+        B, S = ids_cpu.shape
+        flat = ids_cpu.reshape(-1)
+        vis_idx = torch.full((B * S,), -1, dtype=torch.int64)
+        parts, keys, off = [], [], 0
+        for tok_id, vis, k in ((cfg.cand_token_id, cand_vis, None), (cfg.hist_token_id, hist_vis, hist_keys),
+                               (cfg.obj_token_id, obj_vis, None)):
+            loc = torch.nonzero(flat == tok_id).view(-1)
+            if loc.numel() == 0:
+                continue
+            assert vis is not None and vis.shape[0] == loc.numel(), \
+                f"{loc.numel()} special tokens of id {tok_id} but {None if vis is None else vis.shape[0]} visual rows"
+            vis_idx[loc] = torch.arange(off, off + loc.numel())
+            parts.append(vis.to(F32))
+            keys.extend(k if k is not None else [False] * loc.numel())
+            off += loc.numel()
+        vis_all = torch.cat(parts, 0).contiguous() if parts else None
+        lens = am_cpu.bool().sum(1).tolist()
+        ids_l = [ids_cpu[b, S - lens[b]:].tolist() for b in range(B)]
+        vix_l = [vis_idx.view(B, S)[b, S - lens[b]:].tolist() for b in range(B)]
+        return ids_l, vix_l, vis_all, keys
+
+    def _lm_cached(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None, hist_keys=None):
+        """no-grad twin of `_lm(..., cls_tail=True)` over the K/V cache: [B, d] hidden state of each prompt's last token."""
+        assert bool((ids_cpu[:, -1] == self.cfg.cls_token_ids[0]).all()), "cached path: prompts must end in <cls_1>"
+        ids_l, vix_l, vis_all, keys = self._vis_layout(ids_cpu, am_cpu, cand_vis, hist_vis, obj_vis, hist_keys)
+        return self.kv.extend(ids_l, vix_l, vis_all, keys)
+
+    @torch.no_grad()
+    def _generate(self, ids_cpu, am_cpu, cand_vis, hist_vis, max_new_tokens=20, trie=None, do_sample=False, **unused):
+        """`self.lang_model.generate(...)` of nav_model.py:324-341,388-402: greedy, eos-terminated, pad = unk, special
+        ids masked, optional trie; served by the K/V-cache decoder (navillm_amd/kvcache.py)."""
+        if do_sample:
+            raise NotImplementedError("sampling (do_sample=True) is not built; the reference's eval configs decode greedily")
+        from .kvcache import KVCacheLM
+        B, S = ids_cpu.shape
+        need = S + max_new_tokens
+        kv = self.kv if (self.kv is not None and self.kv.B == B and self.kv.cap >= need) else \
+            KVCacheLM(self, B, capacity=(need + 127) // 128 * 128)
+        ids_l, vix_l, vis_all, _ = self._vis_layout(ids_cpu, am_cpu, cand_vis, hist_vis, None)
+        tok = self.lang_model.tokenizer
+        eos = getattr(tok, "eos_token_id", None)
+        pad = getattr(tok, "unk_token_id", None)
+        gen = kv.generate(ids_l, vix_l, vis_all, max_new_tokens=max_new_tokens, eos_token_id=2 if eos is None else eos,
+                          pad_token_id=0 if pad is None else pad, trie=trie)
+        kv.reset()
+        out = {"generated_ids": gen}
+        if hasattr(tok, "batch_decode"):
+            out["generated_sentences"] = tok.batch_decode(gen, skip_special_tokens=True, clean_up_tokenization_spaces=False)
+        else:
+            out["generated_sentences"] = [" ".join(str(t) for t in g) for g in gen]
+        return out
+
     def _lm_loss(self, Hs, ids_cpu, labels_cpu):
         """shifted mean CE over labels != -100 (modified_lm.py:126-137)."""
         B, S = ids_cpu.shape
@@ -449,7 +520,12 @@ class NavModel(nn.Module):
 
         hist_vis = self._stack_hist(batch["hist_vis"])
         ids, am, _ = self._tokens(batch, batch["prompts"])
-        Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)
+        if self.kv is not None and not torch.is_grad_enabled() and self.kv.B == B:
+            # history embeddings are constants once appended (mp3d_agent.py:774-778): key = (slot, index, storage)
+            hk = [("hist", b, k, v.data_ptr()) for b, vis in enumerate(batch["hist_vis"]) for k, v in enumerate(vis)]
+            Hs_cls = self._lm_cached(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, hist_keys=hk)
+        else:
+            Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)
         pred = Fn.HeadBF16.apply(Hs_cls, self, "out_head.0")   # [B,100]
 
         # fuse_logits[b][cand slots] = [pred[b,0], pred[b,1:n][inv_perm]] ; -inf elsewhere (:234-242)
@@ -486,9 +562,7 @@ class NavModel(nn.Module):
         return Fn.add(e, self.P("token_type_embeddings.weight")[0])
 
     def forward_3dqa(self, mode, batch, training=True, **kwargs):
-        """nav_model.py:346-385 (training). Inference (`generate`) is not built yet."""
-        if not training:
-            raise NotImplementedError("3dqa generation path: SURVEY.md §8f item 2 (next)")
+        """nav_model.py:346-404: training -> `.loss`; training=False -> greedy generation (`generated_sentences`)."""
         dev, d = self.device, self.cfg.hidden_size
         feats = [ops.h2d(f, dev, F32) for f in batch["features"]]
         B = len(feats)
@@ -504,6 +578,9 @@ class NavModel(nn.Module):
         inv = torch.full((B * N,), -1, dtype=torch.int32)
         inv[sel.long()] = torch.arange(sel.numel(), dtype=torch.int32)
         cand_vis = Fn.GatherRowsF32.apply(pe, ops.h2d(sel, dev), ops.h2d(inv, dev), None)
+        if not training:
+            ids, am, _ = self._tokens(batch, None if batch.get("input_ids") is not None else list(batch["prompts"]))
+            return self._generate(ids, am, cand_vis, None, **kwargs)
         if batch.get("input_ids") is None:
             eos = self.lang_model.tokenizer.eos_token
             text = [[batch["prompts"][bn], batch["answers"][bn][0] + f"{eos}"] for bn in range(B)]
@@ -516,9 +593,8 @@ class NavModel(nn.Module):
         return _Out(loss=self._lm_loss(Hs, ids, labels))
 
     def forward_summarization(self, mode, batch, training=True, **kwargs):
-        """nav_model.py:251-319 (training branch)."""
-        if not training:
-            raise NotImplementedError("summarization/embodied_qa generation path: SURVEY.md §8f item 2 (next)")
+        """nav_model.py:251-343: training -> `.loss`; training=False -> greedy generation with `max_new_tokens=50` and
+        the optional `trie` constraint (`generated_sentences`)."""
         dev, d = self.device, self.cfg.hidden_size
         vp_img = batch["vp_img_embeds"][:, 1:, :]
         nav_masks = torch.as_tensor(batch["vp_nav_masks"]).cpu().bool()[:, 1:]
@@ -528,6 +604,9 @@ class NavModel(nn.Module):
         inv = torch.full((B * N,), -1, dtype=torch.int32)
         inv[sel.long()] = torch.arange(sel.numel(), dtype=torch.int32)
         cand_vis = Fn.GatherRowsF32.apply(x, ops.h2d(sel, dev), ops.h2d(inv, dev), None) if sel.numel() else None
+        if not training:
+            ids, am, _ = self._tokens(batch, None if batch.get("input_ids") is not None else list(batch["prompts"]))
+            return self._generate(ids, am, cand_vis, self._stack_hist(batch["hist_vis"]), max_new_tokens=50, trie=kwargs.get("trie"))
         if batch.get("input_ids") is None:
             eos = self.lang_model.tokenizer.eos_token
             dt = batch["data_type"][0]

@@ -150,6 +150,13 @@ def rope_(qkv, cos_t, sin_t, S, H, hd, backward=False):
     return qkv
 
 
+def rope_rows_(qkv, cos_t, sin_t, pos_i32, H, hd):
+    """in-place RoPE with an explicit position per row (KV-cache inference)."""
+    _lib.check(_L().nv_rope_rows_bf16(qkv.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), pos_i32.data_ptr(), qkv.shape[0], H, hd,
+                                      qkv.stride(0), _st()), "nv_rope_rows_bf16")
+    return qkv
+
+
 def swiglu_fwd(gu, out=None):
     M, ff2 = gu.shape
     if out is None:
@@ -194,6 +201,14 @@ def attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=None, lse2=None, q_row_min=0):
                                _st())
     _lib.check(rc, "nv_attn_fwd_bf16")
     return out, lse2
+
+
+def attn_fwd_strided(qkv, kv_start_i32, B, S, S_stride, H, hd, out, lse2, q_row_min=0):
+    """forward over a KV-cache layout (sample b at rows b*S_stride ..), valid length <= S"""
+    rc = _L().nv_attn_fwd_strided_bf16(qkv.data_ptr(), out.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(), B, S, S_stride, H,
+                                       hd, q_row_min, _st())
+    _lib.check(rc, "nv_attn_fwd_strided_bf16")
+    return out
 
 
 def attn_bwd(qkv, out, dout, lse2, kv_start_i32, B, S, H, hd, dqkv=None, q_row_min=0):

@@ -218,6 +218,47 @@ def lm_forward(P, cfg, input_ids, attention_mask, labels=None, cand_vis=None, hi
     return loss, logits, Hs
 
 
+def greedy_generate(P, cfg, input_ids, attention_mask, cand_vis=None, hist_vis=None, max_new_tokens=20, eos_token_id=2,
+                    pad_token_id=0, trie=None):
+    """`self.lang_model.generate(do_sample=False, ...)` as nav_model.py:324-341,388-402 calls it, restated WITHOUT a
+    K/V cache: every step re-runs `lm_forward` on the whole left-padded batch (quadratic, small cases only).
+    HF greedy bookkeeping (transformers 4.28 `GenerationMixin.greedy_search`): logits of the last position -> logits
+    processors (TrieLogitsProcessor, modified_lm.py:10-30) -> argmax; finished rows emit pad_token_id; a row finishes
+    when it emits eos_token_id; stop when all rows are finished or after max_new_tokens.
+    Parity note: HF's generation path numbers positions per sample (cumsum of the mask) while this recompute numbers them
+    over the padding like the training path does; RoPE depends on differences only, so the two agree up to bf16
+    rounding.  `generate()` itself does not run under the installed transformers, so this function
+    is pinned only through `lm_forward` (fixture G2).  Returns B lists of new tokens."""
+    ids, am = input_ids.clone(), attention_mask.clone()
+    B = ids.shape[0]
+    out = [[] for _ in range(B)]
+    unfinished = [True] * B
+    nodes = [trie.root for _ in range(B)] if trie is not None else None
+    for step in range(max_new_tokens):
+        _, logits, _ = lm_forward(P, cfg, ids, am, cand_vis=cand_vis, hist_vis=hist_vis)
+        lg = logits[:, -1, :].float()
+        if trie is not None:
+            if step > 0:
+                nodes = [trie.get_next_node(nodes[b], int(ids[b, -1])) for b in range(B)]
+            allow = torch.zeros_like(lg, dtype=torch.bool)
+            for b in range(B):
+                allow[b, trie.get_child_index(nodes[b])] = True
+            lg = lg.masked_fill(~allow, float("-inf"))
+        nxt = lg.argmax(-1).tolist()
+        col = []
+        for b in range(B):
+            t = nxt[b] if unfinished[b] else pad_token_id
+            out[b].append(t)
+            col.append(t)
+            if unfinished[b] and t == eos_token_id:
+                unfinished[b] = False
+        ids = torch.cat([ids, torch.tensor(col, dtype=ids.dtype)[:, None]], 1)
+        am = torch.cat([am, torch.ones((B, 1), dtype=am.dtype)], 1)
+        if not any(unfinished):
+            break
+    return out, lg
+
+
 # --------------------------------------------------------------------------- navigation
 def _seq2(x, P, prefix):
     """nn.Sequential(Linear, LayerNorm(1e-12))"""
