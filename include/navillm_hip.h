@@ -90,6 +90,11 @@ int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int*
 size_t nv_attn_bwd_workspace_bytes(int B, int S, int H);
 int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
                      void* workspace, int B, int S, int H, int head_dim, int q_row_min, void* stream);
+/*   the same, with the transpose of RoPE applied to dQ and dK as they are written (bit-identical to nv_attn_bwd_bf16
+ *   followed by nv_rope_bf16(backward=1) on dqkv; rope_cos/rope_sin = that function's tables) */
+int nv_attn_bwd_rope_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
+                          void* workspace, const void* rope_cos, const void* rope_sin, int B, int S, int H, int head_dim,
+                          int q_row_min, void* stream);
 
 /* ---- K10: action / object head Linear(d -> N<=128) in the LM dtype, models/nav_model.py:237,445 */
 int nv_head_fwd_bf16(const void* x, const void* W, const void* bias, void* y, int B, int d, int N, void* stream);

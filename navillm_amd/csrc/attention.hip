@@ -17,6 +17,7 @@
 //  * lse is kept in the log2 domain (lse2 = m2 + log2(l)); fully masked rows store +inf so
 //    the backward's exp2(s2 - lse2) is exactly 0 for them.
 #include "nv_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -77,6 +78,38 @@ __device__ __forceinline__ float grp_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// store one gradient row fragment set (lane: 4 consecutive d per 16-wide tile dt, d = dt*16 + g*4 + r) as bf16, optionally
+// through the transpose of RoPE.  Bit-identical to "round to bf16, then nv_rope_bf16(backward=1)": the partner of
+// d < 64 is d + 64 = tile dt + 4 of the SAME lane.
+__device__ __forceinline__ void store_grad_row(bf16_t* dst, const f32x4 (&v)[8], float scale, const bf16_t* cos_row,
+                                               const bf16_t* sin_row) {
+    if (!cos_row) {
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            u32x2 w = {pack2bf(v[dt][0] * scale, v[dt][1] * scale), pack2bf(v[dt][2] * scale, v[dt][3] * scale)};
+            *(u32x2*)(dst + dt * 16) = w;
+        }
+        return;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const u32x2 cw = *(const u32x2*)(cos_row + dt * 16), sw = *(const u32x2*)(sin_row + dt * 16);
+        const float c[4] = {__uint_as_float(cw[0] << 16), __uint_as_float(cw[0] & 0xffff0000u), __uint_as_float(cw[1] << 16),
+                            __uint_as_float(cw[1] & 0xffff0000u)};
+        const float sn[4] = {__uint_as_float(sw[0] << 16), __uint_as_float(sw[0] & 0xffff0000u), __uint_as_float(sw[1] << 16),
+                             __uint_as_float(sw[1] & 0xffff0000u)};
+        float o1[4], o2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x1 = rbf(v[dt][r] * scale), x2 = rbf(v[dt + 4][r] * scale);
+            o1[r] = rbf(x1 * c[r]) + rbf(x2 * sn[r]);
+            o2[r] = rbf(x2 * c[r]) + rbf(-x1 * sn[r]);
+        }
+        *(u32x2*)(dst + dt * 16) = u32x2{pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3])};
+        *(u32x2*)(dst + (dt + 4) * 16) = u32x2{pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3])};
+    }
+}
+
 struct AttnArgs {
     const bf16_t* qkv; bf16_t* out; float* lse2;        // fwd
     const bf16_t* dout; const float* dsum; bf16_t* dqkv; // bwd
@@ -86,6 +119,7 @@ struct AttnArgs {
     int q_row_min;         // only queries >= q_row_min are computed / differentiated (multiple of 128; 0 = all)
     float scale2;          // head_dim^-0.5 * log2(e)
     float scale;           // head_dim^-0.5
+    const bf16_t* rope_cos; const bf16_t* rope_sin;   // backward only, optional: apply RoPE^T to dQ/dK as they are written
 };
 
 // =========================================================================== forward
@@ -246,7 +280,9 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
 }
 
 // =========================================================================== backward dK, dV
-// grid (ceil(S/64), B*H), 256 threads: wave w owns keys k0 + w*16 .. +15; walks query tiles of 32.
+// grid (ceil(S/(64*KW)), B*H), 256 threads: wave w owns KW key tiles of 16 (keys kblk + (w*KW+jk)*16 ..); walks query
+// tiles of 32.  KW = 2 halves the LDS fragment traffic per MFMA (every Q/dO fragment feeds two key tiles).
+template <int KW>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
@@ -254,10 +290,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int S = p.S, ld = p.ld;
-    const int kblk = blockIdx.x * 64;
+    const int kblk = blockIdx.x * 64 * KW;
     const int kvs = p.kv_start[b];
     const int ki = lane & 15, g = lane >> 4;
-    const int key = kblk + wave * 16 + ki;
     const bf16_t* base = p.qkv + (long)b * S * ld;
     const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
     const u32x4 rq = make_desc(base, span);
@@ -268,20 +303,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     const float* dsum = p.dsum + ((long)b * p.H + h) * S;
 
     // K and V fragments (B operand: j = key, k = head dim) from HBM
-    bf16x8 kf[4], vf[4];
-    {
-        const int kl = key < S ? key : S - 1;
+    bf16x8 kf[KW][4], vf[KW][4];
+    int key[KW];
+#pragma unroll
+    for (int jk = 0; jk < KW; ++jk) {
+        key[jk] = kblk + (wave * KW + jk) * 16 + ki;
+        const int kl = key[jk] < S ? key[jk] : S - 1;
         const bf16_t* kp = base + (long)kl * ld + p.H * HD + h * HD + g * 8;
         const bf16_t* vp = base + (long)kl * ld + 2 * p.H * HD + h * HD + g * 8;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            kf[kk] = *(const bf16x8*)(kp + kk * 32);
-            vf[kk] = *(const bf16x8*)(vp + kk * 32);
+            kf[jk][kk] = *(const bf16x8*)(kp + kk * 32);
+            vf[jk][kk] = *(const bf16x8*)(vp + kk * 32);
         }
     }
-    f32x4 dv[8], dk[8];
+    f32x4 dv[KW][8], dk[KW][8];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int jk = 0; jk < KW; ++jk)
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) { dv[jk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[jk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     // queries that can see this key block: q >= kblk (causal), q >= kvs (pad queries have p=0 anyway)
     const int qt_lo = p.q_row_min / 32;
@@ -290,6 +330,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         stage_rows<32, 256>(rq, smem + buf * 2 * TILE, qt * 32, h * HD, ld, tid);
         stage_rows<32, 256>(rdo, smem + buf * 2 * TILE + TILE, qt * 32, h * HD, od, tid);
     };
+    if (qt_beg <= qt_end) {
     stage(qt_beg, 0);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -299,60 +340,81 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         LDS_PTR(char) sq = smem + cur * 2 * TILE;
         LDS_PTR(char) sdo = sq + TILE;
         // ---- S = Q K^T and dP = dO V^T : lane holds key = lane&15, queries qt*32 + j*16 + g*4 + r
-        f32x4 s[2], dp[2];
+        f32x4 s[KW][2], dp[KW][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { s[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int jk = 0; jk < KW; ++jk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { s[jk][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[jk][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const bf16x8 qa = frag_rm(sq, j * 16, kk, lane);
                 const bf16x8 da = frag_rm(sdo, j * 16, kk, lane);
-                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kk], s[j], 0, 0, 0);
-                dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kk], dp[j], 0, 0, 0);
+#pragma unroll
+                for (int jk = 0; jk < KW; ++jk) {
+                    s[jk][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[jk][kk], s[jk][j], 0, 0, 0);
+                    dp[jk][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[jk][kk], dp[jk][j], 0, 0, 0);
+                }
             }
         }
-        f32x4 pv[2], ds[2];
+        float lq[2][4], dq_[2][4];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int q = qt * 32 + j * 16 + g * 4 + r;
-                const bool ok = (q < S) && (key <= q) && (key >= kvs) && (key < S);
                 const int qc = q < S ? q : S - 1;
-                const float pe = ok ? exp2f(s[j][r] * p.scale2 - lse2[qc]) : 0.f;
-                pv[j][r] = pe;
-                ds[j][r] = pe * (dp[j][r] - dsum[qc]);
+                lq[j][r] = lse2[qc];
+                dq_[j][r] = dsum[qc];
             }
-        const bf16x8 pfrag = pack_frag(pv[0], pv[1]);
-        const bf16x8 dsfrag = pack_frag(ds[0], ds[1]);
+        bf16x8 pfrag[KW], dsfrag[KW];
+#pragma unroll
+        for (int jk = 0; jk < KW; ++jk) {
+            f32x4 pv[2], ds[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qt * 32 + j * 16 + g * 4 + r;
+                    const bool ok = (q < S) && (key[jk] <= q) && (key[jk] >= kvs) && (key[jk] < S);
+                    const float pe = ok ? exp2f(s[jk][j][r] * p.scale2 - lq[j][r]) : 0.f;
+                    pv[j][r] = pe;
+                    ds[j][r] = pe * (dp[jk][j][r] - dq_[j][r]);
+                }
+            pfrag[jk] = pack_frag(pv[0], pv[1]);
+            dsfrag[jk] = pack_frag(ds[0], ds[1]);
+        }
         // ---- dV^T += dO^T P ; dK^T += Q^T dS   (k = the 32 queries, permuted as pack_frag lays them)
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
             const bf16x8 dot_ = frag_tr(sdo, 0, 16, dt * 16, lane);
             const bf16x8 qt_ = frag_tr(sq, 0, 16, dt * 16, lane);
-            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_, pfrag, dv[dt], 0, 0, 0);
-            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsfrag, dk[dt], 0, 0, 0);
+#pragma unroll
+            for (int jk = 0; jk < KW; ++jk) {
+                dv[jk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_, pfrag[jk], dv[jk][dt], 0, 0, 0);
+                dk[jk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsfrag[jk], dk[jk][dt], 0, 0, 0);
+            }
         }
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         cur ^= 1;
     }
-    if (key < S) {
-        bf16_t* kp = p.dqkv + ((long)b * S + key) * ld + p.H * HD + h * HD + g * 4;
-        bf16_t* vp = p.dqkv + ((long)b * S + key) * ld + 2 * p.H * HD + h * HD + g * 4;
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            u32x2 wk = {pack2bf(dk[dt][0] * p.scale, dk[dt][1] * p.scale), pack2bf(dk[dt][2] * p.scale, dk[dt][3] * p.scale)};
-            u32x2 wv = {pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3])};
-            *(u32x2*)(kp + dt * 16) = wk;
-            *(u32x2*)(vp + dt * 16) = wv;
-        }
     }
+#pragma unroll
+    for (int jk = 0; jk < KW; ++jk)
+        if (key[jk] < S) {
+            bf16_t* kp = p.dqkv + ((long)b * S + key[jk]) * ld + p.H * HD + h * HD + g * 4;
+            bf16_t* vp = p.dqkv + ((long)b * S + key[jk]) * ld + 2 * p.H * HD + h * HD + g * 4;
+            store_grad_row(kp, dk[jk], p.scale, p.rope_cos ? p.rope_cos + (long)key[jk] * HD + g * 4 : nullptr,
+                           p.rope_sin ? p.rope_sin + (long)key[jk] * HD + g * 4 : nullptr);
+            store_grad_row(vp, dv[jk], 1.f, nullptr, nullptr);
+        }
 }
 
 // =========================================================================== backward dQ
-// grid (ceil(S/64), B*H), 256 threads: wave w owns queries q0 + w*16 .. +15; walks key tiles of 64.
+// grid (ceil((S-q_row_min)/(64*QW)), B*H), 256 threads: wave w owns QW query tiles of 16; walks key tiles of 64.
+template <int QW>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
@@ -360,34 +422,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
     const int S = p.S, ld = p.ld;
-    const int q0 = p.q_row_min + blockIdx.x * 64;
+    const int q0 = p.q_row_min + blockIdx.x * 64 * QW;
     const int kvs = p.kv_start[b];
     const int qi = lane & 15, g = lane >> 4;
-    const int q = q0 + wave * 16 + qi;
-    const int ql = q < S ? q : S - 1;
     const bf16_t* base = p.qkv + (long)b * S * ld;
     const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
     const u32x4 rs = make_desc(base, span);
     const int od = p.H * HD;
     const int kcol = p.H * HD + h * HD, vcol = 2 * p.H * HD + h * HD;
 
-    bf16x8 qf[4], dof[4];
-    {
+    bf16x8 qf[QW][4], dof[QW][4];
+    int q[QW];
+    float my_lse[QW], my_ds[QW];
+#pragma unroll
+    for (int j = 0; j < QW; ++j) {
+        q[j] = q0 + (wave * QW + j) * 16 + qi;
+        const int ql = q[j] < S ? q[j] : S - 1;
         const bf16_t* qp = base + (long)ql * ld + h * HD + g * 8;
         const bf16_t* dp_ = p.dout + ((long)b * S + ql) * od + h * HD + g * 8;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            qf[kk] = *(const bf16x8*)(qp + kk * 32);
-            dof[kk] = *(const bf16x8*)(dp_ + kk * 32);
+            qf[j][kk] = *(const bf16x8*)(qp + kk * 32);
+            dof[j][kk] = *(const bf16x8*)(dp_ + kk * 32);
         }
+        my_lse[j] = p.lse2[((long)b * p.H + h) * S + ql];
+        my_ds[j] = p.dsum[((long)b * p.H + h) * S + ql];
     }
-    const float my_lse = p.lse2[((long)b * p.H + h) * S + ql];
-    const float my_ds = p.dsum[((long)b * p.H + h) * S + ql];
-    f32x4 dq[8];
+    f32x4 dq[QW][8];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < QW; ++j)
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) dq[j][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int q_hi = (q0 + 63 < S - 1) ? q0 + 63 : S - 1;
+    const int q_hi = (q0 + 64 * QW - 1 < S - 1) ? q0 + 64 * QW - 1 : S - 1;
     const int kt_beg = kvs / 64, kt_end = q_hi / 64;
     if (kt_beg <= kt_end) {
         auto stage = [&](int kt, int buf) {
@@ -402,35 +469,45 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
             if (kt < kt_end) stage(kt + 1, cur ^ 1);
             LDS_PTR(char) sk = smem + cur * 2 * TILE;
             LDS_PTR(char) sv = sk + TILE;
-            f32x4 s[4], dp[4];
+            f32x4 s[4][QW], dp[4][QW];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { s[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < QW; ++j) { s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const bf16x8 ka = frag_rm(sk, i * 16, kk, lane);
                     const bf16x8 va = frag_rm(sv, i * 16, kk, lane);
-                    s[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[kk], s[i], 0, 0, 0);
-                    dp[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[kk], dp[i], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < QW; ++j) {
+                        s[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[j][kk], s[i][j], 0, 0, 0);
+                        dp[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[j][kk], dp[i][j], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < QW; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt * 64 + i * 16 + g * 4 + r;
-                    const bool ok = (q < S) && (key <= q) && (key >= kvs);
-                    const float pe = ok ? exp2f(s[i][r] * p.scale2 - my_lse) : 0.f;
-                    s[i][r] = pe * (dp[i][r] - my_ds);   // dS^T
-                }
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 64 + i * 16 + g * 4 + r;
+                        const bool ok = (q[j] < S) && (key <= q[j]) && (key >= kvs);
+                        const float pe = ok ? exp2f(s[i][j][r] * p.scale2 - my_lse[j]) : 0.f;
+                        s[i][j][r] = pe * (dp[i][j][r] - my_ds[j]);   // dS^T
+                    }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
-                const bf16x8 dsf = pack_frag(s[2 * a], s[2 * a + 1]);
+                bf16x8 dsf[QW];
+#pragma unroll
+                for (int j = 0; j < QW; ++j) dsf[j] = pack_frag(s[2 * a][j], s[2 * a + 1][j]);
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) {
                     const bf16x8 kt_ = frag_tr(sk, a * 32, a * 32 + 16, dt * 16, lane);
-                    dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsf, dq[dt], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < QW; ++j) dq[j][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsf[j], dq[j][dt], 0, 0, 0);
                 }
             }
             wait_vmcnt<0>();
@@ -438,14 +515,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
             cur ^= 1;
         }
     }
-    if (q < S) {
-        bf16_t* qp = p.dqkv + ((long)b * S + q) * ld + h * HD + g * 4;
 #pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-            u32x2 w = {pack2bf(dq[dt][0] * p.scale, dq[dt][1] * p.scale), pack2bf(dq[dt][2] * p.scale, dq[dt][3] * p.scale)};
-            *(u32x2*)(qp + dt * 16) = w;
+    for (int j = 0; j < QW; ++j)
+        if (q[j] < S) {
+            bf16_t* qp = p.dqkv + ((long)b * S + q[j]) * ld + h * HD + g * 4;
+            store_grad_row(qp, dq[j], p.scale, p.rope_cos ? p.rope_cos + (long)q[j] * HD + g * 4 : nullptr,
+                           p.rope_sin ? p.rope_sin + (long)q[j] * HD + g * 4 : nullptr);
         }
-    }
 }
 
 int set_lds(const void* fn, int bytes) {
@@ -491,14 +567,22 @@ int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int*
 // dsum: workspace [B,H,S] fp32 (nv_attn_bwd_workspace_bytes)
 size_t nv_attn_bwd_workspace_bytes(int B, int S, int H) { return (size_t)B * S * H * sizeof(float); }
 
-int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
-                     void* workspace, int B, int S, int H, int head_dim, int q_row_min, void* stream) {
+static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
+                         void* workspace, int B, int S, int H, int head_dim, int q_row_min, const void* rope_cos,
+                         const void* rope_sin, void* stream) {
     if (!qkv || !out || !dout || !lse2 || !kv_start || !dqkv || !workspace) return NV_ERR_ARG;
     if (head_dim != HD || (q_row_min & 127) || q_row_min < 0 || (S > 0 && q_row_min >= S)) return NV_ERR_SHAPE;
+    if ((rope_cos == nullptr) != (rope_sin == nullptr)) return NV_ERR_ARG;
     if (B == 0 || S == 0) return NV_OK;
+    // measurement/test knob: 1 (default) = 16 rows per wave, 2 = 32 rows per wave.  Measured at B=8, S=656, H=32: the
+    // 32-row form halves the LDS fragment reads per MFMA but runs 539 vs 344 us -- with one barrier-synchronised tile
+    // step per iteration these kernels live on occupancy, which the wider form halves.
+    const char* ev = getenv("NV_ATTN_BWD_VARIANT");
+    const int variant = ev ? atoi(ev) : 1;
     static bool once = false;
     if (!once) {
-        if (set_lds((const void*)attn_bwd_dkv_kernel, 32768) || set_lds((const void*)attn_bwd_dq_kernel, 65536))
+        if (set_lds((const void*)attn_bwd_dkv_kernel<1>, 32768) || set_lds((const void*)attn_bwd_dq_kernel<1>, 65536) ||
+            set_lds((const void*)attn_bwd_dkv_kernel<2>, 32768) || set_lds((const void*)attn_bwd_dq_kernel<2>, 65536))
             return NV_ERR_LAUNCH;
         once = true;
     }
@@ -511,11 +595,31 @@ int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const f
     p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.lse2 = (float*)lse2; p.dsum = dsum; p.dqkv = (bf16_t*)dqkv;
     p.kv_start = kv_start; p.B = B; p.S = S; p.Sst = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
+    p.rope_cos = (const bf16_t*)rope_cos; p.rope_sin = (const bf16_t*)rope_sin;
     // with q_row_min > 0 only those query rows carry gradient: dK/dV still cover every key, dQ rows below
     // q_row_min are NOT written (the caller zero-fills them)
-    NV_LAUNCH(attn_bwd_dkv_kernel, dim3((S + 63) / 64, B * H), dim3(256), 32768, st, p);
-    NV_LAUNCH(attn_bwd_dq_kernel, dim3((S - q_row_min + 63) / 64, B * H), dim3(256), 65536, st, p);
+    if (variant == 1) {
+        NV_LAUNCH(attn_bwd_dkv_kernel<1>, dim3((S + 63) / 64, B * H), dim3(256), 32768, st, p);
+        NV_LAUNCH(attn_bwd_dq_kernel<1>, dim3((S - q_row_min + 63) / 64, B * H), dim3(256), 65536, st, p);
+    } else {
+        NV_LAUNCH(attn_bwd_dkv_kernel<2>, dim3((S + 127) / 128, B * H), dim3(256), 32768, st, p);
+        NV_LAUNCH(attn_bwd_dq_kernel<2>, dim3((S - q_row_min + 127) / 128, B * H), dim3(256), 65536, st, p);
+    }
     return nv_check_launch();
+}
+
+int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
+                     void* workspace, int B, int S, int H, int head_dim, int q_row_min, void* stream) {
+    return attn_bwd_impl(qkv, out, dout, lse2, kv_start, dqkv, workspace, B, S, H, head_dim, q_row_min, nullptr, nullptr, stream);
+}
+
+// The same with the transpose of RoPE applied to dQ and dK as they are written (cos/sin: the [maxS, 128] bf16 tables of
+// nv_rope_bf16; position of a row = its index within the sample): saves the separate in-place pass over dqkv.
+int nv_attn_bwd_rope_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
+                          void* workspace, const void* rope_cos, const void* rope_sin, int B, int S, int H, int head_dim,
+                          int q_row_min, void* stream) {
+    if (!rope_cos || !rope_sin) return NV_ERR_ARG;
+    return attn_bwd_impl(qkv, out, dout, lse2, kv_start, dqkv, workspace, B, S, H, head_dim, q_row_min, rope_cos, rope_sin, stream);
 }
 
 }  // extern "C"

@@ -397,8 +397,7 @@ class LlamaStack(torch.autograd.Function):
             ops.scatter_rows_bf16_(dattn_r, rows, dattn)
             dqkv = sc["dqkv"]
             dqkv.zero_()                       # dQ rows below qmin are not written by the kernel
-            ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd, dqkv=dqkv, q_row_min=qmin)
-            ops.rope_(dqkv, model.rope_cos, model.rope_sin, S, H, hd, backward=True)
+            ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd, dqkv=dqkv, q_row_min=qmin, rope=(model.rope_cos, model.rope_sin))
             dn1 = ops.gemm_bf16(ops.NN, dqkv, st.qkv(i), out=sc["dn1"])
             ops.gemm_bf16(ops.TN, dqkv, n1, out=st.qkv(i, grad=True), epilogue=ops.EPI_ACCUM)
             resid = sc["dx1"]
@@ -462,8 +461,7 @@ class LlamaStack(torch.autograd.Function):
             dattn = ops.gemm_bf16(ops.NN, dx1, Wo, out=sc["dattn"])
             ev.append(wgrad("dx1", dx1, attn, st.g(p + "self_attn.o_proj.weight")))
             before_write("dqkv")
-            dqkv = ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd, dqkv=sc["dqkv"])
-            ops.rope_(dqkv, model.rope_cos, model.rope_sin, S, H, hd, backward=True)
+            dqkv = ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd, dqkv=sc["dqkv"], rope=(model.rope_cos, model.rope_sin))
             dn1 = ops.gemm_bf16(ops.NN, dqkv, st.qkv(i), out=sc["dn1"])
             ev.append(wgrad("dqkv", dqkv, n1, st.qkv(i, grad=True)))
             before_write(nxt_name)

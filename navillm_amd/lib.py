@@ -35,6 +35,7 @@ SIGNATURES = {
     "nv_attn_fwd_strided_bf16": (i, [vp, vp, fp, ip, i, i, i, i, i, i, vp]),
     "nv_attn_bwd_workspace_bytes": (sz, [i, i, i]),
     "nv_attn_bwd_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, i, vp]),
+    "nv_attn_bwd_rope_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, vp, vp, i, i, i, i, i, vp]),
     "nv_head_fwd_bf16": (i, [vp, vp, vp, vp, i, i, i, vp]),
     "nv_head_bwd_bf16": (i, [vp, vp, vp, vp, vp, vp, i, i, i, vp]),
     "nv_action_ce_bf16": (i, [vp, lp, fp, vp, i, i, f, fp, vp]),

@@ -211,12 +211,18 @@ def attn_fwd_strided(qkv, kv_start_i32, B, S, S_stride, H, hd, out, lse2, q_row_
     return out
 
 
-def attn_bwd(qkv, out, dout, lse2, kv_start_i32, B, S, H, hd, dqkv=None, q_row_min=0):
+def attn_bwd(qkv, out, dout, lse2, kv_start_i32, B, S, H, hd, dqkv=None, q_row_min=0, rope=None):
+    """rope=(cos_t, sin_t): dQ/dK leave the kernel already rotated back (RoPE^T fused into the final store)."""
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
     ws = _workspace(_L().nv_attn_bwd_workspace_bytes(B, S, H), qkv.device, "attn")
-    rc = _L().nv_attn_bwd_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(),
-                               dqkv.data_ptr(), ws.data_ptr(), B, S, H, hd, q_row_min, _st())
+    if rope is None:
+        rc = _L().nv_attn_bwd_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(),
+                                   dqkv.data_ptr(), ws.data_ptr(), B, S, H, hd, q_row_min, _st())
+    else:
+        rc = _L().nv_attn_bwd_rope_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(),
+                                        dqkv.data_ptr(), ws.data_ptr(), rope[0].data_ptr(), rope[1].data_ptr(), B, S, H, hd,
+                                        q_row_min, _st())
     _lib.check(rc, "nv_attn_bwd_bf16")
     return dqkv
 

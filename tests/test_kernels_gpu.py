@@ -238,9 +238,11 @@ def _attn_ref(qkv, B, S, H, hd, kv_start):
     return o, ok
 
 
+@pytest.mark.parametrize("variant", ["1", "2"])
 @pytest.mark.parametrize("B,S,H,pads", [(2, 200, 2, [0, 37]), (1, 64, 1, [0]), (3, 333, 2, [5, 130, 0]), (2, 700, 4, [0, 64])])
-def test_attention_fwd_bwd(B, S, H, pads):
+def test_attention_fwd_bwd(B, S, H, pads, variant, monkeypatch):
     from navillm_amd import ops
+    monkeypatch.setenv("NV_ATTN_BWD_VARIANT", variant)     # 1 = 16 rows per wave (default), 2 = 32 rows per wave
     hd = 128
     qkv = rnd(B * S, 3 * H * hd, dtype=BF, seed=60, scale=1.0)
     kvs = torch.tensor(pads, dtype=torch.int32, device=dev())
@@ -265,6 +267,15 @@ def test_attention_fwd_bwd(B, S, H, pads):
         assert torch.isfinite(got).all() and rel < 2e-2, f"attn {name}: rel err {rel.item():.4e}"
     # pad rows receive no gradient
     assert bool((dqkv[~real].float().abs().max() == 0) if (~real).any() else True)
+    # RoPE^T fused into the final store == the separate in-place pass, bit for bit
+    pos = torch.arange(S, device=dev(), dtype=torch.float32)
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev(), dtype=torch.float32) / hd))
+    emb = torch.cat([torch.outer(pos, inv)] * 2, -1)
+    cos_t, sin_t = emb.cos().to(BF).contiguous(), emb.sin().to(BF).contiguous()
+    fused = ops.attn_bwd(qkv, out, dout, lse2, kvs, B, S, H, hd, rope=(cos_t, sin_t))
+    ops.rope_(dqkv, cos_t, sin_t, S, H, hd, backward=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.view(torch.int16), dqkv.view(torch.int16)), "fused RoPE^T differs from attn_bwd + rope"
 
 
 # ------------------------------------------------------------------------------ heads / losses / optimizer
