@@ -39,6 +39,7 @@ struct GemmArgs {
     float* slabs;           // [rem*split][BM*BN] fp32 partials
     unsigned* counters;     // [rem] arrival tickets, zero between launches
     int debug;              // NV_GEMM_DEBUG (measurement only): bit0 skip the C stores, bit1 skip the K loop
+    int items, persist;     // work items of the launch (tiles + tail K-slices); persistent-block mode on/off
 };
 
 // ---- LDS images (BKT = K extent of a stage, 64 or 32) -----------------------------------
@@ -200,19 +201,22 @@ __device__ __forceinline__ void wait_tiles(int tiles) {
     else wait_vmcnt<0>();
 }
 
+// One work item (an output tile, or one K-slice of a tail tile) of the GEMM.  `first` = this block's first item: later
+// items of a persistent block start with the previous tile's C stores still in flight (see the kernel below).
 template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE>
-__global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(1, ((NSTAGE * (BM + BN) * BKT * 2 > 80 * 1024) ? 1 : 2) * (WGM * WGN) / 4)))
-void gemm_bf16_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, const bool first, LDS_PTR(char) smem) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2;
     constexpr int LOADS = (A_BYTES + B_BYTES) / (NT * 16);     // buffer_load...lds per thread per stage
     static_assert(3 * LOADS < 64, "vmcnt immediate range");
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // opaque per tile: otherwise hipcc hoists every lane-dependent address of the prologue/epilogue out of the persistent
+    // tile loop, cannot keep them next to the 128 accumulators and spills them (+6 % kernel time measured)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
     // Tile order: each XCD (block b runs on XCD b%8) gets a contiguous chunk of a GROUPED order in which
@@ -221,7 +225,7 @@ void gemm_bf16_kernel(GemmArgs p) {
     // that XCD's 4 MiB L2 (measured: strip order = 49% L2 hit rate on the forward GEMM).
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    int tile_b = blockIdx.x, ks = 0, nsplit = 1, tail_u = 0;
+    int tile_b = item, ks = 0, nsplit = 1, tail_u = 0;
     if (tile_b >= p.full_blocks) {           // uniform per block
         const int q = tile_b - p.full_blocks;
         ks = q / p.rem;
@@ -317,7 +321,9 @@ void gemm_bf16_kernel(GemmArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
         };
         stage(0, 0);
-        if (KT > 1) { stage(1, 1); wait_vmcnt<LOADS>(); } else { wait_vmcnt<0>(); }
+        // counted wait only while nothing but DMA is in flight: a persistent block's later tiles still have the previous
+        // tile's C stores outstanding, and loads/stores do not retire in order relative to each other
+        if (KT > 1) { stage(1, 1); if (first) wait_vmcnt<LOADS>(); else wait_vmcnt<0>(); } else { wait_vmcnt<0>(); }
         __builtin_amdgcn_s_barrier();
         ldfr(0, 0, fa0, fb0);
         if constexpr (PIPE == 4) {
@@ -568,6 +574,23 @@ void gemm_bf16_kernel(GemmArgs p) {
     }
 }
 
+// Optional persistent form (NV_GEMM_PERSIST=1; off by default): the grid is at most one block per CU and each block walks
+// its work items (item, item + grid, ...; 256 % 8 == 0, so an item keeps the XCD its id implies); the C stores of tile i
+// drain while the first K-tiles of tile i+1 are already on their way into LDS.  Measured on MI355X: identical to the
+// hardware dispatcher placing one block per tile (1306 vs 1306 TFLOP/s at 5152x12288x4096) -- the ~10 us per round
+// of tiles that is not K-loop is prologue/epilogue latency inside the tile, not dispatch or store drain.
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE>
+__global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(1, ((NSTAGE * (BM + BN) * BKT * 2 > 80 * 1024) ? 1 : 2) * (WGM * WGN) / 4)))
+void gemm_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
+    for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
+        const bool first = item == (int)blockIdx.x;
+        if (!first) __syncthreads();          // every wave is done with the LDS image of the previous tile's C
+        gemm_tile<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI, PIPE>(p, item, first, smem);
+    }
+}
+
 template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE = 0>
 int launch(const GemmArgs& p, hipStream_t st) {
     constexpr int LDS = NSTAGE * (BM + BN) * BKT * 2;
@@ -594,7 +617,9 @@ int launch(const GemmArgs& p, hipStream_t st) {
             if (split >= 2) { q.full_blocks = tiles - rem; q.rem = rem; q.split = split; }
         }
     }
-    const int grid = q.full_blocks + (q.split > 1 ? q.rem * q.split : 0);
+    q.items = q.full_blocks + (q.split > 1 ? q.rem * q.split : 0);
+    // persistent blocks for the interleaved kernel (its prologue/epilogue are the per-tile fixed cost worth hiding)
+    const int grid = (PIPE == 4 && p.persist && q.items > CUS) ? CUS : q.items;
     NV_LAUNCH(kern, dim3(grid), dim3(WGM * WGN * 64), LDS, st, q);
     return nv_check_launch();
 }
@@ -665,7 +690,9 @@ extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C
         static const int env_debug = [] { const char* e = getenv("NV_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
         static const int env_group = [] { const char* e = getenv("NV_GEMM_GROUP_M"); return e ? atoi(e) : 4; }();   // 4 x 8 patch per XCD
         static const int env_order = [] { const char* e = getenv("NV_GEMM_ORDER"); return e ? atoi(e) : -1; }();    // 0 rows, 1 column strips
+        static const int env_persist = [] { const char* e = getenv("NV_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
         p.debug = env_debug;
+        p.persist = env_persist;
         p.group_m = env_group < 1 ? 1 : env_group;
         // default: partition the LARGER operand across the 8 XCD L2s (read once), replicate the smaller one
         p.col_strips = env_order >= 0 ? env_order : ((long)N > (long)M ? 1 : 0);
