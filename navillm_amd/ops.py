@@ -17,8 +17,20 @@ def _L():
     return _lib.load()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_dev_idx = None
+
+
 def _st():
-    return torch.cuda.current_stream().cuda_stream
+    """raw hipStream_t of torch's current stream.  `torch.cuda.current_stream()` costs ~13 us of Python per call (it was
+    a third of the host time of a cached-inference step); the C accessor is ~0.2 us.  One process drives one GPU
+    (parallel.py), so the device index is resolved once."""
+    global _dev_idx
+    if _raw_stream is None:
+        return torch.cuda.current_stream().cuda_stream
+    if _dev_idx is None:
+        _dev_idx = torch.cuda.current_device()
+    return _raw_stream(_dev_idx)
 
 
 def _p(t):
@@ -77,7 +89,7 @@ _gemm_ws_cache = {}
 
 def _gemm_ws(device):
     """zero-initialised split-K workspace, one per (device, stream)"""
-    key = (str(device), torch.cuda.current_stream().cuda_stream)
+    key = _st()
     t = _gemm_ws_cache.get(key)
     if t is None:
         t = torch.zeros((_L().nv_gemm_bf16_workspace_bytes(),), dtype=torch.uint8, device=device)
