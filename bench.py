@@ -162,7 +162,14 @@ def main():
     model.train()
     model.reserve_activations(a.batch, a.instr_len + 256)
     opt = FlatAdamW(model, lr=a.lr)
-    wrapped = NavDataParallel(model) if world > 1 else model
+    if world == 1 and os.environ.get("NAVILLM_DP_FORCE"):
+        # single-GPU rehearsal of the N > 1 path: a one-rank RCCL group, every gradient slice all-reduced from inside the
+        # backward exactly as with 8 ranks (the numbers are then NOT comparable with the plain N = 1 line)
+        if os.environ.get("NAVILLM_COMM") != "rccl":
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", world_size=1, rank=0, device_id=device)
+        wrapped = NavDataParallel(model, force_sync=True)
+    else:
+        wrapped = NavDataParallel(model) if world > 1 else model
     crit = CrossEntropyLoss()
     ep = SyntheticEpisodes(cfg, a.batch, seed=seed, instr_len=a.instr_len, device=device)
     timer = GemmTimer()
@@ -273,6 +280,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

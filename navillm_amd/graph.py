@@ -111,13 +111,21 @@ class GraphMap:
 
     def update_node_embed(self, vp, embed, rewrite=False):
         if rewrite or vp not in self.node_embeds:
-            self.node_embeds[vp] = [embed, 1]
+            self.node_embeds[vp] = [embed, 1, embed]          # running sum, count, cached mean
         else:
-            self.node_embeds[vp][0] = self.node_embeds[vp][0] + embed
-            self.node_embeds[vp][1] += 1
+            e = self.node_embeds[vp]
+            e[0] = e[0] + embed
+            e[1] += 1
+            e[2] = None
 
     def get_node_embed(self, vp):
-        return self.node_embeds[vp][0] / self.node_embeds[vp][1]
+        """sum / count (graph_utils.py:137-142).  The mean is cached until the node is updated again: the reference
+        re-divides every node on every step, which on a device tensor is one tiny kernel launch per node per step
+        (432 launches per 8-episode step here); the cached value is bit-identical."""
+        e = self.node_embeds[vp]
+        if e[2] is None:
+            e[2] = e[0] / e[1]
+        return e[2]
 
     def get_pos_fts(self, cur_vp, gmap_vpids, cur_heading, cur_elevation, angle_feat_size=4):
         n = len(gmap_vpids)

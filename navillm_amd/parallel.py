@@ -122,13 +122,14 @@ class GradSlices:
 
 
 class NavDataParallel(torch.nn.Module):
-    def __init__(self, module, group=None, overlap=True, comm=None):
+    def __init__(self, module, group=None, overlap=True, comm=None, force_sync=False):
         super().__init__()
         self.module = module
         self.group = group
         if comm is None and os.environ.get("NAVILLM_COMM") == "rccl" and module.store.device.type == "cuda":
             _, rank, world = world_info_from_env()
             comm = RcclComm(rank, world)
+        self.force_sync = force_sync     # run the exchange even in a world of one (single-GPU test of the stream/event wiring)
         self.comm = comm                 # None: torch.distributed (RCCL through ProcessGroupNCCL); else the C-ABI communicator
         self.overlap = overlap
         self.require_sync = True
@@ -178,7 +179,7 @@ class NavDataParallel(torch.nn.Module):
             _allreduce_mean_(t, self.group)
 
     def _active(self):
-        return self.require_sync and self._world() > 1
+        return self.require_sync and (self._world() > 1 or self.force_sync)
 
     def on_backward_begin(self):
         if not self._active() or self._queued:
