@@ -24,11 +24,11 @@
 
 namespace {
 
-enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_RESID = 2, EPI_BIAS = 3 };
+enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_RESID = 2, EPI_BIAS = 3, EPI_SWIGLU_BWD = 4 };
 
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; bf16_t* C;
-    const bf16_t* R;        // EPI_RESID: residual [M,N] (ldr) ; EPI_BIAS: bias[N]
+    const bf16_t* R;        // EPI_RESID: residual [M,N] (ldr) ; EPI_BIAS: bias[N] ; EPI_SWIGLU_BWD: gate|up [M,2N] (ldr)
     int M, N, K;
     int lda, ldb, ldc, ldr;
     uint32_t a_bytes, b_bytes;
@@ -199,6 +199,14 @@ __device__ __forceinline__ void wait_tiles(int tiles) {
     else if (MAXT >= 2 && tiles == 2) wait_vmcnt<2 * LOADS>();
     else if (MAXT >= 1 && tiles == 1) wait_vmcnt<LOADS>();
     else wait_vmcnt<0>();
+}
+
+// SwiGLU backward on one element (the arithmetic and rounding points of swiglu_bwd_kernel, lm_rowops.hip):
+// dh arrives rounded to bf16, like the materialised dh tensor it replaces.
+__device__ __forceinline__ void swiglu_bwd_elem(float dh, float g, float u, float& dg, float& du) {
+    const float sg = 1.f / (1.f + expf(-g));
+    du = dh * rbf(g * sg);
+    dg = rbf(dh * u) * (sg * (1.f + g * (1.f - sg)));
 }
 
 // One work item (an output tile, or one K-slice of a tail tile) of the GEMM.  `first` = this block's first item: later
@@ -505,7 +513,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     // and the 16-B row reads).  Needs 16-B aligned rows; anything else takes the element-wise path below.
     static_assert(BM * BN * 2 <= NSTAGE * (BM + BN) * BKT * 2, "C tile image must fit in the stage buffers");
     const bool staged = ((p.ldc & 7) == 0) && ((p.N & 7) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
-                        (EPI != EPI_RESID || (((p.ldr & 7) == 0) && ((((uintptr_t)p.R) & 15) == 0))) &&
+                        ((EPI != EPI_RESID && EPI != EPI_SWIGLU_BWD) || (((p.ldr & 7) == 0) && ((((uintptr_t)p.R) & 15) == 0))) &&
                         (EPI != EPI_BIAS || ((((uintptr_t)p.R) & 7) == 0));
     if (staged) {
         __syncthreads();                                  // every wave is done with the operand stages
@@ -547,6 +555,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
                         t[q] = pack2bf(__uint_as_float(rr[q] << 16) + __uint_as_float(t[q] << 16),
                                        __uint_as_float(rr[q] & 0xffff0000u) + __uint_as_float(t[q] & 0xffff0000u));
                 }
+                if (EPI == EPI_SWIGLU_BWD) {
+                    // C = d(gate|up) [M, 2N]: the tile's dh never goes to HBM; gate/up come in 16 B per lane like a residual
+                    const bf16_t* gp = p.R + (long)m * p.ldr + n;
+                    const u32x4 gg = *(const u32x4*)gp, uu = *(const u32x4*)(gp + p.N);
+                    u32x4 og, ou;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float dg0, du0, dg1, du1;
+                        swiglu_bwd_elem(__uint_as_float(t[q] << 16), __uint_as_float(gg[q] << 16), __uint_as_float(uu[q] << 16), dg0, du0);
+                        swiglu_bwd_elem(__uint_as_float(t[q] & 0xffff0000u), __uint_as_float(gg[q] & 0xffff0000u),
+                                        __uint_as_float(uu[q] & 0xffff0000u), dg1, du1);
+                        og[q] = pack2bf(dg0, dg1);
+                        ou[q] = pack2bf(du0, du1);
+                    }
+                    *(u32x4*)cp = og;
+                    *(u32x4*)(cp + p.N) = ou;
+                    continue;
+                }
                 *(u32x4*)cp = t;
             }
         }
@@ -568,6 +594,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
                 if (EPI == EPI_BIAS) v[r] += bf2f(p.R[n + r]);
                 else if (EPI == EPI_ACCUM) v[r] = bf2f(cp[r]) + rbf(v[r]);   // torch: grad += bf16(dW)
                 else if (EPI == EPI_RESID) v[r] = bf2f(p.R[(long)m * p.ldr + n + r]) + rbf(v[r]);
+                else if (EPI == EPI_SWIGLU_BWD) {
+                    float dg, du;
+                    swiglu_bwd_elem(rbf(v[r]), bf2f(p.R[(long)m * p.ldr + n + r]), bf2f(p.R[(long)m * p.ldr + p.N + n + r]), dg, du);
+                    cp[r] = f2bf(dg);
+                    cp[p.N + r] = f2bf(du);
+                    continue;
+                }
                 cp[r] = f2bf(v[r]);
             }
         }
@@ -638,8 +671,8 @@ int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
     }
     switch (tile_cfg) {
         case 1: return launch<128, 128, 2, 2, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
-        case 3: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
-        case 6: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 1>(p, st);   // software-pipelined fragments
+        case 3: if constexpr (EPI != EPI_SWIGLU_BWD) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st); else return NV_ERR_ARG;
+        case 6: if constexpr (EPI != EPI_SWIGLU_BWD) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 1>(p, st); else return NV_ERR_ARG;   // software-pipelined fragments
         case 8: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4>(p, st);   // hand-interleaved phases
     }
     return NV_ERR_ARG;
@@ -652,6 +685,12 @@ int dispatch_epi(const GemmArgs& p, int epi, int tile_cfg, hipStream_t st) {
         case EPI_ACCUM: return dispatch_tile<A_KMAJ, B_KMAJ, EPI_ACCUM>(p, tile_cfg, st);
         case EPI_RESID: return dispatch_tile<A_KMAJ, B_KMAJ, EPI_RESID>(p, tile_cfg, st);
         case EPI_BIAS: return dispatch_tile<A_KMAJ, B_KMAJ, EPI_BIAS>(p, tile_cfg, st);
+        case EPI_SWIGLU_BWD:      // only the down-proj dgrad uses it: NN layout, production tiles
+            if constexpr (A_KMAJ && !B_KMAJ) {
+                if (tile_cfg == 3 || tile_cfg == 6) return NV_ERR_ARG;
+                return dispatch_tile<A_KMAJ, B_KMAJ, EPI_SWIGLU_BWD>(p, tile_cfg, st);
+            }
+            return NV_ERR_ARG;
     }
     return NV_ERR_ARG;
 }
@@ -676,7 +715,7 @@ extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C
                                void* stream) {
     if (!A || !B || !C || M < 0 || N < 0 || K < 0) return NV_ERR_ARG;
     if (M == 0 || N == 0) return NV_OK;
-    if ((epilogue == EPI_RESID || epilogue == EPI_BIAS) && !R) return NV_ERR_ARG;
+    if ((epilogue == EPI_RESID || epilogue == EPI_BIAS || epilogue == EPI_SWIGLU_BWD) && !R) return NV_ERR_ARG;
     if ((lda & 7) || (ldb & 7)) return NV_ERR_SHAPE;                 // 16-B aligned rows for the DMA
     if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return NV_ERR_SHAPE;
     GemmArgs p;

@@ -1,10 +1,17 @@
 """torch.autograd glue over the HIP ops: autograd is used only as the tape that connects the
 stages (scene encoder -> fusion -> LM -> head -> loss); every forward and backward body is a
 sequence of libnavillm_hip.so launches (navillm_amd/ops.py)."""
+import os
+
 import torch
 from . import ops
 
 F32, BF16 = torch.float32, torch.bfloat16
+# A/B knob: 1 = apply SwiGLU' in the down-proj dgrad GEMM's epilogue (dh never reaches HBM) instead of materialising dh and
+# running the separate row kernel.  Measured on MI355X (bench.py, same box, 2x each): fused 38.25/38.43 vs separate
+# 38.71/38.82 nav-steps/s -- the epilogue's exp/divide work is serialised behind each tile's K loop with the CU's MFMA
+# idle, while the separate HBM-bound kernel hides next to the wgrad GEMM of the other stream.  Off by default.
+FUSE_SWIGLU_BWD = os.environ.get("NAVILLM_FUSE_SWIGLU_BWD", "0") == "1"
 
 
 def _c(t):
@@ -449,10 +456,16 @@ class LlamaStack(torch.autograd.Function):
             n1, qkv, attn, x1, n2, gu, h = (a[k][:M] for k in ("n1", "qkv", "attn", "x1", "n2", "gu", "h"))
             lse = a["lse"][:M * H].view(B, H, S)
             Wd, Wo = st.p(p + "mlp.down_proj.weight"), st.p(p + "self_attn.o_proj.weight")
-            dh = ops.gemm_bf16(ops.NN, dx, Wd, out=sc["dh"])
-            ev = [wgrad(dx_name, dx, h, st.g(p + "mlp.down_proj.weight"))]
-            before_write("dgu")
-            dgu = ops.swiglu_bwd(gu, dh, out=sc["dgu"])
+            if FUSE_SWIGLU_BWD:
+                # dh = dx @ Wd never reaches HBM: the dgrad GEMM's epilogue applies SwiGLU' and writes d(gate|up) directly
+                before_write("dgu")
+                dgu = ops.gemm_bf16(ops.NN, dx, Wd, out=sc["dgu"], R=gu, epilogue=ops.EPI_SWIGLU_BWD)
+                ev = [wgrad(dx_name, dx, h, st.g(p + "mlp.down_proj.weight"))]
+            else:
+                dh = ops.gemm_bf16(ops.NN, dx, Wd, out=sc["dh"])
+                ev = [wgrad(dx_name, dx, h, st.g(p + "mlp.down_proj.weight"))]
+                before_write("dgu")
+                dgu = ops.swiglu_bwd(gu, dh, out=sc["dgu"])
             dn2 = ops.gemm_bf16(ops.NN, dgu, st.gate_up(i), out=sc["dn2"])
             ev.append(wgrad("dgu", dgu, n2, st.gate_up(i, grad=True)))
             before_write("dx1")

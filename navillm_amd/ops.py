@@ -9,7 +9,7 @@ from . import lib as _lib
 
 BF16 = torch.bfloat16
 F32 = torch.float32
-EPI_STORE, EPI_ACCUM, EPI_RESID, EPI_BIAS = 0, 1, 2, 3
+EPI_STORE, EPI_ACCUM, EPI_RESID, EPI_BIAS, EPI_SWIGLU_BWD = 0, 1, 2, 3, 4
 NT, NN, TN = 0, 1, 2
 
 
@@ -69,13 +69,15 @@ def gemm_bf16(layout, A, B, out=None, R=None, epilogue=EPI_STORE, tile_cfg=0):
         K, M = A.shape
         K2, N = B.shape
     assert K == K2, (A.shape, B.shape, layout)
+    wide = 2 if epilogue == EPI_SWIGLU_BWD else 1           # SwiGLU-backward epilogue: out = d(gate|up) [M, 2N], R = gate|up
     if out is None:
-        out = torch.empty((M, N), dtype=BF16, device=A.device)
+        out = torch.empty((M, wide * N), dtype=BF16, device=A.device)
     _chk2d(out, BF16)
-    assert tuple(out.shape) == (M, N)
+    assert tuple(out.shape) == (M, wide * N)
     ldr = 0
-    if epilogue == EPI_RESID:
+    if epilogue in (EPI_RESID, EPI_SWIGLU_BWD):
         _chk2d(R, BF16)
+        assert tuple(R.shape) == (M, wide * N)
         ldr = R.stride(0)
     rc = _L().nv_gemm_bf16_ws(layout, A.data_ptr(), B.data_ptr(), out.data_ptr(), _p(R), M, N, K, A.stride(0), B.stride(0),
                               out.stride(0), ldr, epilogue, tile_cfg, _gemm_ws(A.device) if SPLITK_TAIL else 0, _st())
