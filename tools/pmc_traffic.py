@@ -1,0 +1,43 @@
+"""Turn the two rocprofv3 --pmc passes of tools/gpu_pmc_bench.sh (FETCH_SIZE, WRITE_SIZE) into
+profiles/r01_gemm_pmc_traffic.txt and profiles/r01_gemm_traffic.json (bytes per forward-GEMM launch).
+Usage: pmc_traffic.py FETCH_DB WRITE_DB OUT_TXT OUT_JSON"""
+import collections, json, re, sqlite3, sys
+
+def per_kernel(db):
+    c = sqlite3.connect(db)
+    rows = c.execute("select kernel_name, counter_name, value from counters_collection").fetchall()
+    # a dispatch reports one row per (counter, dimension instance): sum the instances of a dispatch first
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    try:
+        rows = c.execute("select kernel_name, counter_name, dispatch_id, sum(value) from counters_collection group by 1,2,3").fetchall()
+        for k, cn, _, v in rows:
+            if "gemm_bf16_kernel" in k:
+                a = agg[(re.sub(r"\(anonymous namespace\)::|void |\(.*", "", k), cn)]
+                a[0] += 1; a[1] += v
+    except sqlite3.OperationalError:
+        for k, cn, v in rows:
+            if "gemm_bf16_kernel" in k:
+                a = agg[(re.sub(r"\(anonymous namespace\)::|void |\(.*", "", k), cn)]
+                a[0] += 1; a[1] += v
+    return agg
+
+fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+lines = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (two separate passes) of",
+         "#   python bench.py --steps 3 --warmup 0 --prewarm 1 --no-cpu-baseline --no-profile --infer-steps 0   (MI355X, round 1, final kernels)",
+         "# per-dispatch averages for the bf16 GEMM kernels; counters are in KiB; gfx950 correction: FETCH_SIZE reports half",
+         "# of a wide coalesced stream (MI355X_MICROARCH.md §HBM) -> HBM-side bytes = 2*FETCH_SIZE + WRITE_SIZE.",
+         "# FETCH_SIZE counts fabric requests of the L2s (Infinity-Cache hits included), not only HBM reads.",
+         f"# {'kernel':<62} {'counter':<12} {'launches':>8} {'avg_KiB':>12}"]
+fw = {"F": [0, 0.0], "W": [0, 0.0]}
+for tag, agg in (("F", fetch), ("W", write)):
+    for (k, cn), (n, tot) in sorted(agg.items()):
+        lines.append(f"{k:<64} {cn:<12} {n:>8d} {tot / n:>12.1f}")
+        if re.search(r"true, true, [02], 4>", k):          # forward NT launches (store and residual epilogues)
+            fw[tag][0] += n; fw[tag][1] += tot
+f_avg, w_avg = fw["F"][1] / max(fw["F"][0], 1), fw["W"][1] / max(fw["W"][0], 1)
+total = (2 * f_avg + w_avg) * 1024
+lines.append(f"# forward (NT) GEMM launches: avg FETCH_SIZE {f_avg:.0f} KiB, WRITE_SIZE {w_avg:.0f} KiB -> corrected traffic {total/1e9:.3f} GB per launch")
+open(sys.argv[3], "w").write("\n".join(lines) + "\n")
+json.dump({"hbm_bytes_per_forward_gemm_launch": int(total), "fetch_kib_avg": f_avg, "write_kib_avg": w_avg,
+           "launches": fw["F"][0], "source": "profiles/r01_gemm_pmc_traffic.txt"}, open(sys.argv[4], "w"))
+print(lines[-1])
