@@ -68,6 +68,10 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// 2^x as the bare v_exp_f32: exp2f() wraps it in a denormal-range fix-up (compare, select, add, ldexp: 7 VALU ops per
+// element against 1).  Softmax probabilities below 2^-126 are zero for every consumer here (they are rounded to bf16).
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // reduce over the 4 lane groups that share lane&15
 __device__ __forceinline__ float grp_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 16, 64));
@@ -129,9 +133,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
     constexpr int TILE = 64 * ROWB;  // 16 KiB per K or V tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    // grid (B*H, query blocks): x walks the heads, y the query blocks from the LAST one down -- causal work grows with the
+    // query index, so the long blocks are dispatched first and the short ones fill the tail of the launch
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int S = p.S, ld = p.ld;
-    const int q0 = p.q_row_min + blockIdx.x * 128;
+    const int q0 = p.q_row_min + (gridDim.y - 1 - blockIdx.y) * 128;
     const int kvs = p.kv_start[b];
     const int qi = lane & 15, g = lane >> 4;
     const bf16_t* base = p.qkv + (long)b * p.Sst * ld;
@@ -189,31 +195,40 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
                         s[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[j][kk], s[i][j], 0, 0, 0);
                 }
             }
-            // ---- mask + online softmax (per query = per lane&15)
+            // ---- mask + online softmax (per query = per lane&15).  Key tiles entirely below this wave's first query and
+            // entirely at/after the left padding need no mask at all (wave-uniform test): most tiles of a long prompt.
+            const bool interior = (kt * 64 + 63 <= q0 + wave * 32) && (kt * 64 >= kvs);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                float mx = -INFINITY;
+                float mx = -INFINITY;                          // max of the RAW scores (scale2 > 0 commutes with max)
+                if (interior) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kt * 64 + i * 16 + g * 4 + r;
-                        const bool ok = (key <= qpos[j]) && (key >= kvs);
-                        const float v = ok ? s[i][j][r] * p.scale2 : -INFINITY;
-                        s[i][j][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
-                mx = grp_max(mx);
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[i][j][r]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kt * 64 + i * 16 + g * 4 + r;
+                            const bool ok = (key <= qpos[j]) && (key >= kvs);
+                            const float v = ok ? s[i][j][r] : -INFINITY;
+                            s[i][j][r] = v;
+                            mx = fmaxf(mx, v);
+                        }
+                }
+                mx = grp_max(mx) * p.scale2;
                 const float mn = fmaxf(m2[j], mx);
                 const float msafe = (mn == -INFINITY) ? 0.f : mn;
-                const float alpha = exp2f(m2[j] - msafe);   // m2=-inf -> 0
+                const float alpha = fast_exp2(m2[j] - msafe);   // m2=-inf -> 0
                 m2[j] = mn;
                 float rs_ = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = exp2f(s[i][j][r] - msafe);
+                        const float e = fast_exp2(fmaf(s[i][j][r], p.scale2, -msafe));   // masked: fma(-inf, +c, x) = -inf -> 0
                         s[i][j][r] = e;
                         rs_ += e;
                     }
@@ -259,21 +274,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 }
 
 // =========================================================================== backward prep
-// dsum[b,h,q] = sum_d dO[q,d] * O[q,d]   (one wave per (row, head))
+// dsum[b,h,q] = sum_d dO[q,d] * O[q,d]   (16 lanes per (row, head): 16-B loads, 4 items per wave)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
                                                             float* __restrict__ dsum, int B, int S, int H) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long item = (long)blockIdx.x * 4 + wave;   // (row, head)
-    if (item >= (long)B * S * H) return;
-    const long row = item / H;
-    const int h = (int)(item % H);
-    const bf16_t* a = dout + row * (H * HD) + h * HD + lane * 2;
-    const bf16_t* o = out + row * (H * HD) + h * HD + lane * 2;
-    const uint32_t av = *(const uint32_t*)a, ov = *(const uint32_t*)o;
-    float v = __uint_as_float(av << 16) * __uint_as_float(ov << 16) +
-              __uint_as_float(av & 0xffff0000u) * __uint_as_float(ov & 0xffff0000u);
-    v = wave_sum(v);
-    if (lane == 0) {
+    const int sub = threadIdx.x & 15;
+    const long item = (long)blockIdx.x * 16 + (threadIdx.x >> 4);   // (row, head)
+    const bool live = item < (long)B * S * H;
+    const long row = live ? item / H : 0;
+    const int h = live ? (int)(item % H) : 0;
+    const u32x4 av = *(const u32x4*)(dout + row * (H * HD) + h * HD + sub * 8);
+    const u32x4 ov = *(const u32x4*)(out + row * (H * HD) + h * HD + sub * 8);
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        v += __uint_as_float(av[q] << 16) * __uint_as_float(ov[q] << 16) +
+             __uint_as_float(av[q] & 0xffff0000u) * __uint_as_float(ov[q] & 0xffff0000u);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (live && sub == 0) {
         const int bb = (int)(row / S), s = (int)(row % S);
         dsum[((long)bb * H + h) * S + s] = v;
     }
@@ -288,9 +306,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
     constexpr int TILE = 32 * ROWB;  // 8 KiB per Q or dO tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;      // grid (B*H, key blocks): key block 0 (all queries) goes first
     const int S = p.S, ld = p.ld;
-    const int kblk = blockIdx.x * 64 * KW;
+    const int kblk = blockIdx.y * 64 * KW;
     const int kvs = p.kv_start[b];
     const int ki = lane & 15, g = lane >> 4;
     const bf16_t* base = p.qkv + (long)b * S * ld;
@@ -331,12 +349,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         stage_rows<32, 256>(rdo, smem + buf * 2 * TILE + TILE, qt * 32, h * HD, od, tid);
     };
     if (qt_beg <= qt_end) {
+    // 3-slot ring, two tiles in flight: a tile step here is short (32-64 MFMAs), shorter than the DMA round trip, so
+    // with a single tile of prefetch every step ended waiting for its successor
     stage(qt_beg, 0);
-    wait_vmcnt<0>();
+    if (qt_beg < qt_end) { stage(qt_beg + 1, 1); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
     __builtin_amdgcn_s_barrier();
     int cur = 0;
     for (int qt = qt_beg; qt <= qt_end; ++qt) {
-        if (qt < qt_end) stage(qt + 1, cur ^ 1);
+        if (qt + 2 <= qt_end) stage(qt + 2, cur >= 1 ? cur - 1 : 2);      // (cur + 2) % 3
         LDS_PTR(char) sq = smem + cur * 2 * TILE;
         LDS_PTR(char) sdo = sq + TILE;
         // ---- S = Q K^T and dP = dO V^T : lane holds key = lane&15, queries qt*32 + j*16 + g*4 + r
@@ -378,7 +398,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     const int q = qt * 32 + j * 16 + g * 4 + r;
                     const bool ok = (q < S) && (key[jk] <= q) && (key[jk] >= kvs) && (key[jk] < S);
-                    const float pe = ok ? exp2f(s[jk][j][r] * p.scale2 - lq[j][r]) : 0.f;
+                    const float pe = ok ? fast_exp2(fmaf(s[jk][j][r], p.scale2, -lq[j][r])) : 0.f;
                     pv[j][r] = pe;
                     ds[j][r] = pe * (dp[jk][j][r] - dq_[j][r]);
                 }
@@ -396,9 +416,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
                 dk[jk][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsfrag[jk], dk[jk][dt], 0, 0, 0);
             }
         }
-        wait_vmcnt<0>();
+        if (qt + 2 <= qt_end) wait_vmcnt<4>(); else wait_vmcnt<0>();       // tile qt+1 has landed (qt+2 may be in flight)
         __builtin_amdgcn_s_barrier();
-        cur ^= 1;
+        cur = cur == 2 ? 0 : cur + 1;
     }
     }
 #pragma unroll
@@ -420,9 +440,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
     constexpr int TILE = 64 * ROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;      // grid (B*H, query blocks), last (longest) query block first
     const int S = p.S, ld = p.ld;
-    const int q0 = p.q_row_min + blockIdx.x * 64 * QW;
+    const int q0 = p.q_row_min + (gridDim.y - 1 - blockIdx.y) * 64 * QW;
     const int kvs = p.kv_start[b];
     const int qi = lane & 15, g = lane >> 4;
     const bf16_t* base = p.qkv + (long)b * S * ld;
@@ -495,7 +515,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
                     for (int r = 0; r < 4; ++r) {
                         const int key = kt * 64 + i * 16 + g * 4 + r;
                         const bool ok = (q[j] < S) && (key <= q[j]) && (key >= kvs);
-                        const float pe = ok ? exp2f(s[i][j][r] * p.scale2 - my_lse[j]) : 0.f;
+                        const float pe = ok ? fast_exp2(fmaf(s[i][j][r], p.scale2, -my_lse[j])) : 0.f;
                         s[i][j][r] = pe * (dp[i][j][r] - my_ds[j]);   // dS^T
                     }
 #pragma unroll
@@ -543,7 +563,7 @@ int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_star
     p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = kv_start;
     p.B = B; p.S = S; p.Sst = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
-    NV_LAUNCH(attn_fwd_kernel, dim3((S - q_row_min + 127) / 128, B * H), dim3(256), 65536, (hipStream_t)stream, p);
+    NV_LAUNCH(attn_fwd_kernel, dim3(B * H, (S - q_row_min + 127) / 128), dim3(256), 65536, (hipStream_t)stream, p);
     return nv_check_launch();
 }
 
@@ -560,7 +580,7 @@ int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int*
     p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = kv_start;
     p.B = B; p.S = S; p.Sst = S_stride; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
-    NV_LAUNCH(attn_fwd_kernel, dim3((S - q_row_min + 127) / 128, B * H), dim3(256), 65536, (hipStream_t)stream, p);
+    NV_LAUNCH(attn_fwd_kernel, dim3(B * H, (S - q_row_min + 127) / 128), dim3(256), 65536, (hipStream_t)stream, p);
     return nv_check_launch();
 }
 
@@ -581,15 +601,15 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
     const int variant = ev ? atoi(ev) : 1;
     static bool once = false;
     if (!once) {
-        if (set_lds((const void*)attn_bwd_dkv_kernel<1>, 32768) || set_lds((const void*)attn_bwd_dq_kernel<1>, 65536) ||
-            set_lds((const void*)attn_bwd_dkv_kernel<2>, 32768) || set_lds((const void*)attn_bwd_dq_kernel<2>, 65536))
+        if (set_lds((const void*)attn_bwd_dkv_kernel<1>, 49152) || set_lds((const void*)attn_bwd_dq_kernel<1>, 65536) ||
+            set_lds((const void*)attn_bwd_dkv_kernel<2>, 49152) || set_lds((const void*)attn_bwd_dq_kernel<2>, 65536))
             return NV_ERR_LAUNCH;
         once = true;
     }
     hipStream_t st = (hipStream_t)stream;
     float* dsum = (float*)workspace;
     const long items = (long)B * S * H;
-    NV_LAUNCH(attn_bwd_prep_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, (const bf16_t*)dout,
+    NV_LAUNCH(attn_bwd_prep_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, (const bf16_t*)dout,
                        (const bf16_t*)out, dsum, B, S, H);
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.lse2 = (float*)lse2; p.dsum = dsum; p.dqkv = (bf16_t*)dqkv;
@@ -599,11 +619,11 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
     // with q_row_min > 0 only those query rows carry gradient: dK/dV still cover every key, dQ rows below
     // q_row_min are NOT written (the caller zero-fills them)
     if (variant == 1) {
-        NV_LAUNCH(attn_bwd_dkv_kernel<1>, dim3((S + 63) / 64, B * H), dim3(256), 32768, st, p);
-        NV_LAUNCH(attn_bwd_dq_kernel<1>, dim3((S - q_row_min + 63) / 64, B * H), dim3(256), 65536, st, p);
+        NV_LAUNCH(attn_bwd_dkv_kernel<1>, dim3(B * H, (S + 63) / 64), dim3(256), 49152, st, p);
+        NV_LAUNCH(attn_bwd_dq_kernel<1>, dim3(B * H, (S - q_row_min + 63) / 64), dim3(256), 65536, st, p);
     } else {
-        NV_LAUNCH(attn_bwd_dkv_kernel<2>, dim3((S + 127) / 128, B * H), dim3(256), 32768, st, p);
-        NV_LAUNCH(attn_bwd_dq_kernel<2>, dim3((S - q_row_min + 127) / 128, B * H), dim3(256), 65536, st, p);
+        NV_LAUNCH(attn_bwd_dkv_kernel<2>, dim3(B * H, (S + 127) / 128), dim3(256), 49152, st, p);
+        NV_LAUNCH(attn_bwd_dq_kernel<2>, dim3(B * H, (S - q_row_min + 127) / 128), dim3(256), 65536, st, p);
     }
     return nv_check_launch();
 }
