@@ -389,19 +389,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
                 dq_[j][r] = dsum[qc];
             }
         bf16x8 pfrag[KW], dsfrag[KW];
+        // query tiles entirely past this wave's keys, inside [0, S), with the keys past the left padding: no mask
+        const int wkey_lo = kblk + wave * KW * 16, wkey_hi = wkey_lo + KW * 16 - 1;
+        const bool interior = (qt * 32 >= wkey_hi) && (qt * 32 + 31 < S) && (wkey_lo >= kvs) && (wkey_hi < S);
 #pragma unroll
         for (int jk = 0; jk < KW; ++jk) {
             f32x4 pv[2], ds[2];
+            if (interior) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = qt * 32 + j * 16 + g * 4 + r;
-                    const bool ok = (q < S) && (key[jk] <= q) && (key[jk] >= kvs) && (key[jk] < S);
-                    const float pe = ok ? fast_exp2(fmaf(s[jk][j][r], p.scale2, -lq[j][r])) : 0.f;
-                    pv[j][r] = pe;
-                    ds[j][r] = pe * (dp[jk][j][r] - dq_[j][r]);
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const float pe = fast_exp2(fmaf(s[jk][j][r], p.scale2, -lq[j][r]));
+                        pv[j][r] = pe;
+                        ds[j][r] = pe * (dp[jk][j][r] - dq_[j][r]);
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = qt * 32 + j * 16 + g * 4 + r;
+                        const bool ok = (q < S) && (key[jk] <= q) && (key[jk] >= kvs) && (key[jk] < S);
+                        const float pe = ok ? fast_exp2(fmaf(s[jk][j][r], p.scale2, -lq[j][r])) : 0.f;
+                        pv[j][r] = pe;
+                        ds[j][r] = pe * (dp[jk][j][r] - dq_[j][r]);
+                    }
+            }
             pfrag[jk] = pack_frag(pv[0], pv[1]);
             dsfrag[jk] = pack_frag(ds[0], ds[1]);
         }
@@ -507,17 +521,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
                     }
                 }
             }
+            // key tiles entirely before this wave's first query, past the left padding, with all its queries < S: no mask
+            const int wq_lo = q0 + wave * QW * 16;
+            const bool interior = (kt * 64 + 63 <= wq_lo) && (kt * 64 >= kvs) && (wq_lo + QW * 16 - 1 < S);
 #pragma unroll
-            for (int j = 0; j < QW; ++j)
+            for (int j = 0; j < QW; ++j) {
+                if (interior) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kt * 64 + i * 16 + g * 4 + r;
-                        const bool ok = (q[j] < S) && (key <= q[j]) && (key >= kvs);
-                        const float pe = ok ? fast_exp2(fmaf(s[i][j][r], p.scale2, -my_lse[j])) : 0.f;
-                        s[i][j][r] = pe * (dp[i][j][r] - my_ds[j]);   // dS^T
-                    }
+                        for (int r = 0; r < 4; ++r) {
+                            const float pe = fast_exp2(fmaf(s[i][j][r], p.scale2, -my_lse[j]));
+                            s[i][j][r] = pe * (dp[i][j][r] - my_ds[j]);   // dS^T
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kt * 64 + i * 16 + g * 4 + r;
+                            const bool ok = (q[j] < S) && (key <= q[j]) && (key >= kvs);
+                            const float pe = ok ? fast_exp2(fmaf(s[i][j][r], p.scale2, -my_lse[j])) : 0.f;
+                            s[i][j][r] = pe * (dp[i][j][r] - my_ds[j]);   // dS^T
+                        }
+                }
+            }
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 bf16x8 dsf[QW];

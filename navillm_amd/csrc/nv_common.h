@@ -22,18 +22,18 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define GLB_PTR(T) __attribute__((address_space(1))) T*
 
 // ---- bf16 <-> f32, round-to-nearest-even (matches torch's CPU/GPU conversions) ----
+// f32 -> bf16 is the gfx950 hardware conversion v_cvt_pk_bf16_f32 (RNE, NaN stays NaN): one instruction per PAIR of
+// values where the integer formulation (add 0x7fff + lsb, NaN select, shift) costs ~6 per value -- the softmax-backward
+// and row kernels are VALU-bound on exactly this.
+typedef __attribute__((ext_vector_type(2))) float nv_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 nv_bf16x2;
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-// round a float to bf16 precision and widen back (a "rounding point")
-__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(nv_f32x2{lo, hi}, nv_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
+// round a float to bf16 precision and widen back (a "rounding point")
+__device__ __forceinline__ float rbf(float f) { return __uint_as_float(pack2bf(f, 0.f) << 16); }
 
 // ---- buffer resource (bounds-checked, OOB loads return 0) ----
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
