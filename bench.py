@@ -261,16 +261,27 @@ def main():
             line["inference_prefix_kv_reuse"] = infer_kv
         if g is not None:
             allg = timer.summary(layouts=(0, 1, 2))
-            line["roofline"] = {"bound": "mfma", "achieved": round(g["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(g["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+            # the dominant kernel is ONE template (gemm_bf16_kernel) in three operand layouts.  With the backward on a
+            # single stream (the default) every launch's event bracket is its kernel duration, so the roofline is taken
+            # over all of them; with the optional wgrad side stream only the forward launches run alone.
+            r = g if model.overlap_wgrad else allg
+            per = {n: timer.summary(layouts=(l,)) for n, l in (("forward_NT", 0), ("dgrad_NN", 1), ("wgrad_TN", 2))}
+            line["roofline"] = {"bound": "mfma", "achieved": round(r["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": round(r["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                                 "traffic": gemm_traffic_from_profile(),
-                                "kernel": "gemm_bf16_kernel<256,256,2,4,64,2,true,true,*,4> (forward y = x W^T launches: qkv, o, "
-                                          "gate|up, down of every layer; they run alone on the stream)",
-                                "launches": g["launches"], "avg_launch_ms": round(g["avg_launch_ms"], 4),
-                                "flops_per_launch": g["flops_per_launch"],
+                                "kernel": "gemm_bf16_kernel<256,256,2,4,64,2,*,*,*,4> -- every bf16 GEMM launch of the timed steps "
+                                          "(forward y = x W^T, dgrad, wgrad of qkv / o / gate|up / down in every layer)"
+                                          if not model.overlap_wgrad else
+                                          "gemm_bf16_kernel<256,256,2,4,64,2,true,true,*,4> (forward launches only: with the wgrad "
+                                          "side stream the backward brackets overlap)",
+                                "launches": r["launches"], "avg_launch_ms": round(r["avg_launch_ms"], 4),
+                                "flops_per_launch": r["flops_per_launch"],
+                                "by_layout_tflops": {n: (round(v["tflops"], 1) if v else None) for n, v in per.items()},
                                 "all_gemm_flops_per_step": allg["flops_per_launch"] * allg["launches"] / a.steps,
-                                "note": "dgrad/wgrad GEMMs overlap on two HIP streams; their per-launch brackets are not "
-                                        "kernel durations and are excluded here (rocprof per-kernel stats: profiles/)"}
+                                "gemm_share_of_step": round(allg["gemm_seconds"] / dt, 3),
+                                "note": "peak = nominal dense bf16 MFMA; with N(0,1) operands the MFMA pipe of this part sustains "
+                                        "1.87-2.0 PFLOP/s (power-limited clock; tools/ubench/mix_rate.hip, DESIGN.md §4); "
+                                        "traffic = 2*FETCH_SIZE+WRITE_SIZE per forward launch from the PMC passes in profiles/"}
         if not a.no_cpu_baseline and world == 1:
             try:
                 line["cpu_baseline"] = cpu_baseline(a, cfg, 1234)
