@@ -18,6 +18,10 @@ dict in the reference's state_dict layout) and no `transformers` dependency, of
   * heads and losses            models/nav_model.py:234-242,407-451, train.py:229,
                                 models/modified_lm.py:126-137
   * grad clip + AdamW           train.py:86-89, tools/optims.py:43-45
+  * greedy generation           models/nav_model.py:324-341,388-402, models/modified_lm.py:10-30,184-199 -> HF
+                                `generate(do_sample=False)` (third-party; restated as a cache-free recompute loop:
+                                `greedy_generate`) -- PARITY UNPINNED for the loop itself: the reference's generate()
+                                does not run under the installed transformers, only `lm_forward` under it is pinned
 
 Parity pinning: the reference ships no tests, so this oracle is pinned by golden
 vectors produced HERE by importing the reference itself (tests/golden/make_golden.py,
