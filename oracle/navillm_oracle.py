@@ -20,8 +20,8 @@ dict in the reference's state_dict layout) and no `transformers` dependency, of
   * grad clip + AdamW           train.py:86-89, tools/optims.py:43-45
   * greedy generation           models/nav_model.py:324-341,388-402, models/modified_lm.py:10-30,184-199 -> HF
                                 `generate(do_sample=False)` (third-party; restated as a cache-free recompute loop:
-                                `greedy_generate`) -- PARITY UNPINNED for the loop itself: the reference's generate()
-                                does not run under the installed transformers, only `lm_forward` under it is pinned
+                                `greedy_generate`), pinned by fixture G9 = the reference's own generate() calls run
+                                here with two library-side signature shims (tests/golden/make_golden.py)
 
 Parity pinning: the reference ships no tests, so this oracle is pinned by golden
 vectors produced HERE by importing the reference itself (tests/golden/make_golden.py,
@@ -231,8 +231,9 @@ def greedy_generate(P, cfg, input_ids, attention_mask, cand_vis=None, hist_vis=N
     when it emits eos_token_id; stop when all rows are finished or after max_new_tokens.
     Parity note: HF's generation path numbers positions per sample (cumsum of the mask) while this recompute numbers them
     over the padding like the training path does; RoPE depends on differences only, so the two agree up to bf16
-    rounding.  `generate()` itself does not run under the installed transformers, so this function
-    is pinned only through `lm_forward` (fixture G2).  Returns B lists of new tokens."""
+    rounding.  Pinned by fixture G9 (tests/golden/g9_generate_*.npz): the reference's own generate() calls, run with two
+    library-side signature shims (tests/golden/make_golden.py::install_generation_shims).  Returns (B lists of new
+    tokens, last-step logits)."""
     ids, am = input_ids.clone(), attention_mask.clone()
     B = ids.shape[0]
     out = [[] for _ in range(B)]
@@ -377,6 +378,28 @@ def summarization_loss(P, cfg, vp_img_embeds, vp_nav_masks, hist_vis, input_ids,
     labels[token_type_ids == 0] = -100
     loss, _, _ = lm_forward(P, cfg, input_ids, attention_mask, labels=labels, cand_vis=x[nm], hist_vis=hist)
     return loss
+
+
+def qa_3d_generate(P, cfg, features, input_ids, attention_mask, **gen):
+    """NavModel.forward_3dqa inference branch, nav_model.py:386-404 -> new token ids per sample."""
+    vf = pad_tensors_wgrad(list(features))
+    vl = torch.tensor([f.shape[0] for f in features])
+    out = scene_encoder(P, cfg, vf, vl)
+    pe, pm = out["pano_embeds"], out["pano_masks"]
+    pe = pe + _seq2(torch.zeros(pe.shape[:2] + (14,)), P, "vp_pos_embeddings")
+    pe = pe + P["token_type_embeddings.weight"][0]
+    return greedy_generate(P, cfg, input_ids, attention_mask, cand_vis=pe[pm], **gen)[0]
+
+
+def summarization_generate(P, cfg, vp_img_embeds, vp_nav_masks, hist_vis, input_ids, attention_mask, **gen):
+    """NavModel.forward_summarization inference branch, nav_model.py:320-343 (max_new_tokens=50, optional trie)."""
+    x = vp_img_embeds[:, 1:, :]
+    nm = vp_nav_masks[:, 1:].bool()
+    x = x + _seq2(torch.zeros(x.shape[:2] + (14,)), P, "vp_pos_embeddings")
+    x = x + P["token_type_embeddings.weight"][0]
+    hv = [v for vis in hist_vis for v in vis]
+    hist = torch.stack(hv, 0) if hv else None
+    return greedy_generate(P, cfg, input_ids, attention_mask, cand_vis=x[nm], hist_vis=hist, **gen)[0]
 
 
 def action_loss(logits, targets):

@@ -16,6 +16,7 @@ Outputs (all small, committed):
     g6_prompts.json    prompt strings         (G6)
     g7_graph.npz       graph_utils            (G7)
     g8_adamw.npz       clip + AdamW on bf16   (G8)
+    g9_generate_*.npz  greedy generation through the reference's own generate() calls (3dqa free, summarization trie)
 
 Three shims, all outside the reference tree (the third -- fp32 RoPE
 frequencies, see build_reference -- undoes a transformers 4.28 -> 5.15 drift): the bert-large-uncased
@@ -24,6 +25,13 @@ locally trained SentencePiece tokenizer.  Weights are NOT the reference's random
 init: they come from navillm_amd.params.synth_state_dict (seeded, per-name), are loaded
 into the reference module with load_state_dict(strict=True), and are regenerated from
 the seed by the tests -- so fixtures hold inputs + expected outputs only.
+
+G9 needs two more version-drift shims, both on the LIBRARY side (install_generation_shims): the reference calls
+`LlamaForCausalLM.prepare_inputs_for_generation(self, input_ids, past_key_values, attention_mask, inputs_embeds)`
+positionally (modified_lm.py:187-193, the 4.28 signature) while 5.15 put `next_sequence_length` second; and it tests
+`if not past_key_values` (modified_lm.py:194) for "this is the prefill step", where 4.28 passed None and 5.15 passes an
+empty DynamicCache object.  The shims re-map the positionals to keywords and make an EMPTY cache falsy; nothing in the
+reference tree is touched.
 """
 import os, sys, json, types, logging, random, io
 import numpy as np
@@ -82,6 +90,90 @@ def make_tiny_llama_dir(cfg):
                      rms_norm_eps=cfg.rms_norm_eps, max_position_embeddings=2048)
     hf._attn_implementation = "eager"
     hf.save_pretrained(TINY_DIR)
+
+
+def install_generation_shims():
+    from transformers import LlamaForCausalLM
+    from transformers.cache_utils import DynamicCache
+    if getattr(LlamaForCausalLM, "_nv_shimmed", False):
+        return
+    orig = LlamaForCausalLM.prepare_inputs_for_generation
+
+    def prep(self, input_ids, *args, **kw):
+        if args and not isinstance(args[0], int):          # 4.28 calling convention
+            for n, v in zip(["past_key_values", "attention_mask", "inputs_embeds"], args):
+                kw[n] = v
+            args = ()
+        return orig(self, input_ids, *args, **kw)
+
+    LlamaForCausalLM.prepare_inputs_for_generation = prep
+    DynamicCache.__bool__ = lambda self: self.get_seq_length() > 0
+    LlamaForCausalLM._nv_shimmed = True
+
+
+def gen_generation(model, cfg, tag, seed=23):
+    """G9: the reference's inference branches (nav_model.py:320-343, 386-404) run through ITS generate() calls;
+    the ids HF returns are captured by wrapping lang_model.generate."""
+    from tasks.agents.r2r import R2RAgent
+    from tools.trie import Trie
+    install_generation_shims()
+    lm = model.lang_model
+    g = torch.Generator().manual_seed(seed)
+    B, N = 3, 4
+    captured = []
+    real_generate = lm.generate
+
+    def spy(*a, **k):
+        out = real_generate(*a, **k)
+        captured.append((k["input_ids"].clone(), k["attention_mask"].clone(), out.clone()))
+        return out
+
+    lm.generate = spy
+    try:
+        with torch.no_grad():
+            # ---- 3dqa, unconstrained, max_new_tokens=6 (llava.py:57-63 passes do_sample/temperature/max_new_tokens)
+            feats = [torch.randn(n, cfg.image_feat_size, generator=g) for n in (5, 3, 4)]
+            qprompts = [" ".join(["<cand>"] * f.shape[0]) + " ### Question: " + q + " ### Answer: "
+                        for f, q in zip(feats, ("what color is the chair ?", "what is near the window ?", "exist table ?"))]
+            qb = dict(question=qprompts, prompts=qprompts, answers=[["x"]] * B, features=feats, data_type=["scanqa"] * B)
+            qo = model("3dqa", qb, training=False, do_sample=False, max_new_tokens=6)
+            q_in, q_am, q_out = captured[-1]
+            # ---- summarization with the trie constraint (mp3d_agent.py:541-581 builds it from candidate instructions)
+            pin_s, _ = pano_inputs(cfg, g, B, N)
+            ps = model("panorama", dict(pin_s))
+            vp_img = torch.cat([torch.zeros_like(ps["pano_embeds"][:, :1]), ps["pano_embeds"]], 1)
+            nav_masks = torch.cat([torch.ones(B, 1, dtype=torch.bool), pin_s["nav_types"] == 1], 1)
+            hist_ts = [1, 0, 2]
+            hvs = [[torch.randn(cfg.hidden_size, generator=g) for _ in range(hist_ts[b])] for b in range(B)]
+            cn = nav_masks[:, 1:].sum(1)
+            prompts_s = [R2RAgent.get_summarization_prompt(None, INSTR[b], hist_ts[b], int(cn[b])) for b in range(B)]
+            tok = lm.tokenizer
+            words = ["walk to the kitchen", "walk to the sofa and stop", "turn left at the door", "go up the stairs"]
+            trie = Trie(tok.bos_token_id, tok.eos_token_id)
+            word_ids = []
+            for w in words:
+                ids = tok(w, add_special_tokens=False)["input_ids"] + [tok.eos_token_id]
+                trie.insert(ids)
+                word_ids.append(ids)
+            sb = dict(vp_img_embeds=vp_img.clone(), vp_pos_fts=torch.zeros(B, N + 1, 14), vp_nav_masks=nav_masks,
+                      vp_cand_vpids=[[None]] * B, instruction=INSTR, answer=[""] * B, history=[["<hist>"] * t for t in hist_ts],
+                      hist_vis=hvs, data_type=["r2r"] * B, prompts=prompts_s)
+            so = model("summarization", sb, training=False, trie=trie)
+            s_in, s_am, s_out = captured[-1]
+    finally:
+        lm.generate = real_generate
+    L = max(len(w) for w in word_ids)
+    words_arr = np.full((len(word_ids), L), -1, dtype=np.int64)
+    for i, w in enumerate(word_ids):
+        words_arr[i, :len(w)] = w
+    hv_flat = torch.stack([v for vis in hvs for v in vis], 0)
+    save(f"g9_generate_{tag}.npz", qa_features=pad(feats), qa_feat_lens=torch.tensor([f.shape[0] for f in feats]),
+         qa_input_ids=q_in, qa_attention_mask=q_am, qa_new_ids=q_out[:, q_in.shape[1]:],
+         **{"sum_" + k: v for k, v in pin_s.items() if torch.is_tensor(v)}, sum_vp_nav_masks=nav_masks, sum_hist_vis_flat=hv_flat,
+         sum_input_ids=s_in, sum_attention_mask=s_am, sum_new_ids=s_out[:, s_in.shape[1]:], trie_words=words_arr,
+         meta=np.array(json.dumps(dict(hist_t=hist_ts, qa_prompts=qprompts, sum_prompts=prompts_s, trie_words=words,
+                                       qa_sentences=qo["generated_sentences"], sum_sentences=so["generated_sentences"],
+                                       eos=tok.eos_token_id, pad=tok.unk_token_id, bos=tok.bos_token_id))))
 
 
 def build_reference(cfg, seed):
@@ -472,8 +564,14 @@ def main():
     cfg = nvcfg.tiny()
     make_tiny_llama_dir(cfg)
     meta = {}
+    if "--only-generation" in sys.argv:          # add G9 without touching the other fixtures
+        for prec in ("fp32", "amp_bf16"):
+            c = nvcfg.tiny(precision=prec)
+            gen_generation(build_reference(c, 11), c, "bf16" if c.lm_is_bf16 else "fp32")
+        return
     for prec in ("fp32", "amp_bf16"):
         model, c = gen_precision(prec)
+        gen_generation(model, c, "bf16" if c.lm_is_bf16 else "fp32")
         meta[prec] = {k: [list(v.shape), str(v.dtype)] for k, v in model.state_dict().items()}
     # also record the key inventory for the configs with fuse_obj / no objects
     with open(os.path.join(HERE, "g_meta.json"), "w") as f:

@@ -142,6 +142,53 @@ def test_g5_summarization_and_fgr2r_losses(tag):
     close(lq, z["qa_loss"], tol, what="fgr2r loss")
 
 
+class _GoldTrie:
+    """tools/trie.py protocol over the fixture's word list (no defaultdict side effects)"""
+
+    class _N:
+        def __init__(self):
+            self.child = {}
+
+    def __init__(self, words, eos):
+        self.root, self.eos = self._N(), eos
+        for w in words:
+            cur = self.root
+            for c in w:
+                cur = cur.child.setdefault(int(c), self._N())
+
+    def get_child_index(self, cur):
+        return [self.eos] if not cur.child else list(cur.child.keys())
+
+    def get_next_node(self, cur, w):
+        return cur if not cur.child else cur.child.setdefault(int(w), self._N())
+
+
+def g9_inputs(z):
+    m = meta_of(z)
+    feats = [T(z["qa_features"])[i, :int(n)] for i, n in enumerate(z["qa_feat_lens"])]
+    words = [[int(c) for c in row if c >= 0] for row in z["trie_words"]]
+    return m, feats, _GoldTrie(words, m["eos"])
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_g9_generation_matches_reference_generate(tag):
+    """the oracle's cache-free greedy loop reproduces the token ids the reference's own generate() calls returned:
+    3dqa (free decoding, 6 new tokens) and summarization (trie-constrained, eos-terminated)."""
+    z = gold(f"g9_generate_{tag}.npz")
+    cfg, P = tiny_weights(tag)
+    m, feats, trie = g9_inputs(z)
+    with torch.no_grad():
+        qa = O.qa_3d_generate(P, cfg, feats, T(z["qa_input_ids"]), T(z["qa_attention_mask"]), max_new_tokens=6,
+                              eos_token_id=m["eos"], pad_token_id=m["pad"])
+        ps = O.scene_encoder(P, cfg, T(z["sum_view_img_fts"]), T(z["sum_view_lens"]), T(z["sum_loc_fts"]), T(z["sum_nav_types"]))
+        vp = torch.cat([torch.zeros_like(ps["pano_embeds"][:, :1]), ps["pano_embeds"]], 1)
+        hv = hist_lists(T(z["sum_hist_vis_flat"]), m["hist_t"])
+        sm = O.summarization_generate(P, cfg, vp, T(z["sum_vp_nav_masks"]), hv, T(z["sum_input_ids"]), T(z["sum_attention_mask"]),
+                                      max_new_tokens=50, eos_token_id=m["eos"], pad_token_id=m["pad"], trie=trie)
+    assert qa == z["qa_new_ids"].tolist(), (qa, z["qa_new_ids"].tolist())
+    assert sm == z["sum_new_ids"].tolist(), (sm, z["sum_new_ids"].tolist())
+
+
 def test_g8_clip_adamw():
     z = gold("g8_adamw.npz")
     ps = [T(z[f"p0_{i}"]) for i in range(3)]

@@ -193,6 +193,31 @@ def test_g5_summarization_and_fgr2r_losses_vs_reference():
     assert abs(float(o2["loss"]) - float(z["qa_loss"])) <= 0.04
 
 
+def test_g9_generation_vs_reference_generate():
+    """model('3dqa' | 'summarization', batch, training=False[, trie=...]) against the token ids the reference's own
+    generate() calls returned (fixture G9; bf16): K/V-cache greedy decoding, special-id mask, eos bookkeeping, trie."""
+    from test_oracle_golden import g9_inputs
+    z = gold("g9_generate_bf16.npz")
+    m = build(tiny_cfg("bf16"))
+    import types
+    meta, feats_cpu, trie = g9_inputs(z)
+    m.lang_model.tokenizer = types.SimpleNamespace(eos_token_id=meta["eos"], unk_token_id=meta["pad"])   # ids only: prompts are pre-tokenised
+    feats = [f.to(DEV) for f in feats_cpu]
+    B = len(feats)
+    with torch.no_grad():
+        qa = m("3dqa", dict(features=feats, question=["q"] * B, input_ids=T(z["qa_input_ids"]), attention_mask=T(z["qa_attention_mask"])),
+               training=False, do_sample=False, max_new_tokens=6)
+        pz = {k[4:]: v for k, v in z.items() if k.startswith("sum_")}
+        ps = m("panorama", pano_batch(pz))
+        vp = torch.cat([torch.zeros_like(ps["pano_embeds"][:, :1]), ps["pano_embeds"]], 1)
+        hv = hist_lists(dev(z["sum_hist_vis_flat"]), meta["hist_t"])
+        sm = m("summarization", dict(vp_img_embeds=vp, vp_nav_masks=T(z["sum_vp_nav_masks"]), instruction=["x"] * B, answer=[""] * B,
+                                     hist_vis=hv, data_type=["r2r"] * B, input_ids=T(z["sum_input_ids"]),
+                                     attention_mask=T(z["sum_attention_mask"])), training=False, trie=trie)
+    assert qa["generated_ids"] == z["qa_new_ids"].tolist(), (qa["generated_ids"], z["qa_new_ids"].tolist())
+    assert sm["generated_ids"] == z["sum_new_ids"].tolist(), (sm["generated_ids"], z["sum_new_ids"].tolist())
+
+
 def test_tokenizer_path_matches_fixture_ids():
     """drop-in tokenisation: the attached LlamaTokenizer reproduces the reference's ids."""
     import os
