@@ -42,6 +42,11 @@ int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* 
 size_t nv_gemm_bf16_workspace_bytes(void);
 int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
                     int ldb, int ldc, int ldr, int epilogue, int tile_cfg, void* workspace, void* stream);
+/*   Skinny form for the decode steps of generation (HF generate() reached from models/nav_model.py:324-341,388-402):
+ *   C[M<=16,N] = A[M,K] @ W[N,K]^T (+ R); a weight streamer (HBM-bound, N*K*2 bytes per launch); epilogue 0 = store,
+ *   2 = residual add with nv_gemm_bf16's rounding order; K % 32 == 0. */
+int nv_gemv_bf16(const void* A, const void* W, void* C, const void* R, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
+                 int epilogue, void* stream);
 
 /* ---- K6: embedding gather + visual-token add, models/modified_lm.py:100-110.
  *   out[m] = table[ids[m]]  or  bf16(f32(table[ids[m]]) + vis[vis_idx[m]])  when vis_idx[m] >= 0 */

@@ -79,6 +79,12 @@ def gemm_bf16(layout, A, B, out=None, R=None, epilogue=EPI_STORE, tile_cfg=0):
         _chk2d(R, BF16)
         assert tuple(R.shape) == (M, wide * N)
         ldr = R.stride(0)
+    if GEMV_DECODE and layout == NT and M <= 16 and epilogue in (EPI_STORE, EPI_RESID) and K % 32 == 0 and tile_cfg == 0:
+        # decode step of generation: a handful of token rows against a whole weight matrix -> weight-streaming kernel
+        rc = _L().nv_gemv_bf16(A.data_ptr(), B.data_ptr(), out.data_ptr(), _p(R), M, N, K, A.stride(0), B.stride(0), out.stride(0),
+                               ldr, epilogue, _st())
+        _lib.check(rc, "nv_gemv_bf16")
+        return out
     rc = _L().nv_gemm_bf16_ws(layout, A.data_ptr(), B.data_ptr(), out.data_ptr(), _p(R), M, N, K, A.stride(0), B.stride(0),
                               out.stride(0), ldr, epilogue, tile_cfg, _gemm_ws(A.device) if SPLITK_TAIL else 0, _st())
     _lib.check(rc, "nv_gemm_bf16_ws")
@@ -86,6 +92,7 @@ def gemm_bf16(layout, A, B, out=None, R=None, epilogue=EPI_STORE, tile_cfg=0):
 
 
 SPLITK_TAIL = True
+GEMV_DECODE = True      # M <= 16 NT GEMMs go to nv_gemv_bf16
 _gemm_ws_cache = {}
 
 

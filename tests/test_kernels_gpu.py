@@ -494,3 +494,26 @@ def test_gemm_swiglu_bwd_epilogue_equals_two_pass(M, ff, d, tile):
         assert torch.equal(got.view(torch.int16), want.view(torch.int16))
     else:
         assert_close(got, want.float(), 2 ** -7, 1e-3, "swiglu-bwd epilogue (fallback path)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,resid", [(8, 4096, 4096, False), (8, 1000, 256, True), (1, 22016, 4096, False), (16, 4112, 11008, True),
+                                         (3, 100, 64, False)])
+def test_gemv_bf16_matches_reference(M, N, K, resid):
+    """the decode-step weight streamer against a torch fp32 reference (and it is what ops.gemm_bf16 picks for M <= 16)"""
+    from navillm_amd import ops
+    x = rnd(M, K, dtype=BF, seed=95)
+    W = rnd(N, K, dtype=BF, seed=96, scale=0.05)
+    R = rnd(M, N, dtype=BF, seed=97) if resid else None
+    got = ops.gemm_bf16(ops.NT, x, W, R=R, epilogue=ops.EPI_RESID if resid else ops.EPI_STORE)
+    ref = x.float() @ W.float().t()
+    if resid:
+        ref = R.float() + ref.to(BF).float()
+    torch.cuda.synchronize()
+    assert_close(got, ref, 2 ** -7, 2e-3, f"gemv {M}x{N}x{K} resid={resid}")
+    ops.GEMV_DECODE = False
+    try:
+        big = ops.gemm_bf16(ops.NT, x, W, R=R, epilogue=ops.EPI_RESID if resid else ops.EPI_STORE)
+    finally:
+        ops.GEMV_DECODE = True
+    assert_close(got, big.float(), 2 ** -7, 2e-3, "gemv vs tiled gemm")
