@@ -550,7 +550,12 @@ class NavModel(nn.Module):
         inv[sel.long()] = torch.arange(sel.numel(), dtype=torch.int32)
         cand_vis = Fn.GatherRowsF32.apply(oe, ops.h2d(sel, dev), ops.h2d(inv, dev), None) if sel.numel() else None
         ids, am, _ = self._tokens(batch, batch["prompts"])
-        Hs_cls = self._lm(ids, am, cand_vis=cand_vis, hist_vis=self._stack_hist(batch["hist_vis"]), cls_tail=True)
+        if self.kv is not None and not torch.is_grad_enabled() and self.kv.B == B:
+            # the grounding prompt of the last step shares instruction + history with the navigation prompts before it
+            hk = [("hist", b, k, v.data_ptr()) for b, vis in enumerate(batch["hist_vis"]) for k, v in enumerate(vis)]
+            Hs_cls = self._lm_cached(ids, am, cand_vis=cand_vis, hist_vis=self._stack_hist(batch["hist_vis"]), hist_keys=hk)
+        else:
+            Hs_cls = self._lm(ids, am, cand_vis=cand_vis, hist_vis=self._stack_hist(batch["hist_vis"]), cls_tail=True)
         pred = Fn.HeadBF16.apply(Hs_cls, self, "out_head.0")
         dead = torch.arange(pred.shape[1])[None] >= cand_nums[:, None]
         return {"obj_logits": pred.masked_fill(ops.h2d(dead, dev), float("-inf"))}

@@ -164,7 +164,13 @@ def test_g5_object_grounding_and_qa_vs_reference():
         b = dict(obj_embeds=po["obj_embeds"], obj_masks=po["obj_masks"], obj_loc_fts=po["obj_loc_fts"], hist_vis=hv,
                  input_ids=T(z["input_ids"]), attention_mask=T(z["attention_mask"]), prompts=meta["prompts"])
         oo = m("object_grounding", b)
+        m.enable_kv_cache(len(hv))                      # the same call through the K/V-cache path (inference rollouts)
+        oc = m("object_grounding", b)
+        oc2 = m("object_grounding", b)                  # second call: everything up to the object tokens is reused
+        assert max(m.kv.last_stats["prefix"]) > 0
+        m.kv = None
     assert maxerr(oo["obj_logits"], z["obj_logits"]) < 1e-2
+    assert maxerr(oc["obj_logits"], z["obj_logits"]) < 1e-2 and maxerr(oc2["obj_logits"], z["obj_logits"]) < 1e-2
     q = gold("g5_qa_bf16.npz")
     feats = [dev(q["features"])[i, :int(n)] for i, n in enumerate(q["feat_lens"])]
     with torch.no_grad():
