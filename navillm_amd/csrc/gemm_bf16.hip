@@ -38,7 +38,7 @@ struct GemmArgs {
     int full_blocks, rem, split;
     float* slabs;           // [rem*split][BM*BN] fp32 partials
     unsigned* counters;     // [rem] arrival tickets, zero between launches
-    int debug;              // NV_GEMM_DEBUG (measurement only): bit0 skip the C stores, bit1 skip the K loop
+    int debug;              // NV_GEMM_DEBUG (measurement only): bit0 skip the C stores, bit1 skip the K loop, bit2 record clocks
     int items, persist;     // work items of the launch (tiles + tail K-slices); persistent-block mode on/off
 };
 
@@ -617,10 +617,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(1
 void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
+    unsigned long long c0 = 0, w0 = 0;
+    if (p.debug & 4) { c0 = __builtin_readcyclecounter(); w0 = wall_clock64(); }
     for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
         const bool first = item == (int)blockIdx.x;
         if (!first) __syncthreads();          // every wave is done with the LDS image of the previous tile's C
         gemm_tile<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI, PIPE>(p, item, first, smem);
+    }
+    // NV_GEMM_DEBUG bit 2 (measurement): block 0 leaves its core-clock cycles and 100 MHz wall ticks in the workspace
+    // (bytes 2048..2063) -> average shader clock of the launch = 0.1 GHz * cycles / ticks
+    if ((p.debug & 4) && blockIdx.x == 0 && threadIdx.x == 0 && p.counters) {
+        unsigned long long* o = (unsigned long long*)((char*)p.counters + 2048);
+        o[0] = __builtin_readcyclecounter() - c0;
+        o[1] = wall_clock64() - w0;
     }
 }
 

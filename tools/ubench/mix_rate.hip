@@ -24,6 +24,7 @@ __global__ __launch_bounds__(512) void k_mix(const char* A, const char* B, int K
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int tm = (xcd & 3) * 4 + (idx & 3), tn = (xcd >> 2) * 8 + (idx >> 2);
     const int KT = K / 64;
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     f32x4 acc[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -86,6 +87,11 @@ __global__ __launch_bounds__(512) void k_mix(const char* A, const char* B, int K
 #pragma unroll
     for (int i = 1; i < 32; ++i) s += acc[i];
     if (s[0] + s[1] + s[2] + s[3] == 12345.f) out[tid] = s[0];
+    if (blockIdx.x == 0 && tid == 0) {     // average shader clock over the kernel: core-clock counter vs the 100 MHz wall clock
+        const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+        ((unsigned long long*)out)[512] = c1 - c0;
+        ((unsigned long long*)out)[513] = w1 - w0;
+    }
 }
 template <typename F>
 static float time_ms(F launch) {
@@ -99,14 +105,15 @@ static float time_ms(F launch) {
 }
 int main() {
     char* buf; (void)hipMalloc(&buf, 2ull << 30); (void)hipMemset(buf, 0, 2ull << 30);
-    float* out; (void)hipMalloc(&out, 4096);
+    float* out; (void)hipMalloc(&out, 16384);
     const int K = 4096, iters = 2000;
     char *A = buf, *B = buf + (1ull << 30);
 #define RUN(DMA, RD, MMA, KEEP, BAR, label, ...)                                                                     \
     {                                                                                                              \
         (void)hipFuncSetAttribute((const void*)k_mix<DMA, RD, MMA, KEEP, BAR, ##__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
         float ms = time_ms([&] { hipLaunchKernelGGL((k_mix<DMA, RD, MMA, KEEP, BAR, ##__VA_ARGS__>), dim3(256), dim3(512), 131072, 0, A, B, K, iters, out); }); \
-        printf("%-44s %7.1f ns per K-step  (= %6.0f TF if it were a GEMM)\n", label, ms * 1e6 / iters, 256.0 * 2 * 256 * 256 * 64 / (ms * 1e6 / iters) / 1e3); \
+        unsigned long long ck[2]; (void)hipMemcpy(ck, (char*)out + 4096, 16, hipMemcpyDeviceToHost);                 \
+        printf("%-44s %7.1f ns per K-step  (= %6.0f TF if it were a GEMM)  shader clock %.2f GHz\n", label, ms * 1e6 / iters, 256.0 * 2 * 256 * 256 * 64 / (ms * 1e6 / iters) / 1e3, ck[1] ? 0.1 * ck[0] / ck[1] : 0.0); \
     }
     RUN(false, false, true, 0, false, "MFMA only (zero operands)")
     RUN(false, false, true, 0, false, "MFMA only (random operands)", true)
@@ -119,6 +126,7 @@ int main() {
     RUN(true, false, true, 1, true, "MFMA + DMA (1 step in flight) + barrier")
     RUN(true, true, false, 0, true, "ds_read + DMA (wait all) + barrier")
     RUN(true, true, true, 0, true, "MFMA + ds_read + DMA (wait all) + barrier")
+    RUN(true, true, true, 0, true, "MFMA + ds_read + DMA (wait all), random", true)
     RUN(true, true, true, 1, true, "MFMA + ds_read + DMA (1 in flight) + barrier")
     RUN(true, true, true, 1, false, "MFMA + ds_read + DMA (1 in flight), no barrier")
     return 0;
