@@ -125,6 +125,11 @@ int nv_adamw(void* p, const void* g, void* m, void* v, long n, int is_bf16, doub
  *      models/detr_transformer.py:170-182, models/nav_model.py:146-194 */
 int nv_gemm_f32(int layout, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                 int ldc, int accumulate, void* stream);
+/*   with a caller workspace: launches with few output tiles and a long K (the encoder's [288 x 1024] results) are split
+ *   into up to 8 K slices summed in slice order (deterministic) */
+size_t nv_gemm_f32_workspace_bytes(int M, int N);
+int nv_gemm_f32_ws(int layout, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                   int ldc, int accumulate, void* workspace, void* stream);
 int nv_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd, int M, int d,
                          float eps, void* stream);
 size_t nv_layernorm_bwd_workspace_bytes(int d);

@@ -19,6 +19,10 @@ struct GemmF32Args {
     long sam, sak, sbn, sbk;
     int ldc;
     int accumulate;   // C += result
+    // split-K (vector kernel only): blockIdx.z = K slice of `kchunk` (multiple of FBK); slices write raw partials to
+    // part[z][M][N] and splitk_reduce_f32_kernel adds them in slice order (+bias, +C) -- deterministic, no atomics
+    int ksplit, kchunk;
+    float* part;
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF32Args p) {
@@ -157,13 +161,15 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(GemmF32Args p, uint32
             }
         }
     };
-    gload(0);
+    const int kbeg = p.ksplit > 1 ? blockIdx.z * p.kchunk : 0;
+    const int kend = p.ksplit > 1 ? min(p.K, kbeg + p.kchunk) : p.K;
+    gload(kbeg);
     const int i16 = lane & 15, kq = lane >> 4;
-    for (int k0 = 0; k0 < p.K; k0 += FBK) {
+    for (int k0 = kbeg; k0 < kend; k0 += FBK) {
         __syncthreads();            // previous tile's LDS reads are done
         sstore();
         __syncthreads();
-        if (k0 + FBK < p.K) gload(k0 + FBK);   // in flight under the MFMAs below
+        if (k0 + FBK < kend) gload(k0 + FBK);   // in flight under the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < FBK; ks += 4) {
             float fa[2], fb[2];
@@ -190,10 +196,26 @@ __global__ __launch_bounds__(256) void gemm_f32_vec_kernel(GemmF32Args p, uint32
                 const int n = n0 + wn * 32 + i * 16 + g * 4 + r;
                 if (n >= p.N) continue;
                 float v = acc[i][j][r];
+                if (p.ksplit > 1) { p.part[((long)blockIdx.z * p.M + m) * p.N + n] = v; continue; }
                 if (p.bias) v += p.bias[n];
                 float* c = p.C + (long)m * p.ldc + n;
                 *c = p.accumulate ? (*c + v) : v;
             }
+    }
+}
+
+// C[m,n] (+)= bias[n] + sum_z part[z][m][n], slices added in order
+__global__ __launch_bounds__(256) void splitk_reduce_f32_kernel(const float* __restrict__ part, float* __restrict__ C,
+                                                                const float* __restrict__ bias, int M, int N, int ldc, int S,
+                                                                int accumulate) {
+    const long total = (long)M * N;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float v = 0.f;
+        for (int z = 0; z < S; ++z) v += part[(long)z * total + i];
+        if (bias) v += bias[n];
+        float* c = C + (long)m * ldc + n;
+        *c = accumulate ? (*c + v) : v;
     }
 }
 
@@ -452,12 +474,25 @@ inline int grid_for(long total, int cap = 256 * 8) {
 extern "C" {
 
 // layout 0: NT  A[M,K] B[N,K] ; 1: NN  A[M,K] B[K,N] ; 2: TN  A[K,M] B[K,N]
+size_t nv_gemm_f32_workspace_bytes(int M, int N) { return (size_t)8 * M * N * sizeof(float); }
+
+int nv_gemm_f32_ws(int layout, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                   int ldc, int accumulate, void* workspace, void* stream);
+
 int nv_gemm_f32(int layout, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                 int ldc, int accumulate, void* stream) {
+    return nv_gemm_f32_ws(layout, A, B, C, bias, M, N, K, lda, ldb, ldc, accumulate, nullptr, stream);
+}
+
+// with a workspace of nv_gemm_f32_workspace_bytes(M, N): launches that would leave most CUs idle (the encoder's
+// [288 x 1024] outputs are 80 tiles of 64x64) are cut into up to 8 K slices, reduced in slice order by a second kernel
+int nv_gemm_f32_ws(int layout, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                   int ldc, int accumulate, void* workspace, void* stream) {
     if (!A || !B || !C || M < 0 || N < 0 || K < 0) return NV_ERR_ARG;
     if (M == 0 || N == 0) return NV_OK;
     GemmF32Args p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.ldc = ldc; p.accumulate = accumulate;
+    p.ksplit = 1; p.kchunk = K; p.part = nullptr;
     switch (layout) {
         case 0: p.sam = lda; p.sak = 1; p.sbn = ldb; p.sbk = 1; break;
         case 1: p.sam = lda; p.sak = 1; p.sbn = 1; p.sbk = ldb; break;
@@ -473,9 +508,26 @@ int nv_gemm_f32(int layout, const float* A, const float* B, float* C, const floa
         const long a_rows = a_kc ? M : K, a_cols = a_kc ? K : M, b_rows = b_kc ? N : K, b_cols = b_kc ? K : N;
         const uint32_t ab = (uint32_t)(((a_rows - 1) * (long)lda + a_cols) * 4), bb = (uint32_t)(((b_rows - 1) * (long)ldb + b_cols) * 4);
         hipStream_t st = (hipStream_t)stream;
-        if (layout == 0) NV_LAUNCH((gemm_f32_vec_kernel<true, true>), grid, dim3(256), 0, st, p, ab, bb);
-        else if (layout == 1) NV_LAUNCH((gemm_f32_vec_kernel<true, false>), grid, dim3(256), 0, st, p, ab, bb);
-        else NV_LAUNCH((gemm_f32_vec_kernel<false, false>), grid, dim3(256), 0, st, p, ab, bb);
+        dim3 g3 = grid;
+        const int blocks = grid.x * grid.y, ktiles = (K + FBK - 1) / FBK;
+        if (workspace && blocks < 512 && ktiles >= 8) {
+            // aim at ~4 blocks per CU: these launches are latency-bound (one 64x64x32 step per barrier pair)
+            int S = (1024 + blocks - 1) / blocks;
+            if (S > 8) S = 8;
+            if (S > ktiles / 4) S = ktiles / 4;
+            if (S >= 2) {
+                p.kchunk = ((ktiles + S - 1) / S) * FBK;
+                p.ksplit = (K + p.kchunk - 1) / p.kchunk;
+                p.part = (float*)workspace;
+                g3.z = p.ksplit;
+            }
+        }
+        if (layout == 0) NV_LAUNCH((gemm_f32_vec_kernel<true, true>), g3, dim3(256), 0, st, p, ab, bb);
+        else if (layout == 1) NV_LAUNCH((gemm_f32_vec_kernel<true, false>), g3, dim3(256), 0, st, p, ab, bb);
+        else NV_LAUNCH((gemm_f32_vec_kernel<false, false>), g3, dim3(256), 0, st, p, ab, bb);
+        if (p.ksplit > 1)
+            NV_LAUNCH(splitk_reduce_f32_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, st, (const float*)p.part, C, bias, M, N, ldc,
+                      p.ksplit, accumulate);
         return nv_check_launch();
     }
     NV_LAUNCH(gemm_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);

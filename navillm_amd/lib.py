@@ -45,6 +45,8 @@ SIGNATURES = {
     "nv_clip_coef": (i, [fp, i, f, fp, vp]),
     "nv_adamw": (i, [vp, vp, vp, vp, l, i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i, fp, vp]),
     "nv_gemm_f32": (i, [i, fp, fp, fp, fp, i, i, i, i, i, i, i, vp]),
+    "nv_gemm_f32_workspace_bytes": (sz, [i, i]),
+    "nv_gemm_f32_ws": (i, [i, fp, fp, fp, fp, i, i, i, i, i, i, i, vp, vp]),
     "nv_layernorm_fwd_f32": (i, [fp, fp, fp, fp, fp, fp, i, i, f, vp]),
     "nv_layernorm_bwd_workspace_bytes": (sz, [i]),
     "nv_layernorm_bwd_f32": (i, [fp, fp, fp, fp, fp, fp, fp, fp, vp, i, i, i, vp]),

@@ -323,9 +323,10 @@ def gemm_f32(layout, A, B, bias=None, out=None, accumulate=False):
     if out is None:
         assert not accumulate
         out = torch.empty((M, N), dtype=F32, device=A.device)
-    rc = _L().nv_gemm_f32(layout, A.data_ptr(), B.data_ptr(), out.data_ptr(), _p(bias), M, N, K, A.stride(0), B.stride(0),
-                          out.stride(0), 1 if accumulate else 0, _st())
-    _lib.check(rc, "nv_gemm_f32")
+    ws = _workspace(_L().nv_gemm_f32_workspace_bytes(M, N), A.device, "gemm_f32") if M * N <= (1 << 22) else None
+    rc = _L().nv_gemm_f32_ws(layout, A.data_ptr(), B.data_ptr(), out.data_ptr(), _p(bias), M, N, K, A.stride(0), B.stride(0),
+                             out.stride(0), 1 if accumulate else 0, 0 if ws is None else ws.data_ptr(), _st())
+    _lib.check(rc, "nv_gemm_f32_ws")
     return out
 
 

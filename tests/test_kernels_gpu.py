@@ -366,7 +366,7 @@ def test_clip_and_adamw_match_oracle_sequence():
 
 # ------------------------------------------------------------------------------ fp32 encoder kernels
 @pytest.mark.parametrize("layout", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(288, 1024, 768), (100, 130, 7), (36, 256, 64), (65, 129, 33)])
+@pytest.mark.parametrize("M,N,K", [(288, 1024, 768), (100, 130, 7), (36, 256, 64), (65, 129, 33), (288, 1024, 4096), (200, 1024, 1000)])
 def test_gemm_f32(layout, M, N, K):
     from navillm_amd import ops
     if layout == 0:
