@@ -88,6 +88,16 @@ __device__ __forceinline__ void dma16_m0imm(const u32x4& desc, uint32_t lds_base
                  : "v"(voff), "s"(lds_base_uniform), "s"(desc), "n"(IMM), "s"(soff)
                  : "memory", "m0", "scc");
 }
+// The same in two halves, so that independent work (a group of MFMAs) can sit between the M0 write and the load that
+// consumes it instead of an s_nop: set_m0_imm<IMM>(base) ... dma16_m0set(desc, voff, soff).  Nothing else may write M0
+// in between (the GEMM main loop has no other M0 user).
+template <int IMM>
+__device__ __forceinline__ void set_m0_imm(uint32_t lds_base_uniform) {
+    asm volatile("s_add_u32 m0, %0, %1" : : "s"(lds_base_uniform), "n"(IMM) : "memory", "m0", "scc");
+}
+__device__ __forceinline__ void dma16_m0set(const u32x4& desc, uint32_t voff, uint32_t soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(desc), "s"(soff) : "memory");
+}
 #pragma clang diagnostic pop
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
