@@ -148,6 +148,8 @@ def main():
     from navillm_amd.parallel import init_distributed_device, NavDataParallel
     import torch.distributed as dist
     device, rank, world = init_distributed_device()
+    if world > 1:            # one process per GPU share the host: do not let every rank spin up all cores for its CPU-side ops
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     from navillm_amd import ops
     from navillm_amd.nav_model import NavModel
