@@ -47,6 +47,11 @@ int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C, const voi
  *   2 = residual add with nv_gemm_bf16's rounding order; K % 32 == 0. */
 int nv_gemv_bf16(const void* A, const void* W, void* C, const void* R, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                  int epilogue, void* stream);
+/*   packed q|k|v projection with RoPE (modified_lm.py:112-116 -> HF LlamaAttention) applied to the first rope_cols
+ *   columns in the GEMM epilogue: position of row m = m % S; tables as nv_rope_bf16. Bit-identical to
+ *   nv_gemm_bf16(NT) + nv_rope_bf16. */
+int nv_gemm_bf16_rope(const void* A, const void* W, void* C, const void* rope_cos, const void* rope_sin, int M, int N, int K,
+                      int lda, int ldw, int ldc, int S, int rope_cols, void* workspace, void* stream);
 
 /* ---- K6: embedding gather + visual-token add, models/modified_lm.py:100-110.
  *   out[m] = table[ids[m]]  or  bf16(f32(table[ids[m]]) + vis[vis_idx[m]])  when vis_idx[m] >= 0 */

@@ -24,7 +24,7 @@
 
 namespace {
 
-enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_RESID = 2, EPI_BIAS = 3, EPI_SWIGLU_BWD = 4 };
+enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_RESID = 2, EPI_BIAS = 3, EPI_SWIGLU_BWD = 4, EPI_ROPE = 5 };
 
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; bf16_t* C;
@@ -40,6 +40,9 @@ struct GemmArgs {
     unsigned* counters;     // [rem] arrival tickets, zero between launches
     int debug;              // NV_GEMM_DEBUG (measurement only): bit0 skip the C stores, bit1 skip the K loop, bit2 record clocks
     int items, persist;     // work items of the launch (tiles + tail K-slices); persistent-block mode on/off
+    // EPI_ROPE (packed q|k|v projection): rotate the q and k columns (n < rope_cols) as they are written; position of row
+    // m is m % rope_S; R = cos table, rope_sin = sin table, both [maxS][128] bf16 as nv_rope_bf16 takes them
+    const bf16_t* rope_sin; int rope_S, rope_cols;
 };
 
 // ---- LDS images (BKT = K extent of a stage, 64 or 32) -----------------------------------
@@ -522,6 +525,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     static_assert(BM * BN * 2 <= NSTAGE * (BM + BN) * BKT * 2, "C tile image must fit in the stage buffers");
     const bool staged = ((p.ldc & 7) == 0) && ((p.N & 7) == 0) && ((((uintptr_t)p.C) & 15) == 0) &&
                         ((EPI != EPI_RESID && EPI != EPI_SWIGLU_BWD) || (((p.ldr & 7) == 0) && ((((uintptr_t)p.R) & 15) == 0))) &&
+                        (EPI != EPI_ROPE || (BN % 128 == 0)) &&
                         (EPI != EPI_BIAS || ((((uintptr_t)p.R) & 7) == 0));
     if (staged) {
         __syncthreads();                                  // every wave is done with the operand stages
@@ -562,6 +566,30 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
                     for (int q = 0; q < 4; ++q)
                         t[q] = pack2bf(__uint_as_float(rr[q] << 16) + __uint_as_float(t[q] << 16),
                                        __uint_as_float(rr[q] & 0xffff0000u) + __uint_as_float(t[q] & 0xffff0000u));
+                }
+                if (EPI == EPI_ROPE) {
+                    // head_dim 128, rotate-half: column c of a head pairs with c +- 64 -- the same row of the LDS image
+                    // (a 256-wide tile holds two whole heads).  Arithmetic = rope_kernel (lm_rowops.hip), bit for bit.
+                    if (n < p.rope_cols) {
+                        const int c = n & 127;                         // 8 columns c .. c+7 inside one half
+                        const bool lo = c < 64;
+                        const int pc16 = (c16 + (lo ? 8 : -8));         // partner 16-B slot (64 columns away)
+                        const u32x4 pr = *(LDS_PTR(u32x4))(smem + ml * (BN * 2) + ((pc16 ^ (ml & 15)) << 4));
+                        const int pos = m % p.rope_S;
+                        const u32x4 cw = *(const u32x4*)(p.R + (long)pos * 128 + (c & 63));
+                        const u32x4 sw = *(const u32x4*)(p.rope_sin + (long)pos * 128 + (c & 63));
+                        const float sgn = lo ? -1.f : 1.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float x0 = __uint_as_float(t[q] << 16), x1 = __uint_as_float(t[q] & 0xffff0000u);
+                            const float y0 = __uint_as_float(pr[q] << 16), y1 = __uint_as_float(pr[q] & 0xffff0000u);
+                            const float c0 = __uint_as_float(cw[q] << 16), c1 = __uint_as_float(cw[q] & 0xffff0000u);
+                            const float s0 = __uint_as_float(sw[q] << 16), s1 = __uint_as_float(sw[q] & 0xffff0000u);
+                            t[q] = pack2bf(rbf(x0 * c0) + rbf(sgn * y0 * s0), rbf(x1 * c1) + rbf(sgn * y1 * s1));
+                        }
+                    }
+                    *(u32x4*)cp = t;
+                    continue;
                 }
                 if (EPI == EPI_SWIGLU_BWD) {
                     // C = d(gate|up) [M, 2N]: the tile's dh never goes to HBM; gate/up come in 16 B per lane like a residual
@@ -688,8 +716,8 @@ int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
     }
     switch (tile_cfg) {
         case 1: return launch<128, 128, 2, 2, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
-        case 3: if constexpr (EPI != EPI_SWIGLU_BWD) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st); else return NV_ERR_ARG;
-        case 6: if constexpr (EPI != EPI_SWIGLU_BWD) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 1>(p, st); else return NV_ERR_ARG;   // software-pipelined fragments
+        case 3: if constexpr (EPI != EPI_SWIGLU_BWD && EPI != EPI_ROPE) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st); else return NV_ERR_ARG;
+        case 6: if constexpr (EPI != EPI_SWIGLU_BWD && EPI != EPI_ROPE) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 1>(p, st); else return NV_ERR_ARG;   // software-pipelined fragments
         case 8: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4>(p, st);   // hand-interleaved phases
     }
     return NV_ERR_ARG;
@@ -702,6 +730,12 @@ int dispatch_epi(const GemmArgs& p, int epi, int tile_cfg, hipStream_t st) {
         case EPI_ACCUM: return dispatch_tile<A_KMAJ, B_KMAJ, EPI_ACCUM>(p, tile_cfg, st);
         case EPI_RESID: return dispatch_tile<A_KMAJ, B_KMAJ, EPI_RESID>(p, tile_cfg, st);
         case EPI_BIAS: return dispatch_tile<A_KMAJ, B_KMAJ, EPI_BIAS>(p, tile_cfg, st);
+        case EPI_ROPE:            // only the packed q|k|v projection uses it: NT layout, production tiles, staged epilogue
+            if constexpr (A_KMAJ && B_KMAJ) {
+                if (tile_cfg == 3 || tile_cfg == 6) return NV_ERR_ARG;
+                return dispatch_tile<A_KMAJ, B_KMAJ, EPI_ROPE>(p, tile_cfg, st);
+            }
+            return NV_ERR_ARG;
         case EPI_SWIGLU_BWD:      // only the down-proj dgrad uses it: NN layout, production tiles
             if constexpr (A_KMAJ && !B_KMAJ) {
                 if (tile_cfg == 3 || tile_cfg == 6) return NV_ERR_ARG;
@@ -727,12 +761,12 @@ extern "C" size_t nv_gemm_bf16_workspace_bytes() { return (size_t)256 * 256 * 25
 
 // workspace: nv_gemm_bf16_workspace_bytes() bytes, ZERO-FILLED once by the caller (the kernel leaves its
 // ticket words zero again); NULL disables the split-K tail.
-extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
-                               int lda, int ldb, int ldc, int ldr, int epilogue, int tile_cfg, void* workspace,
-                               void* stream) {
+static int gemm_entry(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb,
+                      int ldc, int ldr, int epilogue, int tile_cfg, void* workspace, void* stream, const void* rope_sin, int rope_S,
+                      int rope_cols) {
     if (!A || !B || !C || M < 0 || N < 0 || K < 0) return NV_ERR_ARG;
     if (M == 0 || N == 0) return NV_OK;
-    if ((epilogue == EPI_RESID || epilogue == EPI_BIAS || epilogue == EPI_SWIGLU_BWD) && !R) return NV_ERR_ARG;
+    if ((epilogue == EPI_RESID || epilogue == EPI_BIAS || epilogue == EPI_SWIGLU_BWD || epilogue == EPI_ROPE) && !R) return NV_ERR_ARG;
     if ((lda & 7) || (ldb & 7)) return NV_ERR_SHAPE;                 // 16-B aligned rows for the DMA
     if ((((uintptr_t)A) | ((uintptr_t)B)) & 15) return NV_ERR_SHAPE;
     GemmArgs p;
@@ -741,6 +775,7 @@ extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C
     p.counters = (unsigned*)workspace;
     p.slabs = workspace ? (float*)((char*)workspace + 4096) : nullptr;
     p.full_blocks = 0; p.rem = 1; p.split = 1;
+    p.rope_sin = (const bf16_t*)rope_sin; p.rope_S = rope_S; p.rope_cols = rope_cols;
     {
         // tuning / measurement knobs, read once per process
         static const int env_debug = [] { const char* e = getenv("NV_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
@@ -768,6 +803,23 @@ extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C
             return dispatch_epi<false, false>(p, epilogue, tile_cfg, st);
     }
     return NV_ERR_ARG;
+}
+
+extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K,
+                               int lda, int ldb, int ldc, int ldr, int epilogue, int tile_cfg, void* workspace,
+                               void* stream) {
+    if (epilogue == EPI_ROPE) return NV_ERR_ARG;             // has its own entry point (needs the tables)
+    return gemm_entry(layout, A, B, C, R, M, N, K, lda, ldb, ldc, ldr, epilogue, tile_cfg, workspace, stream, nullptr, 1, 0);
+}
+
+// y = x W^T for the packed q|k|v projection with RoPE applied to the first `rope_cols` columns (q and k) in the epilogue:
+// row m has position m % S; cos/sin = nv_rope_bf16's [maxS][128] bf16 tables (head_dim 128).  Bit-identical to
+// nv_gemm_bf16(NT) followed by nv_rope_bf16; saves one read+write pass over q and k.
+extern "C" int nv_gemm_bf16_rope(const void* A, const void* W, void* C, const void* rope_cos, const void* rope_sin, int M, int N,
+                                 int K, int lda, int ldw, int ldc, int S, int rope_cols, void* workspace, void* stream) {
+    if (!rope_cos || !rope_sin || S <= 0 || rope_cols < 0 || rope_cols > N || (rope_cols & 127)) return NV_ERR_ARG;
+    if ((ldc & 7) || (N & 7) || (((uintptr_t)C) & 15) || ((((uintptr_t)rope_cos) | ((uintptr_t)rope_sin)) & 15)) return NV_ERR_SHAPE;
+    return gemm_entry(0, A, W, C, rope_cos, M, N, K, lda, ldw, ldc, 0, EPI_ROPE, 0, workspace, stream, rope_sin, S, rope_cols);
 }
 
 extern "C" int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K,

@@ -12,6 +12,8 @@ F32, BF16 = torch.float32, torch.bfloat16
 # 38.71/38.82 nav-steps/s -- the epilogue's exp/divide work is serialised behind each tile's K loop with the CU's MFMA
 # idle, while the separate HBM-bound kernel hides next to the wgrad GEMM of the other stream.  Off by default.
 FUSE_SWIGLU_BWD = os.environ.get("NAVILLM_FUSE_SWIGLU_BWD", "0") == "1"
+# RoPE applied in the q|k|v projection's GEMM epilogue (bit-identical to the separate in-place pass; A/B knob)
+FUSE_ROPE_FWD = os.environ.get("NAVILLM_FUSE_ROPE_FWD", "1") != "0"
 
 
 def _c(t):
@@ -331,8 +333,11 @@ class LlamaStack(torch.autograd.Function):
             p = f"lang_model.model.layers.{i}."
             a = ar.layers[i]
             n1, rstd1 = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps, out=a["n1"][:M], rstd=a["rstd1"][:M])
-            qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i), out=a["qkv"][:M])
-            ops.rope_(qkv, model.rope_cos, model.rope_sin, S, H, hd)
+            if FUSE_ROPE_FWD and M > 16:
+                qkv = ops.gemm_qkv_rope(n1, st.qkv(i), model.rope_cos, model.rope_sin, S, 2 * H * hd, out=a["qkv"][:M])
+            else:
+                qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i), out=a["qkv"][:M])
+                ops.rope_(qkv, model.rope_cos, model.rope_sin, S, H, hd)
             attn, lse = ops.attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=a["attn"][:M], lse2=a["lse"][:M * H].view(B, H, S))
             x1 = ops.gemm_bf16(ops.NT, attn, st.p(p + "self_attn.o_proj.weight"), out=a["x1"][:M], R=x, epilogue=ops.EPI_RESID)
             n2, rstd2 = ops.rmsnorm_fwd(x1, st.p(p + "post_attention_layernorm.weight"), eps, out=a["n2"][:M],
@@ -347,8 +352,11 @@ class LlamaStack(torch.autograd.Function):
             a = ar.layers[i]
             qmin = ((S - 1) // 128) * 128
             n1, _ = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps, out=a["n1"][:M], rstd=a["rstd1"][:M])
-            qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i), out=a["qkv"][:M])
-            ops.rope_(qkv, model.rope_cos, model.rope_sin, S, H, hd)
+            if FUSE_ROPE_FWD and M > 16:
+                qkv = ops.gemm_qkv_rope(n1, st.qkv(i), model.rope_cos, model.rope_sin, S, 2 * H * hd, out=a["qkv"][:M])
+            else:
+                qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i), out=a["qkv"][:M])
+                ops.rope_(qkv, model.rope_cos, model.rope_sin, S, H, hd)
             attn, _ = ops.attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=a["attn"][:M], lse2=a["lse"][:M * H].view(B, H, S),
                                    q_row_min=qmin)
             attn_r = ops.gather_rows_bf16(attn, tail_rows)

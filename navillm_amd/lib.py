@@ -18,6 +18,7 @@ SIGNATURES = {
     "nv_gemm_bf16": (i, [i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp]),
     "nv_gemm_bf16_workspace_bytes": (sz, []),
     "nv_gemm_bf16_ws": (i, [i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp, vp]),
+    "nv_gemm_bf16_rope": (i, [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp, vp]),
     "nv_gemv_bf16": (i, [vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp]),
     "nv_embed_vis_bf16": (i, [vp, ip, ip, fp, vp, i, i, vp]),
     "nv_vis_grad_f32": (i, [vp, ip, fp, i, i, vp]),

@@ -91,6 +91,20 @@ def gemm_bf16(layout, A, B, out=None, R=None, epilogue=EPI_STORE, tile_cfg=0):
     return out
 
 
+def gemm_qkv_rope(x, Wqkv, cos_t, sin_t, S, rope_cols, out=None):
+    """packed q|k|v = x @ Wqkv^T with RoPE on the first `rope_cols` columns applied in the GEMM epilogue (row m at position m % S)"""
+    _chk2d(x, BF16)
+    _chk2d(Wqkv, BF16)
+    M, K = x.shape
+    N = Wqkv.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=x.device)
+    rc = _L().nv_gemm_bf16_rope(x.data_ptr(), Wqkv.data_ptr(), out.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), M, N, K, x.stride(0),
+                                Wqkv.stride(0), out.stride(0), S, rope_cols, _gemm_ws(x.device) if SPLITK_TAIL else 0, _st())
+    _lib.check(rc, "nv_gemm_bf16_rope")
+    return out
+
+
 SPLITK_TAIL = True
 GEMV_DECODE = True      # M <= 16 NT GEMMs go to nv_gemv_bf16
 _gemm_ws_cache = {}

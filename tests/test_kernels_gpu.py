@@ -517,3 +517,24 @@ def test_gemv_bf16_matches_reference(M, N, K, resid):
     finally:
         ops.GEMV_DECODE = True
     assert_close(got, big.float(), 2 ** -7, 2e-3, "gemv vs tiled gemm")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S,H,d_in", [(2, 333, 2, 256), (8, 656, 8, 1024), (3, 100, 1, 128)])
+def test_gemm_rope_epilogue_equals_two_pass(B, S, H, d_in):
+    """q|k|v projection with RoPE in the GEMM epilogue == GEMM followed by the in-place RoPE pass, bit for bit (ragged M
+    tiles, both tile sizes, v columns untouched)."""
+    from navillm_amd import ops
+    hd = 128
+    M, N = B * S, 3 * H * hd
+    x = rnd(M, d_in, dtype=BF, seed=110)
+    W = rnd(N, d_in, dtype=BF, seed=111, scale=0.05)
+    pos = torch.arange(2048, device=dev(), dtype=torch.float32)
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev(), dtype=torch.float32) / hd))
+    emb = torch.cat([torch.outer(pos, inv)] * 2, -1)
+    cos_t, sin_t = emb.cos().to(BF).contiguous(), emb.sin().to(BF).contiguous()
+    want = ops.gemm_bf16(ops.NT, x, W)
+    ops.rope_(want, cos_t, sin_t, S, H, hd)
+    got = ops.gemm_qkv_rope(x, W, cos_t, sin_t, S, 2 * H * hd)
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
