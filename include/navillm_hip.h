@@ -48,10 +48,11 @@ int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C, const voi
 int nv_gemv_bf16(const void* A, const void* W, void* C, const void* R, int M, int N, int K, int lda, int ldw, int ldc, int ldr,
                  int epilogue, void* stream);
 /*   packed q|k|v projection with RoPE (modified_lm.py:112-116 -> HF LlamaAttention) applied to the first rope_cols
- *   columns in the GEMM epilogue: position of row m = m % S; tables as nv_rope_bf16. Bit-identical to
+ *   columns in the GEMM epilogue: position of row m = pos[m] (int32, packed rows) or, with pos == NULL, m % S; tables as
+ *   nv_rope_bf16. Bit-identical to
  *   nv_gemm_bf16(NT) + nv_rope_bf16. */
-int nv_gemm_bf16_rope(const void* A, const void* W, void* C, const void* rope_cos, const void* rope_sin, int M, int N, int K,
-                      int lda, int ldw, int ldc, int S, int rope_cols, void* workspace, void* stream);
+int nv_gemm_bf16_rope(const void* A, const void* W, void* C, const void* rope_cos, const void* rope_sin, const int* pos, int M,
+                      int N, int K, int lda, int ldw, int ldc, int S, int rope_cols, void* workspace, void* stream);
 
 /* ---- K6: embedding gather + visual-token add, models/modified_lm.py:100-110.
  *   out[m] = table[ids[m]]  or  bf16(f32(table[ids[m]]) + vis[vis_idx[m]])  when vis_idx[m] >= 0 */
@@ -97,6 +98,15 @@ int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_star
  *   sample b's rows start at b*S_stride in qkv, out and lse2; S = longest valid length. */
 int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, int B, int S, int S_stride, int H,
                              int head_dim, int q_row_min, void* stream);
+/*   Packed ("varlen") rows: sample b = rows [cu[b], cu[b+1]) (cu: int32 [B+1], device), S_max = longest sample, lse2
+ *   [B,H,S_max]; no padding keys; pos0[b] = position of the sample's first token (the reference numbers positions over
+ *   its left padding) -- read only by the backward's fused RoPE^T.  q_row_min >= 0 as above, -1 =
+ *   each sample's own last 128-row block.  The LM then never computes the left-padding rows of a batch. */
+int nv_attn_fwd_varlen_bf16(const void* qkv, void* out, float* lse2, const int* cu, const int* pos0, int B, int S_max, int H,
+                            int head_dim, int q_row_min, void* stream);
+int nv_attn_bwd_varlen_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* cu, const int* pos0,
+                            void* dqkv, void* workspace, const void* rope_cos, const void* rope_sin, int B, int S_max, long rows,
+                            int H, int head_dim, int q_row_min, void* stream);
 size_t nv_attn_bwd_workspace_bytes(int B, int S, int H);
 int nv_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
                      void* workspace, int B, int S, int H, int head_dim, int q_row_min, void* stream);

@@ -114,10 +114,15 @@ __device__ __forceinline__ void store_grad_row(bf16_t* dst, const f32x4 (&v)[8],
     }
 }
 
+struct Seq { long row0; int S, kvs, pos0, qmin; };
+
 struct AttnArgs {
     const bf16_t* qkv; bf16_t* out; float* lse2;        // fwd
     const bf16_t* dout; const float* dsum; bf16_t* dqkv; // bwd
     const int* kv_start;
+    const int* cu;         // packed ("varlen") rows: sample b = rows [cu[b], cu[b+1]); nullptr = padded [B, S] layout.  Packed
+                           // samples have no padding keys: kv_start[b] is then only the POSITION of the sample's first token
+                           // (the reference numbers positions over its left padding), used by the fused RoPE^T
     int B, S, H, ld;       // ld = 3*H*HD (qkv row stride), out row stride = H*HD
     int Sst;               // rows between consecutive samples in qkv/out/lse2 (= S, or a KV cache's capacity >= S)
     int q_row_min;         // only queries >= q_row_min are computed / differentiated (multiple of 128; 0 = all)
@@ -125,6 +130,22 @@ struct AttnArgs {
     float scale;           // head_dim^-0.5
     const bf16_t* rope_cos; const bf16_t* rope_sin;   // backward only, optional: apply RoPE^T to dQ/dK as they are written
 };
+
+// where sample b lives, how long it is, which keys are padding, its first position, and the first query row computed
+// (q_row_min >= 0: that row for every sample; -1: each sample's own last 128-row block -- the pruned last layer)
+__device__ __forceinline__ Seq seq_of(const AttnArgs& p, int b) {
+    Seq s;
+    if (p.cu) {
+        const int r0 = p.cu[b];
+        s.row0 = r0; s.S = p.cu[b + 1] - r0; s.kvs = 0; s.pos0 = p.kv_start[b];
+    } else {
+        s.row0 = (long)b * p.Sst; s.S = p.S; s.kvs = p.kv_start[b]; s.pos0 = 0;
+    }
+    s.qmin = p.q_row_min >= 0 ? p.q_row_min : ((s.S - 1) / 128) * 128;
+    return s;
+}
+__device__ __forceinline__ int lse_stride(const AttnArgs& p) { return p.cu ? p.S : p.Sst; }
+
 
 // =========================================================================== forward
 // grid (ceil(S/128), B*H), 256 threads: wave w owns queries q0 + w*32 .. +31 (two 16-query tiles)
@@ -136,11 +157,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     // grid (B*H, query blocks): x walks the heads, y the query blocks from the LAST one down -- causal work grows with the
     // query index, so the long blocks are dispatched first and the short ones fill the tail of the launch
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
-    const int S = p.S, ld = p.ld;
-    const int q0 = p.q_row_min + (gridDim.y - 1 - blockIdx.y) * 128;
-    const int kvs = p.kv_start[b];
+    const Seq sq = seq_of(p, b);
+    const int S = sq.S, ld = p.ld;
+    const int q0 = sq.qmin + (gridDim.y - 1 - blockIdx.y) * 128;
+    if (q0 >= S) return;                                       // packed rows: a shorter sample has fewer query blocks
+    const int kvs = sq.kvs;
     const int qi = lane & 15, g = lane >> 4;
-    const bf16_t* base = p.qkv + (long)b * p.Sst * ld;
+    const bf16_t* base = p.qkv + sq.row0 * ld;
     const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
     const u32x4 rs = make_desc(base, span);
     const int kcol = p.H * HD + h * HD, vcol = 2 * p.H * HD + h * HD;
@@ -262,24 +285,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
         const bool valid = qpos[j] < S;
         const float inv = lt > 0.f ? 1.f / lt : 0.f;
         if (valid) {
-            bf16_t* op = p.out + ((long)b * p.Sst + qpos[j]) * (p.H * HD) + h * HD + g * 4;
+            bf16_t* op = p.out + (sq.row0 + qpos[j]) * (p.H * HD) + h * HD + g * 4;
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
                 u32x2 w = {pack2bf(o[dt][j][0] * inv, o[dt][j][1] * inv), pack2bf(o[dt][j][2] * inv, o[dt][j][3] * inv)};
                 *(u32x2*)(op + dt * 16) = w;
             }
-            if (g == 0) p.lse2[((long)b * p.H + h) * p.Sst + qpos[j]] = lt > 0.f ? m2[j] + log2f(lt) : INFINITY;
+            if (g == 0) p.lse2[((long)b * p.H + h) * lse_stride(p) + qpos[j]] = lt > 0.f ? m2[j] + log2f(lt) : INFINITY;
         }
     }
 }
 
 // =========================================================================== backward prep
 // dsum[b,h,q] = sum_d dO[q,d] * O[q,d]   (16 lanes per (row, head): 16-B loads, 4 items per wave)
+// rows = B*S (padded layout) or cu[B] (packed layout: the sample of a row is found by walking cu, B is small)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
-                                                            float* __restrict__ dsum, int B, int S, int H) {
+                                                            float* __restrict__ dsum, const int* __restrict__ cu, long rows, int B,
+                                                            int S, int H) {
     const int sub = threadIdx.x & 15;
     const long item = (long)blockIdx.x * 16 + (threadIdx.x >> 4);   // (row, head)
-    const bool live = item < (long)B * S * H;
+    const bool live = item < rows * H;
     const long row = live ? item / H : 0;
     const int h = live ? (int)(item % H) : 0;
     const u32x4 av = *(const u32x4*)(dout + row * (H * HD) + h * HD + sub * 8);
@@ -292,7 +317,14 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if (live && sub == 0) {
-        const int bb = (int)(row / S), s = (int)(row % S);
+        int bb, s;
+        if (cu) {
+            bb = 0;
+            while (bb + 1 < B && row >= cu[bb + 1]) ++bb;
+            s = (int)(row - cu[bb]);
+        } else {
+            bb = (int)(row / S); s = (int)(row % S);
+        }
         dsum[((long)bb * H + h) * S + s] = v;
     }
 }
@@ -307,18 +339,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
     constexpr int TILE = 32 * ROWB;  // 8 KiB per Q or dO tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;      // grid (B*H, key blocks): key block 0 (all queries) goes first
-    const int S = p.S, ld = p.ld;
+    const Seq sq = seq_of(p, b);
+    const int S = sq.S, ld = p.ld;
     const int kblk = blockIdx.y * 64 * KW;
-    const int kvs = p.kv_start[b];
+    if (kblk >= S) return;
+    const int kvs = sq.kvs;
     const int ki = lane & 15, g = lane >> 4;
-    const bf16_t* base = p.qkv + (long)b * S * ld;
+    const bf16_t* base = p.qkv + sq.row0 * ld;
     const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
     const u32x4 rq = make_desc(base, span);
     const int od = p.H * HD;
-    const bf16_t* dobase = p.dout + (long)b * S * od;
+    const bf16_t* dobase = p.dout + sq.row0 * od;
     const u32x4 rdo = make_desc(dobase, (uint32_t)(((long)(S - 1) * od + od) * 2));
-    const float* lse2 = p.lse2 + ((long)b * p.H + h) * S;
-    const float* dsum = p.dsum + ((long)b * p.H + h) * S;
+    const float* lse2 = p.lse2 + ((long)b * p.H + h) * lse_stride(p);
+    const float* dsum = p.dsum + ((long)b * p.H + h) * lse_stride(p);
 
     // K and V fragments (B operand: j = key, k = head dim) from HBM
     bf16x8 kf[KW][4], vf[KW][4];
@@ -342,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         for (int dt = 0; dt < 8; ++dt) { dv[jk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[jk][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     // queries that can see this key block: q >= kblk (causal), q >= kvs (pad queries have p=0 anyway)
-    const int qt_lo = p.q_row_min / 32;
+    const int qt_lo = sq.qmin / 32;
     const int qt_beg = kblk / 32 > qt_lo ? kblk / 32 : qt_lo, qt_end = (S - 1) / 32;
     auto stage = [&](int qt, int buf) {
         stage_rows<32, 256>(rq, smem + buf * 2 * TILE, qt * 32, h * HD, ld, tid);
@@ -438,10 +472,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
     for (int jk = 0; jk < KW; ++jk)
         if (key[jk] < S) {
-            bf16_t* kp = p.dqkv + ((long)b * S + key[jk]) * ld + p.H * HD + h * HD + g * 4;
-            bf16_t* vp = p.dqkv + ((long)b * S + key[jk]) * ld + 2 * p.H * HD + h * HD + g * 4;
-            store_grad_row(kp, dk[jk], p.scale, p.rope_cos ? p.rope_cos + (long)key[jk] * HD + g * 4 : nullptr,
-                           p.rope_sin ? p.rope_sin + (long)key[jk] * HD + g * 4 : nullptr);
+            bf16_t* kp = p.dqkv + (sq.row0 + key[jk]) * ld + p.H * HD + h * HD + g * 4;
+            bf16_t* vp = p.dqkv + (sq.row0 + key[jk]) * ld + 2 * p.H * HD + h * HD + g * 4;
+            store_grad_row(kp, dk[jk], p.scale, p.rope_cos ? p.rope_cos + (long)(key[jk] + sq.pos0) * HD + g * 4 : nullptr,
+                           p.rope_sin ? p.rope_sin + (long)(key[jk] + sq.pos0) * HD + g * 4 : nullptr);
             store_grad_row(vp, dv[jk], 1.f, nullptr, nullptr);
         }
 }
@@ -455,11 +489,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
     constexpr int TILE = 64 * ROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;      // grid (B*H, query blocks), last (longest) query block first
-    const int S = p.S, ld = p.ld;
-    const int q0 = p.q_row_min + (gridDim.y - 1 - blockIdx.y) * 64 * QW;
-    const int kvs = p.kv_start[b];
+    const Seq sq = seq_of(p, b);
+    const int S = sq.S, ld = p.ld;
+    const int q0 = sq.qmin + (gridDim.y - 1 - blockIdx.y) * 64 * QW;
+    if (q0 >= S) return;
+    const int kvs = sq.kvs;
     const int qi = lane & 15, g = lane >> 4;
-    const bf16_t* base = p.qkv + (long)b * S * ld;
+    const bf16_t* base = p.qkv + sq.row0 * ld;
     const uint32_t span = (uint32_t)(((long)(S - 1) * ld + 3 * p.H * HD) * 2);
     const u32x4 rs = make_desc(base, span);
     const int od = p.H * HD;
@@ -473,14 +509,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         q[j] = q0 + (wave * QW + j) * 16 + qi;
         const int ql = q[j] < S ? q[j] : S - 1;
         const bf16_t* qp = base + (long)ql * ld + h * HD + g * 8;
-        const bf16_t* dp_ = p.dout + ((long)b * S + ql) * od + h * HD + g * 8;
+        const bf16_t* dp_ = p.dout + (sq.row0 + ql) * od + h * HD + g * 8;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             qf[j][kk] = *(const bf16x8*)(qp + kk * 32);
             dof[j][kk] = *(const bf16x8*)(dp_ + kk * 32);
         }
-        my_lse[j] = p.lse2[((long)b * p.H + h) * S + ql];
-        my_ds[j] = p.dsum[((long)b * p.H + h) * S + ql];
+        my_lse[j] = p.lse2[((long)b * p.H + h) * lse_stride(p) + ql];
+        my_ds[j] = p.dsum[((long)b * p.H + h) * lse_stride(p) + ql];
     }
     f32x4 dq[QW][8];
 #pragma unroll
@@ -566,9 +602,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 #pragma unroll
     for (int j = 0; j < QW; ++j)
         if (q[j] < S) {
-            bf16_t* qp = p.dqkv + ((long)b * S + q[j]) * ld + h * HD + g * 4;
-            store_grad_row(qp, dq[j], p.scale, p.rope_cos ? p.rope_cos + (long)q[j] * HD + g * 4 : nullptr,
-                           p.rope_sin ? p.rope_sin + (long)q[j] * HD + g * 4 : nullptr);
+            bf16_t* qp = p.dqkv + (sq.row0 + q[j]) * ld + h * HD + g * 4;
+            store_grad_row(qp, dq[j], p.scale, p.rope_cos ? p.rope_cos + (long)(q[j] + sq.pos0) * HD + g * 4 : nullptr,
+                           p.rope_sin ? p.rope_sin + (long)(q[j] + sq.pos0) * HD + g * 4 : nullptr);
         }
 }
 
@@ -612,14 +648,34 @@ int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int*
     return nv_check_launch();
 }
 
+// Packed ("varlen") rows: sample b = rows [cu[b], cu[b+1]) of qkv / out (cu: int32 [B+1] on the device), S_max = the
+// longest sample (lse2 is [B,H,S_max]); no padding keys exist, pos0[b] = position of the sample's first token (only the
+// backward's fused RoPE^T reads it).  q_row_min >= 0 as above, or -1: each sample's own last 128-row block (pruned last
+// decoder layer).  Removes the left-padding rows of a batch from every row kernel and GEMM of the LM.
+int nv_attn_fwd_varlen_bf16(const void* qkv, void* out, float* lse2, const int* cu, const int* pos0, int B, int S_max, int H,
+                            int head_dim, int q_row_min, void* stream) {
+    if (!qkv || !out || !lse2 || !cu || !pos0) return NV_ERR_ARG;
+    if (head_dim != HD || (q_row_min >= 0 && (q_row_min & 127)) || q_row_min < -1 || (S_max > 0 && q_row_min >= S_max)) return NV_ERR_SHAPE;
+    if (B == 0 || S_max == 0) return NV_OK;
+    static bool once = false;
+    if (!once) { if (set_lds((const void*)attn_fwd_kernel, 65536)) return NV_ERR_LAUNCH; once = true; }
+    AttnArgs p{};
+    p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = pos0; p.cu = cu;
+    p.B = B; p.S = S_max; p.Sst = S_max; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
+    p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
+    const int qblocks = q_row_min < 0 ? 1 : (S_max - q_row_min + 127) / 128;
+    NV_LAUNCH(attn_fwd_kernel, dim3(B * H, qblocks), dim3(256), 65536, (hipStream_t)stream, p);
+    return nv_check_launch();
+}
+
 // dsum: workspace [B,H,S] fp32 (nv_attn_bwd_workspace_bytes)
 size_t nv_attn_bwd_workspace_bytes(int B, int S, int H) { return (size_t)B * S * H * sizeof(float); }
 
 static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
                          void* workspace, int B, int S, int H, int head_dim, int q_row_min, const void* rope_cos,
-                         const void* rope_sin, void* stream) {
+                         const void* rope_sin, void* stream, const int* cu = nullptr, long rows = -1) {
     if (!qkv || !out || !dout || !lse2 || !kv_start || !dqkv || !workspace) return NV_ERR_ARG;
-    if (head_dim != HD || (q_row_min & 127) || q_row_min < 0 || (S > 0 && q_row_min >= S)) return NV_ERR_SHAPE;
+    if (head_dim != HD || (q_row_min >= 0 && (q_row_min & 127)) || q_row_min < (cu ? -1 : 0) || (S > 0 && q_row_min >= S)) return NV_ERR_SHAPE;
     if ((rope_cos == nullptr) != (rope_sin == nullptr)) return NV_ERR_ARG;
     if (B == 0 || S == 0) return NV_OK;
     // measurement/test knob: 1 (default) = 16 rows per wave, 2 = 32 rows per wave.  Measured at B=8, S=656, H=32: the
@@ -636,22 +692,23 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
     }
     hipStream_t st = (hipStream_t)stream;
     float* dsum = (float*)workspace;
-    const long items = (long)B * S * H;
+    if (rows < 0) rows = (long)B * S;
+    const long items = rows * H;
     NV_LAUNCH(attn_bwd_prep_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, (const bf16_t*)dout,
-                       (const bf16_t*)out, dsum, B, S, H);
+                       (const bf16_t*)out, dsum, cu, rows, B, S, H);
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.lse2 = (float*)lse2; p.dsum = dsum; p.dqkv = (bf16_t*)dqkv;
-    p.kv_start = kv_start; p.B = B; p.S = S; p.Sst = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
+    p.kv_start = kv_start; p.cu = cu; p.B = B; p.S = S; p.Sst = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
     p.rope_cos = (const bf16_t*)rope_cos; p.rope_sin = (const bf16_t*)rope_sin;
     // with q_row_min > 0 only those query rows carry gradient: dK/dV still cover every key, dQ rows below
     // q_row_min are NOT written (the caller zero-fills them)
     if (variant == 1) {
         NV_LAUNCH(attn_bwd_dkv_kernel<1>, dim3(B * H, (S + 63) / 64), dim3(256), 49152, st, p);
-        NV_LAUNCH(attn_bwd_dq_kernel<1>, dim3(B * H, (S - q_row_min + 63) / 64), dim3(256), 65536, st, p);
+        NV_LAUNCH(attn_bwd_dq_kernel<1>, dim3(B * H, q_row_min < 0 ? 2 : (S - q_row_min + 63) / 64), dim3(256), 65536, st, p);
     } else {
         NV_LAUNCH(attn_bwd_dkv_kernel<2>, dim3(B * H, (S + 127) / 128), dim3(256), 49152, st, p);
-        NV_LAUNCH(attn_bwd_dq_kernel<2>, dim3(B * H, (S - q_row_min + 127) / 128), dim3(256), 65536, st, p);
+        NV_LAUNCH(attn_bwd_dq_kernel<2>, dim3(B * H, q_row_min < 0 ? 1 : (S - q_row_min + 127) / 128), dim3(256), 65536, st, p);
     }
     return nv_check_launch();
 }
@@ -668,6 +725,15 @@ int nv_attn_bwd_rope_bf16(const void* qkv, const void* out, const void* dout, co
                           int q_row_min, void* stream) {
     if (!rope_cos || !rope_sin) return NV_ERR_ARG;
     return attn_bwd_impl(qkv, out, dout, lse2, kv_start, dqkv, workspace, B, S, H, head_dim, q_row_min, rope_cos, rope_sin, stream);
+}
+
+// backward over packed rows (see nv_attn_fwd_varlen_bf16); rope_cos/rope_sin optional (both or neither); `rows` = cu[B]
+int nv_attn_bwd_varlen_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* cu, const int* pos0,
+                            void* dqkv, void* workspace, const void* rope_cos, const void* rope_sin, int B, int S_max, long rows,
+                            int H, int head_dim, int q_row_min, void* stream) {
+    if (!cu || rows < 0) return NV_ERR_ARG;
+    return attn_bwd_impl(qkv, out, dout, lse2, pos0, dqkv, workspace, B, S_max, H, head_dim, q_row_min, rope_cos, rope_sin, stream, cu,
+                         rows);
 }
 
 }  // extern "C"

@@ -43,6 +43,7 @@ struct GemmArgs {
     // EPI_ROPE (packed q|k|v projection): rotate the q and k columns (n < rope_cols) as they are written; position of row
     // m is m % rope_S; R = cos table, rope_sin = sin table, both [maxS][128] bf16 as nv_rope_bf16 takes them
     const bf16_t* rope_sin; int rope_S, rope_cols;
+    const int* rope_pos;    // optional: position of row m (packed rows); nullptr -> m % rope_S
 };
 
 // ---- LDS images (BKT = K extent of a stage, 64 or 32) -----------------------------------
@@ -575,7 +576,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
                         const bool lo = c < 64;
                         const int pc16 = (c16 + (lo ? 8 : -8));         // partner 16-B slot (64 columns away)
                         const u32x4 pr = *(LDS_PTR(u32x4))(smem + ml * (BN * 2) + ((pc16 ^ (ml & 15)) << 4));
-                        const int pos = m % p.rope_S;
+                        const int pos = p.rope_pos ? p.rope_pos[m] : m % p.rope_S;
                         const u32x4 cw = *(const u32x4*)(p.R + (long)pos * 128 + (c & 63));
                         const u32x4 sw = *(const u32x4*)(p.rope_sin + (long)pos * 128 + (c & 63));
                         const float sgn = lo ? -1.f : 1.f;
@@ -763,7 +764,7 @@ extern "C" size_t nv_gemm_bf16_workspace_bytes() { return (size_t)256 * 256 * 25
 // ticket words zero again); NULL disables the split-K tail.
 static int gemm_entry(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda, int ldb,
                       int ldc, int ldr, int epilogue, int tile_cfg, void* workspace, void* stream, const void* rope_sin, int rope_S,
-                      int rope_cols) {
+                      int rope_cols, const int* rope_pos = nullptr) {
     if (!A || !B || !C || M < 0 || N < 0 || K < 0) return NV_ERR_ARG;
     if (M == 0 || N == 0) return NV_OK;
     if ((epilogue == EPI_RESID || epilogue == EPI_BIAS || epilogue == EPI_SWIGLU_BWD || epilogue == EPI_ROPE) && !R) return NV_ERR_ARG;
@@ -775,7 +776,7 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
     p.counters = (unsigned*)workspace;
     p.slabs = workspace ? (float*)((char*)workspace + 4096) : nullptr;
     p.full_blocks = 0; p.rem = 1; p.split = 1;
-    p.rope_sin = (const bf16_t*)rope_sin; p.rope_S = rope_S; p.rope_cols = rope_cols;
+    p.rope_sin = (const bf16_t*)rope_sin; p.rope_S = rope_S; p.rope_cols = rope_cols; p.rope_pos = rope_pos;
     {
         // tuning / measurement knobs, read once per process
         static const int env_debug = [] { const char* e = getenv("NV_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
@@ -813,13 +814,15 @@ extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C
 }
 
 // y = x W^T for the packed q|k|v projection with RoPE applied to the first `rope_cols` columns (q and k) in the epilogue:
-// row m has position m % S; cos/sin = nv_rope_bf16's [maxS][128] bf16 tables (head_dim 128).  Bit-identical to
+// row m has position pos[m] (pos != NULL: packed rows) or m % S; cos/sin = nv_rope_bf16's [maxS][128] bf16 tables.  Bit-identical to
 // nv_gemm_bf16(NT) followed by nv_rope_bf16; saves one read+write pass over q and k.
-extern "C" int nv_gemm_bf16_rope(const void* A, const void* W, void* C, const void* rope_cos, const void* rope_sin, int M, int N,
-                                 int K, int lda, int ldw, int ldc, int S, int rope_cols, void* workspace, void* stream) {
-    if (!rope_cos || !rope_sin || S <= 0 || rope_cols < 0 || rope_cols > N || (rope_cols & 127)) return NV_ERR_ARG;
+extern "C" int nv_gemm_bf16_rope(const void* A, const void* W, void* C, const void* rope_cos, const void* rope_sin, const int* pos,
+                                 int M, int N, int K, int lda, int ldw, int ldc, int S, int rope_cols, void* workspace,
+                                 void* stream) {
+    if (!rope_cos || !rope_sin || (!pos && S <= 0) || rope_cols < 0 || rope_cols > N || (rope_cols & 127)) return NV_ERR_ARG;
     if ((ldc & 7) || (N & 7) || (((uintptr_t)C) & 15) || ((((uintptr_t)rope_cos) | ((uintptr_t)rope_sin)) & 15)) return NV_ERR_SHAPE;
-    return gemm_entry(0, A, W, C, rope_cos, M, N, K, lda, ldw, ldc, 0, EPI_ROPE, 0, workspace, stream, rope_sin, S, rope_cols);
+    return gemm_entry(0, A, W, C, rope_cos, M, N, K, lda, ldw, ldc, 0, EPI_ROPE, 0, workspace, stream, rope_sin, S > 0 ? S : 1, rope_cols,
+                      pos);
 }
 
 extern "C" int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K,

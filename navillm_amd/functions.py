@@ -316,29 +316,46 @@ class LlamaStack(torch.autograd.Function):
     live in the model's ActivationArena."""
 
     @staticmethod
-    def forward(ctx, E, model, B, S, kv_start_i32, tail_rows=None):
+    def forward(ctx, E, model, B, S, kv_start_i32, tail_rows=None, packed=None):
         """tail_rows (int32 device tensor, one row per sample, each the LAST position of its sample) switches on
         the pruned last layer: only those rows are consumed downstream (nav_model.py:237 reads the <cls_1> row), so
         after the last layer's K/V projection everything -- attention queries, o_proj, MLP, final norm -- is
         computed for B rows instead of B*S.  Returns [B, d] then.  (Same spirit as skipping lm_head in navigation
-        mode: work the reference does and never reads.)"""
+        mode: work the reference does and never reads.)
+
+        packed = (cu_i32 [B+1], pos_i32 [M], S_max): E holds only the REAL tokens of the batch, sample b in rows
+        [cu[b], cu[b+1]) (the left-padding rows of the reference's [B, S] layout are never materialised: they feed nothing,
+        every row kernel and GEMM here is row-wise, and attention masks them anyway); pos = each row's position in the
+        reference's frame (it numbers positions over the padding), kv_start = position of each sample's first token."""
         cfg, st, ar = model.cfg, model.store, model.arena
         H, hd, eps = cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps
-        M = B * S
-        ar.reserve(M)
+        M = E.shape[0]
+        cu, pos, Sm = packed if packed is not None else (None, None, S)
+        ar.reserve(max(M, B * Sm))
         ar.generation += 1
         x = E
+
+        def qkv_proj(n1, i, a):
+            if FUSE_ROPE_FWD and M > 16:
+                return ops.gemm_qkv_rope(n1, st.qkv(i), model.rope_cos, model.rope_sin, S, 2 * H * hd, out=a["qkv"][:M], pos_i32=pos)
+            qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i), out=a["qkv"][:M])
+            if pos is not None:
+                return ops.rope_rows_(qkv, model.rope_cos, model.rope_sin, pos, H, hd)
+            return ops.rope_(qkv, model.rope_cos, model.rope_sin, S, H, hd)
+
+        def attention(qkv, a, qmin):
+            lse = a["lse"][:B * H * Sm].view(B, H, Sm)
+            if cu is not None:
+                return ops.attn_fwd_varlen(qkv, cu, kv_start_i32, B, Sm, H, hd, out=a["attn"][:M], lse2=lse, q_row_min=qmin)
+            return ops.attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=a["attn"][:M], lse2=lse, q_row_min=max(qmin, 0))
+
         L_full = cfg.num_layers - (1 if tail_rows is not None else 0)
         for i in range(L_full):
             p = f"lang_model.model.layers.{i}."
             a = ar.layers[i]
             n1, rstd1 = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps, out=a["n1"][:M], rstd=a["rstd1"][:M])
-            if FUSE_ROPE_FWD and M > 16:
-                qkv = ops.gemm_qkv_rope(n1, st.qkv(i), model.rope_cos, model.rope_sin, S, 2 * H * hd, out=a["qkv"][:M])
-            else:
-                qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i), out=a["qkv"][:M])
-                ops.rope_(qkv, model.rope_cos, model.rope_sin, S, H, hd)
-            attn, lse = ops.attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=a["attn"][:M], lse2=a["lse"][:M * H].view(B, H, S))
+            qkv = qkv_proj(n1, i, a)
+            attn, lse = attention(qkv, a, 0)
             x1 = ops.gemm_bf16(ops.NT, attn, st.p(p + "self_attn.o_proj.weight"), out=a["x1"][:M], R=x, epilogue=ops.EPI_RESID)
             n2, rstd2 = ops.rmsnorm_fwd(x1, st.p(p + "post_attention_layernorm.weight"), eps, out=a["n2"][:M],
                                         rstd=a["rstd2"][:M])
@@ -350,15 +367,11 @@ class LlamaStack(torch.autograd.Function):
             i = cfg.num_layers - 1
             p = f"lang_model.model.layers.{i}."
             a = ar.layers[i]
-            qmin = ((S - 1) // 128) * 128
+            # padded layout: every sample ends at row S-1 -> one global first query row; packed: per sample (-1)
+            qmin = -1 if cu is not None else ((S - 1) // 128) * 128
             n1, _ = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps, out=a["n1"][:M], rstd=a["rstd1"][:M])
-            if FUSE_ROPE_FWD and M > 16:
-                qkv = ops.gemm_qkv_rope(n1, st.qkv(i), model.rope_cos, model.rope_sin, S, 2 * H * hd, out=a["qkv"][:M])
-            else:
-                qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i), out=a["qkv"][:M])
-                ops.rope_(qkv, model.rope_cos, model.rope_sin, S, H, hd)
-            attn, _ = ops.attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=a["attn"][:M], lse2=a["lse"][:M * H].view(B, H, S),
-                                   q_row_min=qmin)
+            qkv = qkv_proj(n1, i, a)
+            attn, _ = attention(qkv, a, qmin)
             attn_r = ops.gather_rows_bf16(attn, tail_rows)
             x_r = ops.gather_rows_bf16(x, tail_rows)
             x1_r = ops.gemm_bf16(ops.NT, attn_r, st.p(p + "self_attn.o_proj.weight"), R=x_r, epilogue=ops.EPI_RESID)
@@ -369,7 +382,7 @@ class LlamaStack(torch.autograd.Function):
             ctx.tail = (tail_rows, qmin, attn_r, x1_r, rstd2_r, n2_r, gu_r, h_r, x)
         Hs, rstdf = ops.rmsnorm_fwd(x, st.p("lang_model.model.norm.weight"), eps)
         ctx.model, ctx.E, ctx.rstdf = model, E, rstdf
-        ctx.dims = (B, S, kv_start_i32)
+        ctx.dims = (B, S, kv_start_i32, packed, M)
         ctx.generation = ar.generation
         return Hs
 
@@ -380,8 +393,15 @@ class LlamaStack(torch.autograd.Function):
         if ctx.generation != ar.generation:
             raise RuntimeError("the LM activation arena was reused by a later forward before this backward ran; "
                                "call backward() right after each loss (as the rollout loop does)")
-        B, S, kvs = ctx.dims
-        M = B * S
+        B, S, kvs, packed, M = ctx.dims
+        cu, pos, Sm = packed if packed is not None else (None, None, S)
+        rope = (model.rope_cos, model.rope_sin)
+
+        def attention_bwd(qkv, attn, dattn, lse, dqkv, qmin):
+            if cu is not None:
+                return ops.attn_bwd_varlen(qkv, attn, dattn, lse, cu, kvs, B, Sm, H, hd, dqkv, q_row_min=qmin, rope=rope)
+            return ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd, dqkv=dqkv, q_row_min=max(qmin, 0), rope=rope)
+
         H, hd, L = cfg.num_heads, cfg.head_dim, cfg.num_layers
         sc = {k: v[:M] for k, v in ar.scratch.items()}
         model._dp_begin_backward()
@@ -395,7 +415,7 @@ class LlamaStack(torch.autograd.Function):
             a = ar.layers[i]
             x = ctx.E if i == 0 else ar.layers[i - 1]["x2"][:M]
             n1, qkv, attn = a["n1"][:M], a["qkv"][:M], a["attn"][:M]
-            lse = a["lse"][:M * H].view(B, H, S)
+            lse = a["lse"][:B * H * Sm].view(B, H, Sm)
             dx2_r = ops.rmsnorm_bwd(_c(dH), x2_r, st.p("lang_model.model.norm.weight"), ctx.rstdf,
                                     st.g("lang_model.model.norm.weight"))
             dh_r = ops.gemm_bf16(ops.NN, dx2_r, st.p(p + "mlp.down_proj.weight"))
@@ -412,7 +432,7 @@ class LlamaStack(torch.autograd.Function):
             ops.scatter_rows_bf16_(dattn_r, rows, dattn)
             dqkv = sc["dqkv"]
             dqkv.zero_()                       # dQ rows below qmin are not written by the kernel
-            ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd, dqkv=dqkv, q_row_min=qmin, rope=(model.rope_cos, model.rope_sin))
+            attention_bwd(qkv, attn, dattn, lse, dqkv, qmin)
             dn1 = ops.gemm_bf16(ops.NN, dqkv, st.qkv(i), out=sc["dn1"])
             ops.gemm_bf16(ops.TN, dqkv, n1, out=st.qkv(i, grad=True), epilogue=ops.EPI_ACCUM)
             resid = sc["dx1"]
@@ -462,7 +482,7 @@ class LlamaStack(torch.autograd.Function):
             a = ar.layers[i]
             x = ctx.E if i == 0 else ar.layers[i - 1]["x2"][:M]
             n1, qkv, attn, x1, n2, gu, h = (a[k][:M] for k in ("n1", "qkv", "attn", "x1", "n2", "gu", "h"))
-            lse = a["lse"][:M * H].view(B, H, S)
+            lse = a["lse"][:B * H * Sm].view(B, H, Sm)
             Wd, Wo = st.p(p + "mlp.down_proj.weight"), st.p(p + "self_attn.o_proj.weight")
             if FUSE_SWIGLU_BWD:
                 # dh = dx @ Wd never reaches HBM: the dgrad GEMM's epilogue applies SwiGLU' and writes d(gate|up) directly
@@ -482,7 +502,7 @@ class LlamaStack(torch.autograd.Function):
             dattn = ops.gemm_bf16(ops.NN, dx1, Wo, out=sc["dattn"])
             ev.append(wgrad("dx1", dx1, attn, st.g(p + "self_attn.o_proj.weight")))
             before_write("dqkv")
-            dqkv = ops.attn_bwd(qkv, attn, dattn, lse, kvs, B, S, H, hd, dqkv=sc["dqkv"], rope=(model.rope_cos, model.rope_sin))
+            dqkv = attention_bwd(qkv, attn, dattn, lse, sc["dqkv"], 0)
             dn1 = ops.gemm_bf16(ops.NN, dqkv, st.qkv(i), out=sc["dn1"])
             ev.append(wgrad("dqkv", dqkv, n1, st.qkv(i, grad=True)))
             before_write(nxt_name)
@@ -494,7 +514,7 @@ class LlamaStack(torch.autograd.Function):
         out = dx.clone()
         if side is not None:
             main.wait_stream(side)      # weight gradients complete before anything downstream (optimizer, next forward)
-        return out, None, None, None, None, None
+        return out, None, None, None, None, None, None
 
 
 class GatherRowsBF16(torch.autograd.Function):

@@ -18,7 +18,7 @@ SIGNATURES = {
     "nv_gemm_bf16": (i, [i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp]),
     "nv_gemm_bf16_workspace_bytes": (sz, []),
     "nv_gemm_bf16_ws": (i, [i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp, vp]),
-    "nv_gemm_bf16_rope": (i, [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp, vp]),
+    "nv_gemm_bf16_rope": (i, [vp, vp, vp, vp, vp, ip, i, i, i, i, i, i, i, i, vp, vp]),
     "nv_gemv_bf16": (i, [vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp]),
     "nv_embed_vis_bf16": (i, [vp, ip, ip, fp, vp, i, i, vp]),
     "nv_vis_grad_f32": (i, [vp, ip, fp, i, i, vp]),
@@ -35,6 +35,8 @@ SIGNATURES = {
     "nv_scatter_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
     "nv_attn_fwd_bf16": (i, [vp, vp, fp, ip, i, i, i, i, i, vp]),
     "nv_attn_fwd_strided_bf16": (i, [vp, vp, fp, ip, i, i, i, i, i, i, vp]),
+    "nv_attn_fwd_varlen_bf16": (i, [vp, vp, fp, ip, ip, i, i, i, i, i, vp]),
+    "nv_attn_bwd_varlen_bf16": (i, [vp, vp, vp, fp, ip, ip, vp, vp, vp, vp, i, i, l, i, i, i, vp]),
     "nv_attn_bwd_workspace_bytes": (sz, [i, i, i]),
     "nv_attn_bwd_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, i, vp]),
     "nv_attn_bwd_rope_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, vp, vp, i, i, i, i, i, vp]),

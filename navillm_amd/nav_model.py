@@ -129,6 +129,8 @@ class NavModel(nn.Module):
         self.arena = Fn.ActivationArena(cfg, self.device)
         self.overlap_wgrad = os.environ.get("NAVILLM_OVERLAP_WGRAD", "0") == "1"   # wgrad GEMMs on a side stream (A/B knob)
         self.prune_last_layer = True     # navigation/grounding: last decoder layer computed for the <cls_1> rows only
+        self.pack_rows = os.environ.get("NAVILLM_PACK_ROWS", "1") != "0"   # LM over the real tokens only (no left-padding rows)
+        self._row_map = None
         self.kv = None                   # KVCacheLM (enable_kv_cache): prefix reuse across no-grad navigation steps + generation
         self._wgrad_stream = None
         self._dp = None
@@ -352,12 +354,32 @@ class NavModel(nn.Module):
         return tok["input_ids"], tok["attention_mask"], tok.get("token_type_ids")
 
     def _lm(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None, cls_tail=False):
-        """-> hidden states [B*S, d] bf16 (post final RMSNorm); with cls_tail and every <cls_1> at the last position
-        (always true for the left-padded navigation / grounding prompts): only those B rows, [B, d]."""
+        """-> hidden states (post final RMSNorm), bf16.  Rows: with `pack_rows` (default) only the REAL tokens of the batch,
+        sample after sample (`self._row_map` = their indices in the reference's flattened [B*S] layout; the left-padding
+        rows are never computed); otherwise all B*S rows.  With cls_tail and every <cls_1> at the last position (always
+        true for the left-padded navigation / grounding prompts): only those B rows, [B, d]."""
         cfg = self.cfg
         B, S = ids_cpu.shape
+        am = am_cpu.bool()
+        kv_start = (am.int().cumsum(1) == 0).sum(1).to(torch.int32)
+        assert bool((am == (torch.arange(S)[None] >= kv_start[:, None])).all()), "attention_mask must be left padding"
+        packed = None
+        self._row_map = None
         flat = ids_cpu.reshape(-1)
-        vis_idx = torch.full((B * S,), -1, dtype=torch.int32)
+        if self.pack_rows:
+            keep = torch.nonzero(am.reshape(-1)).view(-1)
+            lens = am.sum(1)
+            cu = torch.zeros(B + 1, dtype=torch.int32)
+            cu[1:] = lens.cumsum(0).to(torch.int32)
+            pos = torch.arange(S, dtype=torch.int32)[None].expand(B, S).reshape(-1)[keep]
+            flat = flat[keep]
+            self._row_map = keep
+            packed = (ops.h2d(cu, self.device), ops.h2d(pos.contiguous(), self.device), int(lens.max()))
+            last_rows = cu[1:].to(torch.int32) - 1
+        else:
+            last_rows = torch.arange(B, dtype=torch.int32) * S + (S - 1)
+        M = flat.numel()
+        vis_idx = torch.full((M,), -1, dtype=torch.int32)
         parts, rows, off = [], [], 0
         for tok_id, vis in ((cfg.cand_token_id, cand_vis), (cfg.hist_token_id, hist_vis), (cfg.obj_token_id, obj_vis)):
             loc = torch.nonzero(flat == tok_id).view(-1)
@@ -371,18 +393,15 @@ class NavModel(nn.Module):
             off += loc.numel()
         vis_all = torch.cat(parts, 0).contiguous() if parts else None
         vis_rows = ops.h2d(torch.cat(rows), self.device) if rows else None
-        am = am_cpu.bool()
-        kv_start = (am.int().cumsum(1) == 0).sum(1).to(torch.int32)
-        assert bool((am == (torch.arange(S)[None] >= kv_start[:, None])).all()), "attention_mask must be left padding"
         E = Fn.EmbedVis.apply(vis_all, self._anchor if torch.is_grad_enabled() else None, self,
                               ops.h2d(flat, self.device, torch.int32), ops.h2d(vis_idx, self.device), vis_rows, flat)
         tail = None
         if cls_tail and self.prune_last_layer and bool((ids_cpu[:, -1] == cfg.cls_token_ids[0]).all()) \
                 and int((ids_cpu == cfg.cls_token_ids[0]).sum()) == B:
-            tail = ops.h2d(torch.arange(B, dtype=torch.int32) * S + (S - 1), self.device)
-        Hs = Fn.LlamaStack.apply(E, self, B, S, ops.h2d(kv_start, self.device), tail)
+            tail = ops.h2d(last_rows, self.device)
+        Hs = Fn.LlamaStack.apply(E, self, B, S, ops.h2d(kv_start, self.device), tail, packed)
         if cls_tail and tail is None:
-            Hs = Fn.GatherRowsBF16.apply(Hs, self._cls_rows(ids_cpu))
+            Hs = Fn.GatherRowsBF16.apply(Hs, self._cls_rows(flat))
         return Hs
 
     def _vis_layout(self, ids_cpu, am_cpu, cand_vis, hist_vis, obj_vis, hist_keys=None):
@@ -447,15 +466,19 @@ class NavModel(nn.Module):
         shift = torch.full((B, S), -100, dtype=torch.int64)
         shift[:, :-1] = labels_cpu[:, 1:]
         n_valid = int((shift != -100).sum())
-        return Fn.LMHeadLoss.apply(Hs, self, ops.h2d(shift.view(-1), self.device, torch.int32), n_valid)
+        shift = shift.view(-1)
+        if self._row_map is not None:          # Hs holds the real tokens only (see _lm); a padding row never carries a label
+            assert int((shift[self._row_map] != -100).sum()) == n_valid
+            shift = shift[self._row_map]
+        return Fn.LMHeadLoss.apply(Hs, self, ops.h2d(shift.contiguous(), self.device, torch.int32), n_valid)
 
     @staticmethod
     def _stack_hist(hist_vis):
         flat = [v for vis in hist_vis for v in vis]
         return torch.stack(flat, 0) if flat else None
 
-    def _cls_rows(self, ids_cpu):
-        loc = torch.nonzero(ids_cpu.reshape(-1) == self.cfg.cls_token_ids[0]).view(-1)
+    def _cls_rows(self, flat_ids_cpu):
+        loc = torch.nonzero(flat_ids_cpu.reshape(-1) == self.cfg.cls_token_ids[0]).view(-1)
         return ops.h2d(loc, self.device, torch.int32)
 
     # ------------------------------------------------------------------ navigation (nav_model.py:129-247)

@@ -91,16 +91,17 @@ def gemm_bf16(layout, A, B, out=None, R=None, epilogue=EPI_STORE, tile_cfg=0):
     return out
 
 
-def gemm_qkv_rope(x, Wqkv, cos_t, sin_t, S, rope_cols, out=None):
-    """packed q|k|v = x @ Wqkv^T with RoPE on the first `rope_cols` columns applied in the GEMM epilogue (row m at position m % S)"""
+def gemm_qkv_rope(x, Wqkv, cos_t, sin_t, S, rope_cols, out=None, pos_i32=None):
+    """packed q|k|v = x @ Wqkv^T with RoPE on the first `rope_cols` columns applied in the GEMM epilogue; row m sits at position
+    pos_i32[m] (packed rows) or m % S"""
     _chk2d(x, BF16)
     _chk2d(Wqkv, BF16)
     M, K = x.shape
     N = Wqkv.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=x.device)
-    rc = _L().nv_gemm_bf16_rope(x.data_ptr(), Wqkv.data_ptr(), out.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), M, N, K, x.stride(0),
-                                Wqkv.stride(0), out.stride(0), S, rope_cols, _gemm_ws(x.device) if SPLITK_TAIL else 0, _st())
+    rc = _L().nv_gemm_bf16_rope(x.data_ptr(), Wqkv.data_ptr(), out.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), _p(pos_i32), M, N, K,
+                                x.stride(0), Wqkv.stride(0), out.stride(0), S, rope_cols, _gemm_ws(x.device) if SPLITK_TAIL else 0, _st())
     _lib.check(rc, "nv_gemm_bf16_rope")
     return out
 
@@ -244,6 +245,23 @@ def attn_fwd_strided(qkv, kv_start_i32, B, S, S_stride, H, hd, out, lse2, q_row_
                                        hd, q_row_min, _st())
     _lib.check(rc, "nv_attn_fwd_strided_bf16")
     return out
+
+
+def attn_fwd_varlen(qkv, cu_i32, pos0_i32, B, S_max, H, hd, out, lse2, q_row_min=0):
+    """packed rows: sample b = rows [cu[b], cu[b+1]); q_row_min = -1: each sample's last 128-row block only"""
+    rc = _L().nv_attn_fwd_varlen_bf16(qkv.data_ptr(), out.data_ptr(), lse2.data_ptr(), cu_i32.data_ptr(), pos0_i32.data_ptr(), B, S_max, H,
+                                      hd, q_row_min, _st())
+    _lib.check(rc, "nv_attn_fwd_varlen_bf16")
+    return out, lse2
+
+
+def attn_bwd_varlen(qkv, out, dout, lse2, cu_i32, pos0_i32, B, S_max, H, hd, dqkv, q_row_min=0, rope=None):
+    ws = _workspace(_L().nv_attn_bwd_workspace_bytes(B, S_max, H), qkv.device, "attn")
+    rc = _L().nv_attn_bwd_varlen_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse2.data_ptr(), cu_i32.data_ptr(),
+                                      pos0_i32.data_ptr(), dqkv.data_ptr(), ws.data_ptr(), _p(rope[0] if rope else None),
+                                      _p(rope[1] if rope else None), B, S_max, qkv.shape[0], H, hd, q_row_min, _st())
+    _lib.check(rc, "nv_attn_bwd_varlen_bf16")
+    return dqkv
 
 
 def attn_bwd(qkv, out, dout, lse2, kv_start_i32, B, S, H, hd, dqkv=None, q_row_min=0, rope=None):

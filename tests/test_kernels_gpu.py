@@ -538,3 +538,56 @@ def test_gemm_rope_epilogue_equals_two_pass(B, S, H, d_in):
     got = ops.gemm_qkv_rope(x, W, cos_t, sin_t, S, 2 * H * hd)
     torch.cuda.synchronize()
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,S,H,pads,tail", [(3, 333, 2, [5, 130, 0], False), (2, 700, 4, [0, 64], False), (3, 400, 2, [17, 0, 140], True)])
+def test_attention_varlen_matches_padded(B, S, H, pads, tail):
+    """packed rows (left padding removed) vs the padded [B, S] layout on the same tokens: forward output, lse-driven
+    backward incl. the fused RoPE^T at the reference's positions, and the per-sample last-block mode (q_row_min = -1)."""
+    from navillm_amd import ops
+    hd = 128
+    qkv = rnd(B * S, 3 * H * hd, dtype=BF, seed=120, scale=1.0)
+    dout = rnd(B * S, H * hd, dtype=BF, seed=121)
+    kvs = torch.tensor(pads, dtype=torch.int32, device=dev())
+    real = (torch.arange(S, device=dev())[None] >= kvs[:, None].long()).reshape(-1)
+    dout[~real] = 0
+    pos = torch.arange(2048, device=dev(), dtype=torch.float32)
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, device=dev(), dtype=torch.float32) / hd))
+    emb = torch.cat([torch.outer(pos, inv)] * 2, -1)
+    rope = (emb.cos().to(BF).contiguous(), emb.sin().to(BF).contiguous())
+    qmin_pad = ((S - 1) // 128) * 128 if tail else 0
+    if tail:      # only the last-block queries carry gradient in this mode
+        keep = (torch.arange(S, device=dev()) >= qmin_pad).repeat(B)
+        dout[~keep] = 0
+    out_p, lse_p = ops.attn_fwd(qkv, kvs, B, S, H, hd, q_row_min=qmin_pad)
+    dq_p = torch.zeros_like(qkv)
+    ops.attn_bwd(qkv, out_p, dout, lse_p, kvs, B, S, H, hd, dqkv=dq_p, q_row_min=qmin_pad, rope=rope)
+    # packed copy of the same tokens
+    idx = torch.nonzero(real).view(-1)
+    lens = (S - kvs.long())
+    cu = torch.zeros(B + 1, dtype=torch.int32, device=dev())
+    cu[1:] = lens.cumsum(0).to(torch.int32)
+    Sm = int(lens.max())
+    qkv_k, dout_k = qkv[idx].contiguous(), dout[idx].contiguous()
+    out_k = torch.zeros(idx.numel(), H * hd, dtype=BF, device=dev())
+    lse_k = torch.empty(B, H, Sm, dtype=torch.float32, device=dev())
+    ops.attn_fwd_varlen(qkv_k, cu, kvs, B, Sm, H, hd, out=out_k, lse2=lse_k, q_row_min=-1 if tail else 0)
+    dq_k = torch.zeros_like(qkv_k)
+    ops.attn_bwd_varlen(qkv_k, out_k, dout_k, lse_k, cu, kvs, B, Sm, H, hd, dq_k, q_row_min=-1 if tail else 0, rope=rope)
+    torch.cuda.synchronize()
+    if tail:
+        # rows computed by BOTH runs: the padded run covers positions >= qmin_pad, the packed run each sample's own last block
+        rows_p = []
+        for b in range(B):
+            L = int(lens[b])
+            lo = max(((L - 1) // 128) * 128, qmin_pad - int(kvs[b]))        # local index
+            rows_p.append(torch.arange(int(cu[b]) + lo, int(cu[b]) + L, device=dev()))
+        sel = torch.cat(rows_p)
+        assert_close(out_k[sel], out_p[idx][sel].float(), 2 ** -6, 5e-3, "varlen fwd (tail)")
+    else:
+        assert_close(out_k, out_p[idx].float(), 2 ** -6, 5e-3, "varlen fwd")
+        for name, sl in (("dq", slice(0, H * hd)), ("dk", slice(H * hd, 2 * H * hd)), ("dv", slice(2 * H * hd, 3 * H * hd))):
+            a, b_ = dq_k[:, sl].float(), dq_p[idx][:, sl].float()
+            rel = (a - b_).norm() / (b_.norm() + 1e-20)
+            assert rel < 2e-2, f"varlen {name}: rel err {rel.item():.3e}"

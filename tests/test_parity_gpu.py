@@ -84,7 +84,8 @@ def test_g2_visual_token_lm_vs_reference():
         loss = m._lm_loss(Hs, ids, T(zb["labels"]))
     real = am.bool().view(-1)
     B, S = ids.shape
-    got = Hs.float().cpu()[real]
+    got = Hs.float().cpu() if m._row_map is not None else Hs.float().cpu()[real]      # packed rows: the real tokens only
+    assert got.shape[0] == int(real.sum())
     ref16 = T(zb["hidden_states"]).view(B * S, -1)[real]
     ref32 = T(zf["hidden_states"]).view(B * S, -1)[real]
     e_hip = (got - ref32).abs().max().item()
