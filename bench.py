@@ -73,14 +73,24 @@ class GemmTimer:
             timer.recs.append((2.0 * M * N * K, e0, e1, layout))
             return r
         ops.gemm_bf16 = timed
+        self.orig_rope = ops.gemm_qkv_rope
+
+        def timed_rope(x, W, cos_t, sin_t, S, rope_cols, out=None, pos_i32=None):     # the q|k|v projection (NT + RoPE epilogue)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = timer.orig_rope(x, W, cos_t, sin_t, S, rope_cols, out=out, pos_i32=pos_i32)
+            e1.record()
+            timer.recs.append((2.0 * r.shape[0] * r.shape[1] * x.shape[1], e0, e1, 0))
+            return r
+        ops.gemm_qkv_rope = timed_rope
 
     def uninstall(self):
         self.ops.gemm_bf16 = self.orig
+        self.ops.gemm_qkv_rope = self.orig_rope
 
     def summary(self, layouts=(0,)):
-        """Forward GEMMs (layout NT) run alone on the stream, so event brackets are kernel durations.  The
-        backward's dgrad (NN) and wgrad (TN) GEMMs run CONCURRENTLY on two streams (navillm_amd/functions.py):
-        their brackets overlap and are reported separately, not as the roofline number."""
+        """Event brackets are kernel durations as long as the launches run alone on their stream: always true for the
+        forward (NT) GEMMs, and for dgrad (NN) / wgrad (TN) with the default single-stream backward."""
         recs = [r for r in self.recs if r[3] in layouts]
         if not recs:
             return None
