@@ -364,3 +364,46 @@ def test_pruned_last_layer_matches_full_path():
         a, b = res[True][1]["lm"][o:o + k], res[False][1]["lm"][o:o + k]
         rel = ((a - b).norm() / (b.norm() + 1e-20)).item()
         assert rel < 3e-2, (n, rel)
+
+
+def test_packed_rows_match_padded_layout():
+    """the LM over the real tokens only (pack_rows, default) vs the reference's padded [B, S] layout: same navigation
+    logits and the same gradients (padding rows feed nothing), with prompts of clearly different lengths, B = 1 included."""
+    from navillm_amd import config as nvcfg
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.synthetic import SyntheticEpisodes
+    from navillm_amd.losses import CrossEntropyLoss
+    cfg = nvcfg.NavConfig(hidden_size=512, num_layers=2, num_heads=4, intermediate_size=1408, base_vocab_size=1000,
+                          enc_hidden_size=256, enc_num_heads=4, enc_intermediate_size=512, image_feat_size=768)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=8)
+    m.eval()
+    crit = CrossEntropyLoss()
+    for B in (3, 1):
+        res = {}
+        for pack in (True, False):
+            m.pack_rows = pack
+            m.zero_grad()
+            ep = SyntheticEpisodes(cfg, B, seed=41, instr_len=150, device=torch.device(DEV))
+            for b in range(B):                                   # very different prompt lengths: 150, 110, 70 instruction tokens
+                ep.instr[b] = ep.instr[b][: 150 - 40 * b]
+            pin = ep.panorama_inputs()
+            pano = m("panorama", pin)
+            ep.update_maps(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+            nav = ep.nav_inputs(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+            nav["input_ids"], nav["attention_mask"] = ep.tokenise(nav, "<cls_1>")
+            if B > 1:
+                assert int(nav["attention_mask"].sum()) < nav["attention_mask"].numel() - 60
+            torch.manual_seed(3)
+            out = m("navigation", nav)
+            tg = ep.teacher_targets(nav, last=False)
+            (crit(out["fuse_logits"], tg.to(DEV)) / B).backward()
+            torch.cuda.synchronize()
+            res[pack] = (out["fuse_logits"].detach().float().cpu(), {g: t.detach().float().cpu().clone() for g, t in m.store.grad.items()})
+        lp, lf = res[True][0], res[False][0]
+        fin = torch.isfinite(lf)
+        assert torch.equal(torch.isfinite(lp), fin) and (lp[fin] - lf[fin]).abs().max().item() < 8e-3
+        for g in ("lm", "f32"):
+            a, b_ = res[True][1][g], res[False][1][g]
+            rel = ((a - b_).norm() / (b_.norm() + 1e-20)).item()
+            assert rel < 2e-2, (B, g, rel)
+    m.pack_rows = True
