@@ -282,8 +282,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         const int kt = kt0 + kt_local;
         // LDS layout: [A|B] per stage, except for the interleaved loop (PIPE 4): [A0][A1][B0][B1], so that the
         // stage index fits in the 16-bit immediate of its ds_reads
-        const uint32_t sa = smem_addr + (PIPE == 4 ? buf * A_BYTES : buf * (A_BYTES + B_BYTES));
-        const uint32_t sb = smem_addr + (PIPE == 4 ? NSTAGE * A_BYTES + buf * B_BYTES : buf * (A_BYTES + B_BYTES) + A_BYTES);
+        const uint32_t sa = smem_addr + (PIPE >= 4 ? buf * A_BYTES : buf * (A_BYTES + B_BYTES));
+        const uint32_t sb = smem_addr + (PIPE >= 4 ? NSTAGE * A_BYTES + buf * B_BYTES : buf * (A_BYTES + B_BYTES) + A_BYTES);
         stage_tile<BM, A_KMAJ, NT, BKT>(ra, sa, m0, kt * BKT, p.lda, tid);
         stage_tile<BN, B_KMAJ, NT, BKT>(rb, sb, n0, kt * BKT, p.ldb, tid);
     };
@@ -305,7 +305,107 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         }
     };
 
-    if constexpr (PIPE >= 1) {
+    if constexpr (PIPE == 5) {
+        // ---- "ping-pong": the two waves of a SIMD take turns on the matrix pipe ---------------------------------------
+        // A workgroup's waves w and w+4 share a SIMD.  Waves 0-3 (group A) and 4-7 (group B) run the same K loop half
+        // a step apart: while one group issues nothing but the 64 MFMAs of a K-tile, the other does all of its memory
+        // work for its next K-tile (24 fragment reads; group A also issues the CU's 64 LDS-DMAs, 16 per wave, because a
+        // stage always frees up right before one of A's memory slots).  Slots are separated by one s_barrier each
+        // (two per K-tile), fragments need no double buffering (a wave is either loading them or multiplying with them).
+        //   slot 2k  : A = MFMAs(k) then vmcnt(0)           | B = reads(k)
+        //   slot 2k+1: A = reads(k+1) + DMA(tile k+2 -> stage k%2) | B = MFMAs(k)
+        static_assert(NSTAGE == 2 && BKT == 64 && TM == 8 && TN == 4 && NT == 512, "ping-pong loop: 256x256x64, 8 waves");
+        static_assert(A_BYTES == B_BYTES, "one toggle serves both stage images");
+        FragAddr2<BM, A_KMAJ, TM, A_BYTES> fa2;
+        FragAddr2<BN, B_KMAJ, TN, B_BYTES> fb2;
+        fa2.init(wm * WTM, lane, smem_addr);
+        fb2.init(wn * WTN, lane, smem_addr + 2 * A_BYTES);
+        if (smem_addr & 0xffffu) __builtin_trap();
+        const bool grpA = __builtin_amdgcn_readfirstlane(wave) < 4;
+        bf16x8 fa[2][TM], fb[2][TN];
+        auto reads = [&]() {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int j = 0; j < TM; ++j) fa[kk][j] = fa2.load(j, kk);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) fb[kk][i] = fb2.load(i, kk);
+            }
+        };
+        auto mma = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto flip = [&]() { fa2.flip(); fb2.flip(); };
+        stage(0, 0);
+        if (KT > 1) stage(1, 1);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (grpA) {
+            // DMA addressing for the 4 issuing waves: piece `it` of an operand image = 4 KiB (chunk = it*4 + wave)
+            constexpr int ND = 256;
+            const int tidA = tid & 255;
+            const uint32_t a_pst = (uint32_t)((A_KMAJ ? (ND / 64) * (1024 / (BKT * 2)) : (ND / 64) * (1024 / (BM * 2))) * 2) * (uint32_t)p.lda;
+            const uint32_t b_pst = (uint32_t)((B_KMAJ ? (ND / 64) * (1024 / (BKT * 2)) : (ND / 64) * (1024 / (BN * 2))) * 2) * (uint32_t)p.ldb;
+            uint32_t pva[2], pvb[2];        // by piece parity: the MN-major swizzle key alternates with it
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                pva[par] = piece_voff<BM, A_KMAJ, ND, BKT>(m0, 0, p.lda, tidA, par) - par * a_pst;
+                pvb[par] = piece_voff<BN, B_KMAJ, ND, BKT>(n0, 0, p.ldb, tidA, par) - par * b_pst;
+                asm volatile("" : "+v"(pva[par]));
+                asm volatile("" : "+v"(pvb[par]));
+            }
+            const uint32_t m0base = __builtin_amdgcn_readfirstlane(smem_addr + (wave & 3) * 1024);
+            const uint32_t m0sum = 2 * m0base + A_BYTES;
+            uint32_t m0cur = m0base;
+            const uint32_t a_step = A_KMAJ ? BKT * 2 : (uint32_t)(BKT * 2) * (uint32_t)p.lda;
+            const uint32_t b_step = B_KMAJ ? BKT * 2 : (uint32_t)(BKT * 2) * (uint32_t)p.ldb;
+            uint64_t a_base = (uint64_t)p.A + (uint64_t)a_step * (kt0 + 2), b_base = (uint64_t)p.B + (uint64_t)b_step * (kt0 + 2);
+            uint32_t a_left = p.a_bytes - a_step * (uint32_t)(kt0 + 2), b_left = p.b_bytes - b_step * (uint32_t)(kt0 + 2);
+            reads();                                              // fragments of K-tile 0
+            for (int k = 0; k < KT; ++k) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                mma();                                            // slot 2k
+                if (k + 1 < KT) wait_vmcnt<0>();                  // tile k+1 (this wave's share) has landed
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                flip();                                           // slot 2k+1: fragments of K-tile k+1 ...
+                if (k + 1 < KT) reads();
+                if (k + 2 < KT) {                                 // ... and tile k+2 into the stage tile k just left
+                    const u32x4 da = make_desc((const void*)a_base, a_left);
+                    const u32x4 db = make_desc((const void*)b_base, b_left);
+                    static_for<16>([&](auto QC) {
+                        constexpr int q = decltype(QC)::value;
+                        if constexpr (q < 8) dma16_m0imm<q * (ND / 64) * 1024>(da, m0cur, pva[q & 1], a_pst * q);
+                        else dma16_m0imm<2 * A_BYTES + (q - 8) * (ND / 64) * 1024>(db, m0cur, pvb[q & 1], b_pst * (q - 8));
+                    });
+                    a_base += a_step; a_left -= a_step;
+                    b_base += b_step; b_left -= b_step;
+                }
+                m0cur = m0sum - m0cur;
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            for (int k = 0; k < KT; ++k) {
+                reads();                                          // slot 2k
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                mma();                                            // slot 2k+1
+                flip();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else if constexpr (PIPE >= 1) {
                 // ---- software-pipelined main loop (2 LDS stages, BK=64 = 2 k-steps of 32) ----------------------
         // Fragment registers are double-buffered: the ds_reads of k-step 1 are in flight under the MFMAs of
         // k-step 0, and the ds_reads of the NEXT tile's k-step 0 under the MFMAs of k-step 1.  One barrier
@@ -318,8 +418,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         fb_addr.init(wn * WTN, lane);
         bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
         auto ldfr = [&](int buf, int kk, bf16x8(&fa)[TM], bf16x8(&fb)[TN]) {
-            LDS_PTR(char) sa = smem + (PIPE == 4 ? buf * A_BYTES : buf * (A_BYTES + B_BYTES));
-            LDS_PTR(char) sb = smem + (PIPE == 4 ? NSTAGE * A_BYTES + buf * B_BYTES : buf * (A_BYTES + B_BYTES) + A_BYTES);
+            LDS_PTR(char) sa = smem + (PIPE >= 4 ? buf * A_BYTES : buf * (A_BYTES + B_BYTES));
+            LDS_PTR(char) sb = smem + (PIPE >= 4 ? NSTAGE * A_BYTES + buf * B_BYTES : buf * (A_BYTES + B_BYTES) + A_BYTES);
 #pragma unroll
             for (int j = 0; j < TM; ++j) fa[j] = fa_addr.load(sa, j, kk);
 #pragma unroll
@@ -706,7 +806,8 @@ int launch(const GemmArgs& p, hipStream_t st) {
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
 int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
     // tile_cfg: 0 = auto, 1 = 128x128x64 2-stage (4 waves), 3 = 256x256x64 2-stage (8 waves), 6 = 3 with software-
-    //           pipelined fragments, 8 = 3 with the hand-interleaved, VALU-free main loop
+    //           pipelined fragments, 8 = 3 with the hand-interleaved, VALU-free main loop, 9 = 8-wave ping-pong
+    //           (experimental: measured 5-13% behind 8)
     if (tile_cfg == 0) {
         // measured on MI355X (profiles/r01_gemm_probe*.txt): the 256x256 tile wins from ~1.4 rounds
         // of the 256 CUs upward, in all three layouts
@@ -720,6 +821,7 @@ int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
         case 3: if constexpr (EPI != EPI_SWIGLU_BWD && EPI != EPI_ROPE) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st); else return NV_ERR_ARG;
         case 6: if constexpr (EPI != EPI_SWIGLU_BWD && EPI != EPI_ROPE) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 1>(p, st); else return NV_ERR_ARG;   // software-pipelined fragments
         case 8: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4>(p, st);   // hand-interleaved phases
+        case 9: if constexpr (EPI <= EPI_RESID) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 5>(p, st); else return NV_ERR_ARG;   // ping-pong (experimental)
     }
     return NV_ERR_ARG;
 }

@@ -37,7 +37,7 @@ def assert_close(got, ref, rtol, atol_scale, what):
 
 
 # ------------------------------------------------------------------------------ bf16 GEMM
-@pytest.mark.parametrize("tile", [1, 3, 6, 8])
+@pytest.mark.parametrize("tile", [1, 3, 6, 8, 9])
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 192), (77, 520, 64), (1000, 384, 448)])
 def test_gemm_bf16_layouts(layout, tile, M, N, K):

@@ -65,6 +65,11 @@ int main() {
         RUN(k32<false>, "32x32x16, constant operands")
         RUN(k16<true>, "16x16x32, random operands")
         RUN(k32<true>, "32x32x16, random operands")
+        {   // one wave per SIMD (256 threads): can a single wave keep the matrix pipe full?  (half the waves -> half the flops)
+            (void)hipEventRecord(e0); hipLaunchKernelGGL(k16<false>, dim3(256), dim3(256), 0, 0, out, iters); (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+            printf("%-34s %7.1f TF\n", "16x16x32, constant, 1 wave/SIMD", 0.5 * fl / ms / 1e9);
+        }
     }
     return 0;
 }
