@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--lr", type=float, default=3e-5)
     ap.add_argument("--prewarm", type=int, default=6, help="untimed setup steps before the W warmup steps (one full episode: "
                     "first-use kernel/attribute/allocator/RCCL initialisation)")
-    ap.add_argument("--infer-steps", type=int, default=4, help="extra, untimed-for-`value` forward-only steps reported aside")
+    ap.add_argument("--infer-steps", type=int, default=6, help="extra, untimed-for-`value` forward-only steps reported aside")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch GEMM event timing")
     return ap.parse_args()
@@ -228,8 +228,9 @@ def main():
         model.eval()
         ep.reset()
         with torch.no_grad():
-            for i in range(2):
+            for i in range(STEPS_PER_EPISODE):      # one whole warm episode: every prompt length of the timed one has been seen
                 nav_step(wrapped, crit, ep, train=False)
+            ep.reset()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(a.infer_steps):
