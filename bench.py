@@ -158,8 +158,10 @@ def main():
     from navillm_amd.parallel import init_distributed_device, NavDataParallel
     import torch.distributed as dist
     device, rank, world = init_distributed_device()
-    if world > 1:            # one process per GPU share the host: do not let every rank spin up all cores for its CPU-side ops
-        torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
+    # Host threads for torch's CPU-side glue ops (masks, index lists): a handful.  With the default (all 256 hardware
+    # threads) a barrier of the intra-op pool now and then takes 80-100 ms on a tiny tensor (tools/pack_probe.py), longer
+    # than a whole forward; and with one process per GPU the ranks must share the host anyway.  (cpu_baseline sets its own.)
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     from navillm_amd import ops
     from navillm_amd.nav_model import NavModel

@@ -235,7 +235,11 @@ class EmbedVis(torch.autograd.Function):
     def forward(ctx, vis, anchor, model, ids_i32, vis_idx_i32, vis_rows_i32, ids_cpu):
         st = model.store
         table = st.p("lang_model.model.embed_tokens.weight")
-        E = ops.embed_vis(table, ids_i32, vis_idx_i32, vis)
+        # into the arena: with packed rows the row count changes from step to step, and a 40 MB torch allocation of a new
+        # size now and then costs a hipMalloc stall (seen as 95-110 ms forward steps among 64 ms ones)
+        M = ids_i32.numel()
+        model.arena.reserve(M)
+        E = ops.embed_vis(table, ids_i32, vis_idx_i32, vis, out=model.arena.scratch["E"][:M])
         ctx.model = model
         ctx.vis_rows = vis_rows_i32
         ctx.ids_cpu = ids_cpu
@@ -272,7 +276,7 @@ class ActivationArena:
     LAYER_FIELDS = (("n1", 1, 0), ("qkv", 3, 0), ("attn", 1, 0), ("x1", 1, 0), ("n2", 1, 0), ("gu", 0, 2), ("h", 0, 1),
                     ("x2", 1, 0))
     SCRATCH_FIELDS = (("dh", 0, 1), ("dgu", 0, 2), ("dn2", 1, 0), ("dx1", 1, 0), ("dattn", 1, 0), ("dqkv", 3, 0),
-                      ("dn1", 1, 0), ("dxa", 1, 0), ("dxb", 1, 0))
+                      ("dn1", 1, 0), ("dxa", 1, 0), ("dxb", 1, 0), ("E", 1, 0), ("dE", 1, 0))
 
     def __init__(self, cfg, device):
         self.cfg, self.device = cfg, device
@@ -511,7 +515,8 @@ class LlamaStack(torch.autograd.Function):
             dx, nxt = ndx, dx
             dx_name, nxt_name = nxt_name, dx_name
             model._dp_layer_done(i, [e_ for e_ in ev if e_ is not None])
-        out = dx.clone()
+        out = sc["dE"]
+        out.copy_(dx)
         if side is not None:
             main.wait_stream(side)      # weight gradients complete before anything downstream (optimizer, next forward)
         return out, None, None, None, None, None, None

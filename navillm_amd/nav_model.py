@@ -16,6 +16,7 @@ import math
 import os
 import types
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -360,44 +361,54 @@ class NavModel(nn.Module):
         true for the left-padded navigation / grounding prompts): only those B rows, [B, d]."""
         cfg = self.cfg
         B, S = ids_cpu.shape
-        am = am_cpu.bool()
-        kv_start = (am.int().cumsum(1) == 0).sum(1).to(torch.int32)
-        assert bool((am == (torch.arange(S)[None] >= kv_start[:, None])).all()), "attention_mask must be left padding"
+        # host-side index bookkeeping in numpy: torch's CPU ops on these few-thousand-element tensors go through the
+        # intra-op thread pool, which on a 256-thread host now and then takes 80-100 ms to get through a barrier
+        # (tools/pack_probe.py) -- more than the whole LM forward
+        am_np = am_cpu.numpy().astype(bool)
+        lens_np = am_np.sum(1)
+        kv_np = (S - lens_np).astype(np.int32)
+        assert bool((am_np == (np.arange(S)[None] >= kv_np[:, None])).all()), "attention_mask must be left padding"
+        kv_start = torch.from_numpy(kv_np)
         packed = None
         self._row_map = None
         flat = ids_cpu.reshape(-1)
         if self.pack_rows:
-            keep = torch.nonzero(am.reshape(-1)).view(-1)
-            lens = am.sum(1)
-            cu = torch.zeros(B + 1, dtype=torch.int32)
-            cu[1:] = lens.cumsum(0).to(torch.int32)
-            pos = torch.arange(S, dtype=torch.int32)[None].expand(B, S).reshape(-1)[keep]
-            flat = flat[keep]
+            keep_np = np.flatnonzero(am_np.reshape(-1))
+            cu_np = np.zeros(B + 1, dtype=np.int32)
+            cu_np[1:] = np.cumsum(lens_np)
+            pos_np = np.broadcast_to(np.arange(S, dtype=np.int32)[None], (B, S)).reshape(-1)[keep_np]
+            keep = torch.from_numpy(keep_np)
+            flat = torch.from_numpy(ids_cpu.numpy().reshape(-1)[keep_np])
             self._row_map = keep
-            packed = (ops.h2d(cu, self.device), ops.h2d(pos.contiguous(), self.device), int(lens.max()))
-            last_rows = cu[1:].to(torch.int32) - 1
+            packed = (ops.h2d(torch.from_numpy(cu_np), self.device), ops.h2d(torch.from_numpy(np.ascontiguousarray(pos_np)), self.device),
+                      int(lens_np.max()))
+            last_rows = torch.from_numpy((cu_np[1:] - 1).astype(np.int32))
         else:
             last_rows = torch.arange(B, dtype=torch.int32) * S + (S - 1)
         M = flat.numel()
-        vis_idx = torch.full((M,), -1, dtype=torch.int32)
+        flat_np = flat.numpy()
+        vis_idx_np = np.full((M,), -1, dtype=np.int32)
         parts, rows, off = [], [], 0
         for tok_id, vis in ((cfg.cand_token_id, cand_vis), (cfg.hist_token_id, hist_vis), (cfg.obj_token_id, obj_vis)):
-            loc = torch.nonzero(flat == tok_id).view(-1)
-            if loc.numel() == 0:
+            loc = np.flatnonzero(flat_np == tok_id)
+            if loc.size == 0:
                 continue
-            assert vis is not None and vis.shape[0] == loc.numel(), \
-                f"{loc.numel()} special tokens of id {tok_id} but {None if vis is None else vis.shape[0]} visual rows"
-            vis_idx[loc] = torch.arange(off, off + loc.numel(), dtype=torch.int32)
-            rows.append(loc.to(torch.int32))
+            assert vis is not None and vis.shape[0] == loc.size, \
+                f"{loc.size} special tokens of id {tok_id} but {None if vis is None else vis.shape[0]} visual rows"
+            vis_idx_np[loc] = np.arange(off, off + loc.size, dtype=np.int32)
+            rows.append(loc.astype(np.int32))
             parts.append(vis.to(F32))
-            off += loc.numel()
+            off += loc.size
+        vis_idx = torch.from_numpy(vis_idx_np)
+        rows = [torch.from_numpy(np.concatenate(rows))] if rows else []
         vis_all = torch.cat(parts, 0).contiguous() if parts else None
         vis_rows = ops.h2d(torch.cat(rows), self.device) if rows else None
         E = Fn.EmbedVis.apply(vis_all, self._anchor if torch.is_grad_enabled() else None, self,
-                              ops.h2d(flat, self.device, torch.int32), ops.h2d(vis_idx, self.device), vis_rows, flat)
+                              ops.h2d(torch.from_numpy(flat_np.astype(np.int32)), self.device), ops.h2d(vis_idx, self.device), vis_rows, flat)
         tail = None
-        if cls_tail and self.prune_last_layer and bool((ids_cpu[:, -1] == cfg.cls_token_ids[0]).all()) \
-                and int((ids_cpu == cfg.cls_token_ids[0]).sum()) == B:
+        ids_np = ids_cpu.numpy()
+        if cls_tail and self.prune_last_layer and bool((ids_np[:, -1] == cfg.cls_token_ids[0]).all()) \
+                and int((ids_np == cfg.cls_token_ids[0]).sum()) == B:
             tail = ops.h2d(last_rows, self.device)
         Hs = Fn.LlamaStack.apply(E, self, B, S, ops.h2d(kv_start, self.device), tail, packed)
         if cls_tail and tail is None:
