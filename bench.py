@@ -113,7 +113,7 @@ def gemm_traffic_from_profile():
 
 def cpu_baseline(a, cfg, seed):
     """The oracle (CPU restatement, kind='port') timed on this box's host cores on a bounded sample:
-    ONE episode, ONE nav step, forward + backward, with 4 of the 32 decoder layers (the LM is 99.9% of
+    ONE episode, ONE nav step, forward + backward, with 8 of the 32 decoder layers (the LM is 99.9% of
     the FLOPs), scaled linearly in layers to the full model."""
     import importlib.util
     from navillm_amd.config import NavConfig
@@ -122,7 +122,7 @@ def cpu_baseline(a, cfg, seed):
     spec = importlib.util.spec_from_file_location("navillm_oracle", os.path.join(ROOT, "oracle", "navillm_oracle.py"))
     O = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(O)
-    Ls = min(4, cfg.num_layers)
+    Ls = min(8, cfg.num_layers)
     c = NavConfig(**{**cfg.__dict__, "num_layers": Ls})
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
