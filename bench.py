@@ -111,6 +111,39 @@ def gemm_traffic_from_profile():
         return None
 
 
+def inference_extras(a, model, wrapped, crit, ep):
+    """untimed-for-`value` extras: the same nav step without loss/backward (validation rollout, mp3d_agent.py:530-590),
+    plain and with prompt-prefix K/V reuse"""
+    from navillm_amd.synthetic import nav_step
+    model.eval()
+    ep.reset()
+    with torch.no_grad():
+        for i in range(STEPS_PER_EPISODE):      # one whole warm episode: every prompt length of the timed one has been seen
+            nav_step(wrapped, crit, ep, train=False)
+        ep.reset()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(a.infer_steps):
+            nav_step(wrapped, crit, ep, train=False)
+        torch.cuda.synchronize()
+    infer = {"nav_steps_per_s_per_gpu": round(a.batch * a.infer_steps / (time.perf_counter() - t1), 2),
+             "steps": a.infer_steps, "what": "panorama + navigation forward only, argmax actions, eval mode"}
+    model.enable_kv_cache(a.batch, capacity=1024)
+    with torch.no_grad():
+        for rep in range(2):                    # one warm episode, one timed episode
+            ep.reset()
+            model.reset_kv_cache()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(STEPS_PER_EPISODE):
+                nav_step(wrapped, crit, ep, train=False)
+            torch.cuda.synchronize()
+    infer_kv = {"nav_steps_per_s_per_gpu": round(a.batch * STEPS_PER_EPISODE / (time.perf_counter() - t1), 2),
+                "steps": STEPS_PER_EPISODE, "last_step_new_tokens": model.kv.last_stats["new"],
+                "what": "one whole episode (first step = full prefill), K/V of the prompt prefix reused from step to step"}
+    return infer, infer_kv
+
+
 def cpu_baseline(a, cfg, seed):
     """The oracle (CPU restatement, kind='port') timed on this box's host cores on a bounded sample:
     ONE episode, ONE nav step, forward + backward, with 8 of the 32 decoder layers (the LM is 99.9% of
@@ -225,35 +258,13 @@ def main():
     dt = float(tmax.item())
 
     # ---- untimed extra: the same nav step without loss/backward (validation rollout, mp3d_agent.py:530-590)
-    infer = None
+    infer = infer_kv = None
     if a.infer_steps > 0:
-        model.eval()
-        ep.reset()
-        with torch.no_grad():
-            for i in range(STEPS_PER_EPISODE):      # one whole warm episode: every prompt length of the timed one has been seen
-                nav_step(wrapped, crit, ep, train=False)
-            ep.reset()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(a.infer_steps):
-                nav_step(wrapped, crit, ep, train=False)
-            torch.cuda.synchronize()
-        infer = {"nav_steps_per_s_per_gpu": round(a.batch * a.infer_steps / (time.perf_counter() - t1), 2),
-                 "steps": a.infer_steps, "what": "panorama + navigation forward only, argmax actions, eval mode"}
-        # the same rollout with prompt-prefix K/V reuse: one warm episode, one timed episode
-        model.enable_kv_cache(a.batch, capacity=1024)
-        with torch.no_grad():
-            for rep in range(2):
-                ep.reset()
-                model.reset_kv_cache()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for i in range(STEPS_PER_EPISODE):
-                    nav_step(wrapped, crit, ep, train=False)
-                torch.cuda.synchronize()
-        infer_kv = {"nav_steps_per_s_per_gpu": round(a.batch * STEPS_PER_EPISODE / (time.perf_counter() - t1), 2),
-                    "steps": STEPS_PER_EPISODE, "last_step_new_tokens": model.kv.last_stats["new"],
-                    "what": "one whole episode (first step = full prefill), K/V of the prompt prefix reused from step to step"}
+        try:        # extras must never take the headline number down with them (nor leave a rank behind at the final barrier)
+            infer, infer_kv = inference_extras(a, model, wrapped, crit, ep)
+        except Exception as e:
+            infer = {"error": f"{type(e).__name__}: {e}"}
+            infer_kv = None
         model.kv = None
         model.train()
 
@@ -273,6 +284,7 @@ def main():
         }
         if infer is not None:
             line["inference_forward_only"] = infer
+        if infer_kv is not None:
             line["inference_prefix_kv_reuse"] = infer_kv
         if g is not None:
             allg = timer.summary(layouts=(0, 1, 2))
