@@ -186,8 +186,30 @@ def cpu_baseline(a, cfg, seed):
                       f"torch CPU bf16, {cores} threads"}
 
 
+def relaunch_one_rank_per_gpu(a):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves (one process per GPU, exactly the
+    launch line of the module docstring) and hand their output through.  Never falls back to a single GPU."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} requested but only {have} GPU(s) are visible; refusing to report a "
+                         f"{a.gpus}-GPU line from fewer devices")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL's peer mappings need it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_one_rank_per_gpu(a))
     from navillm_amd.parallel import init_distributed_device, NavDataParallel
     import torch.distributed as dist
     device, rank, world = init_distributed_device()
@@ -195,7 +217,8 @@ def main():
     # threads) a barrier of the intra-op pool now and then takes 80-100 ms on a tiny tensor (tools/pack_probe.py), longer
     # than a whole forward; and with one process per GPU the ranks must share the host anyway.  (cpu_baseline sets its own.)
     torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: the line would not describe the job that ran")
     from navillm_amd import ops
     from navillm_amd.nav_model import NavModel
     from navillm_amd.losses import CrossEntropyLoss
@@ -217,6 +240,8 @@ def main():
         wrapped = NavDataParallel(model, force_sync=True)
     else:
         wrapped = NavDataParallel(model) if world > 1 else model
+        if world > 1 and os.environ.get("NAVILLM_DP_ALGO") is None:
+            wrapped.calibrate()        # all-reduce vs reduce-scatter + all-gather on one layer slice: keep the faster
     crit = CrossEntropyLoss()
     ep = SyntheticEpisodes(cfg, a.batch, seed=seed, instr_len=a.instr_len, device=device)
     timer = GemmTimer()
@@ -282,6 +307,11 @@ def main():
                        "global_batch": a.batch * world, "seq_len": int(max(ep.S_hist)) if ep.S_hist else None,
                        "parallelism": f"dp{world}", "loss": float(loss.detach()) if loss is not None else None},
         }
+        if world > 1:
+            line["dp"] = {"transport": "nv_comm (RCCL, C ABI)" if wrapped.comm is not None else "torch.distributed",
+                          "reduce": wrapped.reduce, "algo": wrapped.algo, "calibration": wrapped.calibration,
+                          "what": "gradients averaged once per optimizer step, per-layer slices exchanged from inside the "
+                                  "episode's last backward on a side stream"}
         if infer is not None:
             line["inference_forward_only"] = infer
         if infer_kv is not None:

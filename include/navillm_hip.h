@@ -176,6 +176,10 @@ int nv_comm_rank(const nv_ctx* c);
 int nv_comm_world(const nv_ctx* c);
 int nv_comm_allreduce_bf16(nv_ctx* c, void* buf, long count, int average, void* stream);
 int nv_comm_allreduce_f32(nv_ctx* c, void* buf, long count, int average, void* stream);
+/*   the same mean in two phases for the fully connected xGMI node: in-place reduce-scatter (rank r keeps
+ *   the reduced chunk r of `count`/world elements) + in-place all-gather of the chunks; count resp. bytes % world == 0 */
+int nv_comm_reduce_scatter(nv_ctx* c, void* buf, long count, int is_bf16, int average, void* stream);
+int nv_comm_all_gather(nv_ctx* c, void* buf, long bytes, void* stream);
 int nv_comm_broadcast(nv_ctx* c, void* buf, long bytes, int root, void* stream);
 int nv_comm_destroy(nv_ctx* c);
 

@@ -26,6 +26,8 @@ struct Rccl {
     int (*CommDestroy)(ncclComm_t);
     int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
     int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
+    int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t);
     bool ok;
 };
 
@@ -46,7 +48,9 @@ Rccl* rccl() {
         q.CommDestroy = (int (*)(ncclComm_t))dlsym(h, "ncclCommDestroy");
         q.AllReduce = (int (*)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t))dlsym(h, "ncclAllReduce");
         q.Broadcast = (int (*)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t))dlsym(h, "ncclBroadcast");
-        q.ok = q.GetUniqueId && q.CommInitRank && q.CommDestroy && q.AllReduce && q.Broadcast;
+        q.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t))dlsym(h, "ncclReduceScatter");
+        q.AllGather = (int (*)(const void*, void*, size_t, int, ncclComm_t, hipStream_t))dlsym(h, "ncclAllGather");
+        q.ok = q.GetUniqueId && q.CommInitRank && q.CommDestroy && q.AllReduce && q.Broadcast && q.ReduceScatter && q.AllGather;
         return q;
     }();
     return &r;
@@ -105,6 +109,26 @@ int nv_comm_allreduce_f32(nv_ctx* c, void* buf, long count, int average, void* s
     if (count == 0) return NV_OK;
     return rccl()->AllReduce(buf, buf, (size_t)count, ncclFloat32, average ? ncclAvg : ncclSum, c->comm, (hipStream_t)stream) == ncclSuccess
                ? NV_OK : NV_ERR_COMM;
+}
+
+// Two-phase form of the gradient mean for a fully connected xGMI node: in-place reduce-scatter (rank r
+// ends up owning the reduced chunk buf[r*count/world .. (r+1)*count/world)) followed by an in-place all-gather of the
+// chunks.  count must be a multiple of world (the flat gradient slices are multiples of 64 elements).
+int nv_comm_reduce_scatter(nv_ctx* c, void* buf, long count, int is_bf16, int average, void* stream) {
+    if (!c || (!buf && count) || count < 0 || count % c->world) return NV_ERR_ARG;
+    if (count == 0) return NV_OK;
+    const size_t chunk = (size_t)(count / c->world), esz = is_bf16 ? 2 : 4;
+    char* mine = (char*)buf + (size_t)c->rank * chunk * esz;
+    return rccl()->ReduceScatter(buf, mine, chunk, is_bf16 ? ncclBfloat16 : ncclFloat32, average ? ncclAvg : ncclSum, c->comm,
+                                 (hipStream_t)stream) == ncclSuccess ? NV_OK : NV_ERR_COMM;
+}
+
+int nv_comm_all_gather(nv_ctx* c, void* buf, long bytes, void* stream) {
+    if (!c || (!buf && bytes) || bytes < 0 || bytes % c->world) return NV_ERR_ARG;
+    if (bytes == 0) return NV_OK;
+    const size_t chunk = (size_t)(bytes / c->world);
+    const char* mine = (const char*)buf + (size_t)c->rank * chunk;
+    return rccl()->AllGather(mine, buf, chunk, ncclUint8, c->comm, (hipStream_t)stream) == ncclSuccess ? NV_OK : NV_ERR_COMM;
 }
 
 int nv_comm_broadcast(nv_ctx* c, void* buf, long bytes, int root, void* stream) {

@@ -42,6 +42,8 @@ class FlatStore:
         self.lm_dtype = torch.bfloat16 if cfg.lm_is_bf16 else torch.float32
         self.offsets = {}
         self.sizes = {}
+        self.alloc_sizes = {}     # size incl. alignment padding: offsets[n] + alloc_sizes[n] == offset of the next tensor
+        self.touched = set()      # names that have received a gradient at least once (navillm_amd/optim.py: which tensors AdamW updates)
         self.names = {"lm": lm_names, "f32": f32_names}
         self.shape_of = shape_of
         self.group_of = group_of
@@ -61,7 +63,8 @@ class FlatStore:
                     # the contraction of the dgrad GEMM (K % 64 == 0) without copying logits
                     alloc = self.vocab_pad * shape_of[n][1]
                 # packed partners must stay adjacent: q/k/v and gate/up sizes are multiples of ALIGN
-                off += (alloc + ALIGN - 1) // ALIGN * ALIGN
+                self.alloc_sizes[n] = (alloc + ALIGN - 1) // ALIGN * ALIGN
+                off += self.alloc_sizes[n]
             tot[grp] = off
         self.total = tot
         dt = {"lm": self.lm_dtype, "f32": torch.float32}
@@ -115,6 +118,15 @@ class FlatStore:
         last = p + "post_attention_layernorm.weight"
         e = self.offsets[last] + (self.sizes[last] + ALIGN - 1) // ALIGN * ALIGN
         return s, e
+
+    # ---- "this tensor has a gradient now" (torch: p.grad is no longer None); reported by the backward functions
+    def touch(self, *names):
+        self.touched.update(names)
+
+    def touch_layers(self):
+        """every decoder-layer tensor + the final norm (LlamaStack.backward accumulates into all of them)"""
+        if "lang_model.model.norm.weight" not in self.touched:
+            self.touched.update(n for n in self.names["lm"] if n.startswith("lang_model.model.layers.") or n == "lang_model.model.norm.weight")
 
     def zero_grad(self):
         for g in self.grad.values():

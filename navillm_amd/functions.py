@@ -24,7 +24,12 @@ def _c(t):
 def _acc_target(p):
     """Parameters of NavModel carry a persistent `.grad` view into the flat fp32 grad buffer: accumulate
     there directly (no autograd `+=` pass). Plain tensors (tests) get a returned gradient instead."""
-    return p.grad if isinstance(p, torch.nn.Parameter) and p.grad is not None else None
+    if isinstance(p, torch.nn.Parameter) and p.grad is not None:
+        t = getattr(p, "_nv_touch", None)
+        if t is not None:
+            t()                     # FlatStore.touch(name): this parameter has a gradient from now on (navillm_amd/optim.py)
+        return p.grad
+    return None
 
 
 class LinearF32(torch.autograd.Function):
@@ -260,6 +265,7 @@ class EmbedVis(torch.autograd.Function):
         dev = dE.device
         ops.embed_grad(dE, ops.h2d(uniq, dev, torch.int32), ops.h2d(seg, dev), ops.h2d(order, dev, torch.int32),
                        st.g("lang_model.model.embed_tokens.weight"))
+        st.touch("lang_model.model.embed_tokens.weight")
         return dvis, None, None, None, None, None, None
 
 
@@ -408,6 +414,7 @@ class LlamaStack(torch.autograd.Function):
 
         H, hd, L = cfg.num_heads, cfg.head_dim, cfg.num_layers
         sc = {k: v[:M] for k, v in ar.scratch.items()}
+        st.touch_layers()
         model._dp_begin_backward()
         L_full = L
         if ctx.tail is not None:
@@ -556,6 +563,7 @@ class HeadBF16(torch.autograd.Function):
         st = ctx.model.store
         pf = ctx.prefix
         dx = ops.head_bwd(_c(dy), x, st.p(pf + ".weight"), st.g(pf + ".weight"), st.g(pf + ".bias"))
+        st.touch(pf + ".weight", pf + ".bias")
         return dx, None, None
 
 
@@ -585,6 +593,7 @@ class LMHeadLoss(torch.autograd.Function):
             ops.scale_bf16_(dl, gs)             # loss coefficient applied by the caller after .loss
         dH = ops.gemm_bf16(ops.NN, dl, st.lm_head_padded())
         ops.gemm_bf16(ops.TN, dl, Hs, out=st.lm_head_padded(grad=True), epilogue=ops.EPI_ACCUM)
+        st.touch("lang_model.lm_head.weight")
         return dH, None, None, None
 
 

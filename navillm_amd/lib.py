@@ -72,6 +72,8 @@ SIGNATURES = {
     "nv_comm_world": (i, [vp]),
     "nv_comm_allreduce_bf16": (i, [vp, vp, l, i, vp]),
     "nv_comm_allreduce_f32": (i, [vp, vp, l, i, vp]),
+    "nv_comm_reduce_scatter": (i, [vp, vp, l, i, i, vp]),
+    "nv_comm_all_gather": (i, [vp, vp, l, vp]),
     "nv_comm_broadcast": (i, [vp, vp, l, i, vp]),
     "nv_comm_destroy": (i, [vp]),
 }

@@ -12,6 +12,8 @@ Inference extras: `enable_kv_cache()` = prompt-prefix K/V reuse
 Not mirrored (raise NotImplementedError): sampling generation, fp32 LM, OPT LMs.
 """
 import collections
+import functools
+import itertools
 import math
 import os
 import types
@@ -83,7 +85,7 @@ class _Out(dict):
 
 class NavModel(nn.Module):
     def __init__(self, args=None, logger=None, model_config=None, *, nav_config=None, device=None, tokenizer=None,
-                 seed=0, init="synthetic"):
+                 seed=0, init=None):
         super().__init__()
         if nav_config is None:
             nav_config = self._config_from_args(args, model_config)
@@ -114,10 +116,28 @@ class NavModel(nn.Module):
         for name, shape, group in param_specs(cfg):
             p = nn.Parameter(self.store.p(name), requires_grad=True)
             p.grad = self.store.g(name)
+            p._nv_touch = functools.partial(self.store.touch, name)
             self._attach(name, p)
             self._named[name] = p
+        # weights.  nav_config path (benchmarks, tests): seeded synthetic.  args path (the reference's constructor call,
+        # train.py:227): what the reference does -- pretrained LM via the HF checkpoint unless from_scratch / resume, torch
+        # default inits for everything else; never a silent synthetic fallback (navillm_amd/checkpoint.py)
+        if init is None:
+            init = "synthetic" if args is None else "reference"
         if init == "synthetic":
             self.init_synthetic(seed)
+        elif init == "reference":
+            from . import checkpoint as ck
+            scratch = getattr(args, "resume_from_checkpoint", None) is not None or bool(getattr(args, "from_scratch", False))
+            ck.init_reference_scratch(self, seed, lm=scratch, rest=True)
+            if not scratch:
+                n = ck.load_hf_llama(self, args.pretrained_model_name_or_path, seed)
+                if logger is not None:
+                    logger.info(f"loaded {n} LM tensors from {args.pretrained_model_name_or_path}")
+            elif logger is not None:
+                logger.info("Initialize the model from config.")
+        elif init != "none":
+            raise ValueError(f"init={init!r}")
 
         # ---- RoPE tables, built the HF way (fp32 angles on the host, then cast to the LM dtype)
         hd = cfg.head_dim
@@ -219,6 +239,12 @@ class NavModel(nn.Module):
     def P(self, name):
         return self._named[name]
 
+    def _Prow(self, name, i):
+        """row i of an embedding table used as a plain torch index (autograd accumulates into the flat .grad view itself)"""
+        if torch.is_grad_enabled():
+            self.store.touch(name)
+        return self._named[name][i]
+
     def _lin(self, x, prefix):
         return Fn.linear(x, self.P(prefix + ".weight"), self.P(prefix + ".bias"))
 
@@ -288,7 +314,7 @@ class NavModel(nn.Module):
                 o = self._seq2(ops.h2d(obj_img_fts, self.device, F32), e + ".obj_linear")
                 o = Fn.add(o, self._ln(self._lin(ops.h2d(obj_loc_fts, self.device, F32), e + ".loc_linear"),
                                        e + ".loc_layer_norm", 1e-12))
-                o = Fn.add(o.view(B * O, h), self.P(e + ".nav_type_embedding.weight")[2])
+                o = Fn.add(o.view(B * O, h), self._Prow(e + ".nav_type_embedding.weight", 2))
                 T_ = int((vl + olh).max())
                 src_v = torch.full((B * T_,), -1, dtype=torch.int32)
                 src_o = torch.full((B * T_,), -1, dtype=torch.int32)
@@ -488,6 +514,25 @@ class NavModel(nn.Module):
         flat = [v for vis in hist_vis for v in vis]
         return torch.stack(flat, 0) if flat else None
 
+    _hist_serial = itertools.count(1)
+
+    @classmethod
+    def _hist_keys(cls, hist_vis):
+        """one reuse key per history row.  History embeddings are constants once appended (mp3d_agent.py:774-778) and the
+        agent passes the SAME tensor objects step after step, so each object gets a serial number the first time it is seen.
+        (Not `data_ptr()`: after an episode ends the caching allocator hands the same address to a different tensor, and a
+        repeated instruction would then silently reuse stale K/V -- ADVICE r1.)  A caller that rebuilds its history tensors
+        every step just gets fresh serials, i.e. a recompute."""
+        keys = []
+        for b, vis in enumerate(hist_vis):
+            for k, v in enumerate(vis):
+                sid = getattr(v, "_nv_hist_id", None)
+                if sid is None:
+                    sid = next(cls._hist_serial)
+                    v._nv_hist_id = sid
+                keys.append(("hist", b, k, sid))
+        return keys
+
     def _cls_rows(self, flat_ids_cpu):
         loc = torch.nonzero(flat_ids_cpu.reshape(-1) == self.cfg.cls_token_ids[0]).view(-1)
         return ops.h2d(loc, self.device, torch.int32)
@@ -555,8 +600,7 @@ class NavModel(nn.Module):
         hist_vis = self._stack_hist(batch["hist_vis"])
         ids, am, _ = self._tokens(batch, batch["prompts"])
         if self.kv is not None and not torch.is_grad_enabled() and self.kv.B == B:
-            # history embeddings are constants once appended (mp3d_agent.py:774-778): key = (slot, index, storage)
-            hk = [("hist", b, k, v.data_ptr()) for b, vis in enumerate(batch["hist_vis"]) for k, v in enumerate(vis)]
+            hk = self._hist_keys(batch["hist_vis"])
             Hs_cls = self._lm_cached(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, hist_keys=hk)
         else:
             Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)
@@ -586,7 +630,7 @@ class NavModel(nn.Module):
         ids, am, _ = self._tokens(batch, batch["prompts"])
         if self.kv is not None and not torch.is_grad_enabled() and self.kv.B == B:
             # the grounding prompt of the last step shares instruction + history with the navigation prompts before it
-            hk = [("hist", b, k, v.data_ptr()) for b, vis in enumerate(batch["hist_vis"]) for k, v in enumerate(vis)]
+            hk = self._hist_keys(batch["hist_vis"])
             Hs_cls = self._lm_cached(ids, am, cand_vis=cand_vis, hist_vis=self._stack_hist(batch["hist_vis"]), hist_keys=hk)
         else:
             Hs_cls = self._lm(ids, am, cand_vis=cand_vis, hist_vis=self._stack_hist(batch["hist_vis"]), cls_tail=True)
@@ -598,7 +642,7 @@ class NavModel(nn.Module):
     def _zero_pose_type0(self, rows):
         z = torch.zeros((rows, 14), dtype=F32, device=self.device)
         e = self._seq2(z, "vp_pos_embeddings")
-        return Fn.add(e, self.P("token_type_embeddings.weight")[0])
+        return Fn.add(e, self._Prow("token_type_embeddings.weight", 0))
 
     def forward_3dqa(self, mode, batch, training=True, **kwargs):
         """nav_model.py:346-404: training -> `.loss`; training=False -> greedy generation (`generated_sentences`)."""

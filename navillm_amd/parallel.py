@@ -1,18 +1,28 @@
-"""Data parallelism over the 8 GPUs of one MI355X node: one process per GPU, RCCL through
-torch.distributed (backend "nccl" is RCCL on ROCm).  Replaces tools/distributed.py:105-183 (process
-group from the torchrun env) and the DDP wrapper of tools/optims.py:52-54.
+"""Data parallelism over the 8 GPUs of one MI355X node: one process per GPU, gradients exchanged over RCCL/xGMI through
+the C-ABI communicator `nv_comm_*` (include/navillm_hip.h).  Replaces tools/distributed.py:105-183 (process group from the
+torchrun env) and the DDP wrapper of tools/optims.py:52-54.
 
-Design for xGMI (7 point-to-point links per GPU, no switch): few, large messages.  The flat
-gradient buffers (navillm_amd/flat.py) make every decoder layer one contiguous ~400 MB bf16 slice:
-as soon as layer i's backward has accumulated its weight gradients, its slice is all-reduced on a
-side stream while layers i-1..0 are still computing -- 32 large collectives per synced backward, no
-bucket copies, no `find_unused_parameters` bitmap (unused parameters simply carry zero gradients in
-the flat buffer; which is what DDP's flag achieves for `og_head`, nav_model.py:78-80).
-
-`no_sync()` and `.module` follow the DDP protocol the agent relies on (mp3d_agent.py:661-676).
+Design for xGMI (7 point-to-point links per GPU, no switch): few, large messages, moved ONCE per optimizer step.
+  * The flat gradient buffers (navillm_amd/flat.py) make every decoder layer one contiguous ~400 MB bf16 slice: no bucket
+    copies, no `find_unused_parameters` bitmap (unused parameters simply carry zero gradients in the flat buffer; which is what
+    DDP's flag achieves for `og_head`, nav_model.py:78-80).
+  * `reduce="step"` (default): per-step `backward()`s only accumulate locally -- also the up-to-three synced backwards of an
+    episode's last step (mp3d_agent.py:756,824,902), which under DDP are three full 13.6 GB all-reduces.  The mean over ranks
+    of the ACCUMULATED gradient is taken once: either overlapped with the last backward before the optimizer step
+    (`with ddp.final_backward(): loss.backward()` -- layer i's slice is exchanged on a side stream as soon as that backward
+    has accumulated layer i's weight gradients, while layers i-1..0 are still computing), or, when no backward was flagged,
+    by `flush()`, which `FlatAdamW.clip_grad_norm_/step` call first.  Sum of means == mean of sums.
+  * `reduce="backward"`: DDP's semantics literally -- every backward outside `no_sync()` exchanges, overlapped.
+  * Per slice: in-place reduce-scatter + all-gather (`algo="rs_ag"`) or one all-reduce (`algo="allreduce"`); `calibrate()`
+    times both on a layer slice and keeps the faster (identical result on every rank: decided on the max over ranks).
+Transports: the C-ABI communicator `RcclComm` (default on GPUs) or torch.distributed (`NAVILLM_COMM=torch`; the only one for
+the CPU/gloo tests).  `no_sync()` and `.module` follow the DDP protocol the agent relies on (mp3d_agent.py:661-676).
 """
 import contextlib
+import ctypes
 import os
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -23,7 +33,8 @@ def world_info_from_env():
 
 
 def init_distributed_device(backend=None):
-    """-> (device, rank, world_size). env:// rendezvous, one GPU per process."""
+    """-> (device, rank, world_size). env:// rendezvous, one GPU per process.  The torch.distributed group is the CONTROL
+    plane (rendezvous, barriers, the bench's max-over-ranks clock); gradients travel through `RcclComm`."""
     local_rank, rank, world = world_info_from_env()
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
@@ -42,36 +53,51 @@ def init_distributed_device(backend=None):
 
 
 class RcclComm:
-    """The C-ABI communicator (`nv_comm_*`, include/navillm_hip.h) for hosts that do not want torch.distributed in
-    the data path: rank 0 draws the RCCL unique id, the other ranks receive it through `exchange` (any
-    `bytes -> bytes` broadcast: a TCPStore, a file, MPI); collectives run on the CURRENT torch stream, in place.
+    """The C-ABI communicator (`nv_comm_*`, include/navillm_hip.h): rank 0 draws the RCCL unique id, the other ranks receive
+    it through `exchange` (any `bytes -> bytes` broadcast); collectives run on the CURRENT torch stream, in place.
 
-    `NavDataParallel(model, comm=RcclComm(...))` or `NAVILLM_COMM=rccl` selects it; the default exchange uses a
-    `torch.distributed.TCPStore` on MASTER_PORT+1 (control plane only)."""
+    Default exchange: the already initialised torch.distributed group when there is one (control plane only), else a
+    `torch.distributed.TCPStore` on MASTER_PORT+1 that rank 0 keeps alive until every rank has read the id."""
 
     def __init__(self, rank, world, exchange=None):
-        import ctypes
         from . import lib as _lib
         self._lib, self._L = _lib, _lib.load()
         self.rank, self.world = rank, world
+        self._store = None
         n = self._L.nv_comm_unique_id_bytes()
         uid = ctypes.create_string_buffer(n)
         if rank == 0:
             _lib.check(self._L.nv_comm_unique_id(uid), "nv_comm_unique_id")
         if world > 1:
-            exchange = exchange or self._tcp_exchange
+            exchange = exchange or self._default_exchange
             raw = exchange(uid.raw if rank == 0 else None)
-            uid = ctypes.create_string_buffer(raw, n)
+            uid = ctypes.create_string_buffer(bytes(raw), n)
         self._ctx = ctypes.c_void_p()
         _lib.check(self._L.nv_comm_init(ctypes.byref(self._ctx), uid, rank, world), "nv_comm_init")
+        if self._store is not None:
+            # rank 0 owns the store's server: it may only go away once every rank is past its get()
+            self._store.add("nv_comm_ready", 1)
+            if rank == 0:
+                deadline = time.time() + 300
+                while int(self._store.add("nv_comm_ready", 0)) < world and time.time() < deadline:
+                    time.sleep(0.01)
+            self._store = None
 
-    def _tcp_exchange(self, payload):
-        store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 1,
-                              self.world, self.rank == 0)
+    def _default_exchange(self, payload):
+        n = self._L.nv_comm_unique_id_bytes()
+        if dist.is_initialized() and dist.get_world_size() == self.world:
+            on_gpu = dist.get_backend() == "nccl"
+            t = torch.zeros(n, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+            if self.rank == 0:
+                t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+            dist.broadcast(t, src=0)
+            return bytes(t.cpu().numpy().tobytes())
+        self._store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 1,
+                                    self.world, self.rank == 0)
         if self.rank == 0:
-            store.set("nv_comm_uid", payload)
+            self._store.set("nv_comm_uid", payload)
             return payload
-        return store.get("nv_comm_uid")
+        return self._store.get("nv_comm_uid")
 
     @staticmethod
     def _stream():
@@ -80,6 +106,15 @@ class RcclComm:
     def allreduce_mean_(self, t):
         fn = {torch.bfloat16: self._L.nv_comm_allreduce_bf16, torch.float32: self._L.nv_comm_allreduce_f32}[t.dtype]
         self._lib.check(fn(self._ctx, t.data_ptr(), t.numel(), 1, self._stream()), "nv_comm_allreduce")
+        return t
+
+    def reduce_scatter_all_gather_mean_(self, t):
+        """mean over ranks in two in-place phases; t.numel() % world == 0"""
+        assert t.dtype in (torch.bfloat16, torch.float32) and t.numel() % self.world == 0
+        s = self._stream()
+        self._lib.check(self._L.nv_comm_reduce_scatter(self._ctx, t.data_ptr(), t.numel(), 1 if t.dtype == torch.bfloat16 else 0, 1, s),
+                        "nv_comm_reduce_scatter")
+        self._lib.check(self._L.nv_comm_all_gather(self._ctx, t.data_ptr(), t.numel() * t.element_size(), s), "nv_comm_all_gather")
         return t
 
     def broadcast_(self, t, root=0):
@@ -94,8 +129,8 @@ class RcclComm:
 
 
 def _allreduce_mean_(t, group=None):
-    """In-place mean over ranks, enqueued on the CURRENT stream (SUM collective, then a 1/world scale:
-    the plainest RCCL call there is; for bf16 the scale is our own HIP kernel)."""
+    """torch.distributed transport: in-place mean over ranks on the CURRENT stream (SUM collective, then a 1/world scale;
+    for bf16 on the GPU the scale is our own HIP kernel)."""
     world = dist.get_world_size(group)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     if t.is_cuda and t.dtype == torch.bfloat16 and t.numel() % 8 == 0:
@@ -106,7 +141,7 @@ def _allreduce_mean_(t, group=None):
 
 
 class GradSlices:
-    """The ordered list of contiguous gradient slices exchanged per synced backward."""
+    """The ordered list of contiguous gradient slices exchanged per reduction."""
 
     def __init__(self, store):
         self.store = store
@@ -122,25 +157,53 @@ class GradSlices:
 
 
 class NavDataParallel(torch.nn.Module):
-    def __init__(self, module, group=None, overlap=True, comm=None, force_sync=False):
+    def __init__(self, module, group=None, overlap=True, comm=None, force_sync=False, reduce=None, algo=None):
         super().__init__()
         self.module = module
         self.group = group
-        if comm is None and os.environ.get("NAVILLM_COMM") == "rccl" and module.store.device.type == "cuda":
+        on_gpu = module.store.device.type == "cuda"
+        if comm is None and on_gpu and os.environ.get("NAVILLM_COMM", "rccl") != "torch":
             _, rank, world = world_info_from_env()
-            comm = RcclComm(rank, world)
+            if dist.is_initialized():
+                rank, world = dist.get_rank(group), dist.get_world_size(group)
+            if world > 1 or force_sync:
+                comm = RcclComm(rank, world)
         self.force_sync = force_sync     # run the exchange even in a world of one (single-GPU test of the stream/event wiring)
-        self.comm = comm                 # None: torch.distributed (RCCL through ProcessGroupNCCL); else the C-ABI communicator
+        self.comm = comm                 # the C-ABI communicator; None: torch.distributed (gloo on CPU, NAVILLM_COMM=torch)
         self.overlap = overlap
+        self.reduce = reduce or os.environ.get("NAVILLM_DP_REDUCE", "step")
+        assert self.reduce in ("step", "backward")
+        self.algo = algo or os.environ.get("NAVILLM_DP_ALGO", "rs_ag")
+        assert self.algo in ("rs_ag", "allreduce")
         self.require_sync = True
+        self._final = False              # inside final_backward(): this backward exchanges, overlapped
+        self._pending = False            # reduce="step": local gradients not yet averaged over ranks
         self.slices = GradSlices(module.store)
-        self._comm_stream = torch.cuda.Stream() if module.store.device.type == "cuda" else None
+        self._comm_stream = torch.cuda.Stream() if on_gpu else None
         self._queued = False
-        module._dp = self
+        self.calibration = None
+        # back-reference WITHOUT module registration: `module._dp = self` would make the wrapper a child module of the model
+        # it wraps (a cycle: .train()/.eval()/.state_dict() then recurse forever)
+        object.__setattr__(module, "_dp", self)
         self.broadcast_parameters()
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
+
+    # ---- transport
+    def _world(self):
+        if self.comm is not None:
+            return self.comm.world
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _reduce(self, t, algo=None):
+        if self.comm is not None:
+            if (algo or self.algo) == "rs_ag" and t.numel() % self.comm.world == 0:
+                self.comm.reduce_scatter_all_gather_mean_(t)
+            else:
+                self.comm.allreduce_mean_(t)
+        else:
+            _allreduce_mean_(t, self.group)
 
     @torch.no_grad()
     def broadcast_parameters(self):
@@ -149,15 +212,46 @@ class NavDataParallel(torch.nn.Module):
             if self.comm.world > 1:
                 for t in self.module.store.param.values():
                     self.comm.broadcast_(t, 0)
+                probe = torch.zeros(1024, dtype=torch.float32, device=self.module.store.device)
+                self._reduce(probe)          # channel setup for the collectives of the first exchange
             return
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
             for t in self.module.store.param.values():
                 dist.broadcast(t, src=0, group=self.group)
-            # touch the all-reduce path once (communicator/channel setup) so the first synced backward
-            # does not pay for it
             probe = torch.zeros(1024, dtype=torch.float32, device=self.module.store.device)
             dist.all_reduce(probe, group=self.group)
 
+    @torch.no_grad()
+    def calibrate(self, iters=2):
+        """time all-reduce vs reduce-scatter+all-gather on one decoder-layer gradient slice and keep the faster for every
+        slice.  The slice's content is irrelevant and is restored; all ranks take the same decision (max over ranks)."""
+        if self.comm is None or self.comm.world < 2:
+            return None
+        t = self.slices.layer[0]
+        keep = t.clone()
+        res = {}
+        for algo in ("allreduce", "rs_ag"):
+            self._reduce(t, algo)                      # warm the channels of this collective
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                self._reduce(t, algo)
+            torch.cuda.synchronize()
+            dt = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float32, device=t.device)
+            # max over ranks through the communicator itself: mean of (x_r * world) would need a max -- use sum of one-hot
+            # slots instead: rank r writes slot r, all-reduce(mean) * world, then max on the host
+            slots = torch.zeros(self.comm.world, dtype=torch.float32, device=t.device)
+            slots[self.comm.rank] = dt[0] * self.comm.world
+            self.comm.allreduce_mean_(slots)
+            res[algo] = float(slots.max().item())
+        t.copy_(keep)
+        self.algo = "rs_ag" if res["rs_ag"] <= res["allreduce"] else "allreduce"
+        nbytes = t.numel() * t.element_size()
+        self.calibration = {"slice_bytes": nbytes, "seconds": res, "chosen": self.algo,
+                            "algbw_GBps": {k: round(nbytes / v / 1e9, 1) for k, v in res.items()}}
+        return self.calibration
+
+    # ---- the DDP protocol
     @contextlib.contextmanager
     def no_sync(self):
         old, self.require_sync = self.require_sync, False
@@ -166,36 +260,41 @@ class NavDataParallel(torch.nn.Module):
         finally:
             self.require_sync = old
 
+    @contextlib.contextmanager
+    def final_backward(self):
+        """`reduce="step"`: the backward(s) run inside this context are the last before the optimizer step; the exchange is
+        launched from inside them, overlapped with the remaining backward GEMMs."""
+        old, self._final = self._final, True
+        try:
+            yield
+        finally:
+            self._final = old
+
+    def _exchanging(self):
+        """does the backward that is starting now exchange gradients?"""
+        if not (self._world() > 1 or self.force_sync):
+            return False
+        if self.reduce == "backward":
+            return self.require_sync
+        return self._final
+
     # ---- hooks called from LlamaStack.backward
-    def _world(self):
-        if self.comm is not None:
-            return self.comm.world
-        return dist.get_world_size(self.group) if dist.is_initialized() else 1
-
-    def _reduce(self, t):
-        if self.comm is not None:
-            self.comm.allreduce_mean_(t)
-        else:
-            _allreduce_mean_(t, self.group)
-
-    def _active(self):
-        return self.require_sync and (self._world() > 1 or self.force_sync)
-
     def on_backward_begin(self):
-        if not self._active() or self._queued:
+        if self.reduce == "step" and not self._final and (self._world() > 1 or self.force_sync):
+            self._pending = True            # accumulated locally; flush() or a final_backward() will average it
+        if not self._exchanging() or self._queued:
             return
         self._queued = True
         torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
     def on_layer_done(self, i, events=()):
-        if not self._active() or not self.overlap:
+        if not self._exchanging() or not self.overlap:
             return
         self._launch(self.slices.layer[i], events)
 
     def _launch(self, t, events=()):
-        """all-reduce slice `t` on the side stream, ordered after everything enqueued so far on the compute
-        stream and after `events` (the wgrad GEMMs of that layer, which run on their own stream); the host
-        does not block."""
+        """exchange slice `t` on the side stream, ordered after everything enqueued so far on the compute stream and after
+        `events` (the wgrad GEMMs of that layer when they run on their own stream); the host does not block."""
         if self._comm_stream is not None:
             self._comm_stream.wait_stream(torch.cuda.current_stream())
             for e in events:
@@ -206,26 +305,38 @@ class NavDataParallel(torch.nn.Module):
             self._reduce(t)
 
     def _finalize(self):
-        """end of the autograd pass: reduce what is left, then join the side stream."""
+        """end of the autograd pass: exchange what is left, then join the side stream."""
         self._queued = False
         todo = self.slices.rest if self.overlap else self.slices.all_slices()
         for t in todo:
             self._launch(t)
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._pending = False
+
+    @torch.no_grad()
+    def flush(self):
+        """`reduce="step"`: average whatever was accumulated locally since the last exchange (no-op when a final_backward()
+        already did).  Called by FlatAdamW before the clip / the update."""
+        if self._pending:
+            self.sync_gradients()
 
     @torch.no_grad()
     def sync_gradients(self):
-        """Explicit one-shot reduction (e.g. once per optimizer step instead of per synced backward;
-        mathematically the same mean)."""
-        if self._world() > 1:
+        """Explicit one-shot reduction of every slice."""
+        if self._world() > 1 or self.force_sync:
             for t in self.slices.all_slices():
-                self._reduce(t)
+                self._launch(t)
+            if self._comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._pending = False
 
 
-def broadcast_task_id(task_id, device, group=None):
+def broadcast_task_id(task_id, device, group=None, comm=None):
     """tasks/loaders.py:176-179: rank 0 picks the task, everyone follows (1 x int64)."""
     t = torch.tensor([task_id], dtype=torch.int64, device=device)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if comm is not None and comm.world > 1:
+        comm.broadcast_(t, 0)
+    elif dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(t, src=0, group=group)
     return int(t.item())

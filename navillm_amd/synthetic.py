@@ -219,12 +219,19 @@ class SyntheticEpisodes:
             self.gmaps[b].update_graph(self.obs[b])
 
 
-def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accum=1):
-    """One iteration of the rollout loop for all B episodes. Returns (loss tensor or None, logits)."""
+def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accum=1, final=None):
+    """One iteration of the rollout loop for all B episodes. Returns (loss tensor or None, logits).
+    last: the episode's last step (mp3d_agent.py:661-676: every earlier step runs inside `no_sync`).
+    final: this step's backward is the LAST one before the optimizer step (default: `last`); a `NavDataParallel` wrapper then
+    exchanges the accumulated gradients from inside it, overlapped (navillm_amd/parallel.py)."""
     inner = model.module if hasattr(model, "module") else model
+    final = last if final is None else final
     ctx = contextlib.nullcontext
-    if train and hasattr(model, "no_sync") and not last:
-        ctx = model.no_sync
+    if train and hasattr(model, "no_sync"):
+        if not last:
+            ctx = model.no_sync
+        elif final and hasattr(model, "final_backward"):
+            ctx = model.final_backward
     with ctx():
         pin = ep.panorama_inputs()
         pano = model("panorama", pin)

@@ -65,28 +65,63 @@ def _worker(rank, world, port, q):
     # rank-dependent parameters: the wrapper must broadcast rank 0's
     for t in model.store.param.values():
         t.fill_(float(rank + 1))
-    ddp = NavDataParallel(model)
+    ddp = NavDataParallel(model, reduce="backward")
     ok = all(bool((t.float() == 1.0).all()) for t in model.store.param.values())
+    # the wrapper must not become a child module of the model it wraps (.train()/.eval()/.state_dict() recursed)
+    ddp.train(); ddp.eval(); model.train(); model.eval()
+    ddp.state_dict(); model.state_dict()
+    ok &= model._dp is ddp and "_dp" not in dict(model.named_children())
     st = model.store
     x = torch.ones(1, requires_grad=True)
-    # step 1: inside no_sync -> purely local accumulation
+    mean_rank = sum(r_ + 1 for r_ in range(world)) / world          # mean of (rank+1)
+    s0, e0 = st.layer_slice(0)
+
+    def all_mean(k):
+        good = True
+        for i in range(cfg.num_layers):
+            s, e = st.layer_slice(i)
+            good &= bool(torch.allclose(st.grad["lm"][s:e].float(), torch.full((e - s,), k * mean_rank * (i + 1)), rtol=1e-2))
+        good &= bool(torch.allclose(st.grad["f32"], torch.full_like(st.grad["f32"], k * mean_rank * 0.5)))
+        good &= bool(torch.allclose(st.grad["lm"][:s0].float(), torch.full((s0,), k * mean_rank * 7.0), rtol=1e-2))
+        return good
+
+    def all_local(k):
+        return abs(float(st.grad["lm"][s0].float()) - k * (rank + 1) * 1.0) < 1e-6 and \
+            bool(torch.allclose(st.grad["f32"], torch.full_like(st.grad["f32"], k * (rank + 1) * 0.5)))
+
+    # ---- reduce="backward" (DDP semantics).  step 1: inside no_sync -> purely local accumulation
     with ddp.no_sync():
         _Backward.apply(x, model, rank, 1.0).sum().backward()
-    s0, e0 = st.layer_slice(0)
-    ok &= abs(float(st.grad["lm"][s0].float()) - (rank + 1) * 1.0) < 1e-6
+    ok &= all_local(1)
     # step 2: synced backward -> every slice becomes the mean over ranks of the ACCUMULATED gradient
     _Backward.apply(x, model, rank, 1.0).sum().backward()
-    mean_rank = sum(r_ + 1 for r_ in range(world)) / world          # mean of (rank+1)
-    for i in range(cfg.num_layers):
-        s, e = st.layer_slice(i)
-        want = 2 * mean_rank * (i + 1)
-        ok &= bool(torch.allclose(st.grad["lm"][s:e].float(), torch.full((e - s,), want), rtol=1e-2))
-    ok &= bool(torch.allclose(st.grad["f32"], torch.full_like(st.grad["f32"], 2 * mean_rank * 0.5)))
-    ok &= bool(torch.allclose(st.grad["lm"][:s0].float(), torch.full((s0,), 2 * mean_rank * 7.0), rtol=1e-2))
+    ok &= all_mean(2)
     # explicit one-shot reduction is idempotent on already-averaged gradients
     before = st.grad["f32"].clone()
     ddp.sync_gradients()
     ok &= bool(torch.allclose(st.grad["f32"], before))
+
+    # ---- reduce="step" (default): nothing moves until the optimizer step, then exactly once
+    st.zero_grad()
+    ddp.reduce = "step"
+    with ddp.no_sync():
+        _Backward.apply(x, model, rank, 1.0).sum().backward()
+    _Backward.apply(x, model, rank, 1.0).sum().backward()          # "synced" backwards of the last step: still local
+    _Backward.apply(x, model, rank, 1.0).sum().backward()
+    ok &= all_local(3) and ddp._pending
+    ddp.flush()                                                     # what FlatAdamW.clip_grad_norm_/step call first
+    ok &= all_mean(3) and not ddp._pending
+    ddp.flush()                                                     # nothing pending: no second averaging
+    ok &= all_mean(3)
+    # ... or overlapped with the last backward before the step
+    st.zero_grad()
+    with ddp.no_sync():
+        _Backward.apply(x, model, rank, 1.0).sum().backward()
+    with ddp.final_backward():
+        _Backward.apply(x, model, rank, 1.0).sum().backward()
+    ok &= all_mean(2) and not ddp._pending
+    ddp.flush()
+    ok &= all_mean(2)
     # task-id broadcast (tasks/loaders.py:176-179)
     ok &= broadcast_task_id(5 if rank == 0 else 9, dev) == 5
     q.put((rank, bool(ok)))

@@ -1,8 +1,14 @@
-"""The data-parallel wrapper on a real GPU with a world of one (the box has a single MI355X): RCCL all-reduces of the flat
-gradient slices are launched from inside the backward on the communication stream, ordered after the wgrad GEMMs of the
-side stream by events, and joined at the end of the autograd pass.  With one rank every all-reduce is the identity, so
-the gradients must equal the plain run's bit for bit -- what this checks is the stream/event/callback wiring under the
-real runtime, for both transports (torch.distributed/nccl and the C-ABI nv_comm_*)."""
+"""The data-parallel wrapper on real GPUs.
+
+World of one (the test box has a single MI355X): RCCL collectives on the flat gradient slices are launched from inside the
+backward on the communication stream and joined at the end of the autograd pass.  With one rank every collective is the
+identity, so the gradients must equal the plain run's bit for bit -- what this checks is the stream/event/callback wiring
+under the real runtime, for both transports (the C-ABI nv_comm_* default and torch.distributed/nccl), both reduction points
+(`step`: once, from the final backward or from the optimizer's flush; `backward`: DDP's) and both algorithms.
+
+World of two (runs when the box has >= 2 GPUs): two real ranks, real `LlamaStack.backward`, gradients must equal the mean of
+the two single-rank gradients (tools/optims.py:52-54, mp3d_agent.py:661-676)."""
+import os
 import socket
 
 import pytest
@@ -13,42 +19,116 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _step(model, wrapped, seed):
+def _cfg():
+    from navillm_amd import config as nvcfg
+    return nvcfg.NavConfig(hidden_size=512, num_layers=3, num_heads=4, intermediate_size=1408, base_vocab_size=1000,
+                           enc_hidden_size=256, enc_num_heads=4, enc_intermediate_size=512, image_feat_size=768)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _step(model, wrapped, seed, dev=DEV, final=True):
     from navillm_amd.synthetic import SyntheticEpisodes, nav_step
     from navillm_amd.losses import CrossEntropyLoss
-    ep = SyntheticEpisodes(model.cfg, 3, seed=seed, instr_len=150, device=torch.device(DEV))
+    ep = SyntheticEpisodes(model.cfg, 3, seed=seed, instr_len=150, device=torch.device(dev))
     crit = CrossEntropyLoss()
     model.zero_grad()
     torch.manual_seed(1)
     for i in range(2):
-        nav_step(wrapped, crit, ep, train=True, last=(i == 1))      # step 0 inside no_sync, step 1 synced
+        nav_step(wrapped, crit, ep, train=True, last=(i == 1), final=final and i == 1)   # step 0 inside no_sync
     torch.cuda.synchronize()
     return {k: v.clone() for k, v in model.store.grad.items()}
 
 
-@pytest.mark.parametrize("transport", ["torch", "rccl"])
-def test_dp_wrapper_world1_matches_plain_run(transport):
-    from navillm_amd import config as nvcfg
+@pytest.mark.parametrize("transport,reduce,algo", [("rccl", "step", "rs_ag"), ("rccl", "step", "allreduce"),
+                                                   ("rccl", "backward", "rs_ag"), ("torch", "step", "allreduce"),
+                                                   ("rccl", "flush", "rs_ag")])
+def test_dp_wrapper_world1_matches_plain_run(transport, reduce, algo, monkeypatch):
     from navillm_amd.nav_model import NavModel
     from navillm_amd.parallel import NavDataParallel, RcclComm
-    cfg = nvcfg.NavConfig(hidden_size=512, num_layers=3, num_heads=4, intermediate_size=1408, base_vocab_size=1000,
-                          enc_hidden_size=256, enc_num_heads=4, enc_intermediate_size=512, image_feat_size=768)
-    model = NavModel(nav_config=cfg, device=torch.device(DEV), seed=4)
+    from navillm_amd.optim import FlatAdamW
+    model = NavModel(nav_config=_cfg(), device=torch.device(DEV), seed=4)
     model.train()
     base = _step(model, model, 17)
     comm = None
     if transport == "torch":
+        monkeypatch.setenv("NAVILLM_COMM", "torch")
         if not dist.is_initialized():
-            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", world_size=1, rank=0,
                                     device_id=torch.device(DEV))
     else:
         comm = RcclComm(0, 1)
-    ddp = NavDataParallel(model, comm=comm, force_sync=True)
-    got = _step(model, ddp, 17)
-    model._dp = None
+    flush = reduce == "flush"
+    ddp = NavDataParallel(model, comm=comm, force_sync=True, reduce="step" if flush else reduce, algo=algo)
+    assert (ddp.comm is None) == (transport == "torch")
+    # the back-reference must not register the wrapper as a child of the model it wraps
+    ddp.train(); model.train(); model.state_dict(); ddp.state_dict()
+    got = _step(model, ddp, 17, final=not flush)
+    if flush:
+        assert ddp._pending                      # nothing exchanged yet: the optimizer's flush does it, once
+        opt = FlatAdamW(model, lr=0.0)
+        opt.clip_grad_norm_(40.0)
+        torch.cuda.synchronize()
+        got = {k: v.clone() for k, v in model.store.grad.items()}
+    assert not ddp._pending
+    object.__setattr__(model, "_dp", None)
     for k in base:
-        assert torch.equal(base[k], got[k]), f"{transport}: gradient buffer {k} differs from the plain run"
+        assert torch.equal(base[k], got[k]), f"{transport}/{reduce}/{algo}: gradient buffer {k} differs from the plain run"
     assert float(base["lm"].float().abs().sum()) > 0
     if comm is not None:
         comm.close()
+
+
+def _rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.parallel import init_distributed_device, NavDataParallel
+    dev, r, w = init_distributed_device()
+    model = NavModel(nav_config=_cfg(), device=dev, seed=4 + rank)       # rank-dependent weights: the wrapper broadcasts rank 0's
+    model.train()
+    ddp = NavDataParallel(model)
+    cal = ddp.calibrate(iters=1)
+    p0 = {k: v.clone().cpu() for k, v in model.store.param.items()}
+    g = _step(model, ddp, 100 + rank, dev=str(dev))
+    q.put((rank, {k: v.cpu() for k, v in g.items()}, p0, cal))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_dp_world2_real_backward_matches_mean_of_single_rank_gradients():
+    import torch.multiprocessing as mp
+    from navillm_amd.nav_model import NavModel
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+    (_, g0, p0, cal0), (_, g1, p1, _) = res
+    for k in g0:
+        assert torch.equal(p0[k], p1[k]), "parameters were not broadcast from rank 0"
+        assert torch.equal(g0[k], g1[k]), "ranks disagree on the averaged gradient"
+    assert cal0 is not None and cal0["chosen"] in ("rs_ag", "allreduce")
+    # reference: the two ranks' batches on ONE GPU with rank 0's weights, averaged
+    model = NavModel(nav_config=_cfg(), device=torch.device(DEV), seed=4)
+    model.train()
+    a = _step(model, model, 100)
+    b = _step(model, model, 101)
+    for k in a:
+        want = (a[k].float() + b[k].float()) * 0.5
+        got = g0[k].float().to(want.device)
+        err = (got - want).abs().max().item()
+        scale = want.abs().max().item()
+        assert err <= 0.01 * scale + 1e-6, (k, err, scale)

@@ -146,3 +146,88 @@ def test_config_from_hf_dir_and_special_ids():
     assert (cfg.hidden_size, cfg.num_layers, cfg.num_heads, cfg.intermediate_size, cfg.base_vocab_size) == \
         (t.hidden_size, t.num_layers, t.num_heads, t.intermediate_size, t.base_vocab_size)
     assert cfg.special_token_ids == tuple(range(250, 255)) and cfg.pad_token_id == 255 and cfg.vocab_size == 256
+
+
+class _ParamModel(torch.nn.Module):
+    """FlatStore on the CPU + nn.Parameters that are views into it (what NavModel builds on the GPU)"""
+
+    def __init__(self, cfg):
+        super().__init__()
+        from navillm_amd.flat import FlatStore
+        from navillm_amd.params import param_specs
+        self.cfg, self.store = cfg, FlatStore(cfg, "cpu")
+        self._dp = None
+        self.plist = torch.nn.ParameterList([torch.nn.Parameter(self.store.p(n)) for n, _, _ in param_specs(cfg)])
+
+
+def test_flat_adamw_is_a_torch_optimizer_and_tracks_first_gradients():
+    """tools/optims.py:43-47 + train.py:91: the reference hands its optimizer to a LambdaLR scheduler; torch's AdamW skips
+    parameters that never had a gradient and counts steps per parameter."""
+    from navillm_amd.optim import FlatAdamW, active_segments, constant_schedule_with_warmup
+    cfg = tiny_cfg("bf16")
+    m = _ParamModel(cfg)
+    opt = FlatAdamW(m, lr=3e-5)
+    assert isinstance(opt, torch.optim.Optimizer)
+    sched = constant_schedule_with_warmup(opt, num_warmup_steps=4)          # LambdaLR: raises TypeError on a non-Optimizer
+    assert opt.param_groups[0]["initial_lr"] == 3e-5 and abs(opt.lr - 0.0) < 1e-12
+    for _ in range(5):
+        sched.step()
+    assert abs(opt.lr - 3e-5) < 1e-12
+    st = m.store
+    # nothing touched: no segment; then the decoder layers + a head; later lm_head joins with its own step origin
+    assert all(len(v) == 0 for v in active_segments(st, {}).values())
+    st.touch_layers()
+    st.touch("out_head.0.weight", "out_head.0.bias", "lang_model.model.embed_tokens.weight")
+    born = {n: 0 for n in st.touched}
+    segs = active_segments(st, born)["lm"]
+    lm_head = st.offsets["lang_model.lm_head.weight"]
+    covered = lambda segs, off: any(s <= off < e for s, e, _ in segs)
+    assert covered(segs, st.offsets["lang_model.model.layers.0.self_attn.q_proj.weight"]) and not covered(segs, lm_head)
+    assert not covered(segs, st.offsets["og_head.0.weight"]) and covered(segs, st.offsets["out_head.0.weight"])
+    assert segs[0][0] == 0 and segs[0][1] == lm_head       # embed | all layers | final norm: ONE contiguous launch
+    born["lang_model.lm_head.weight"] = 7
+    segs2 = active_segments(st, born)["lm"]
+    assert (lm_head, lm_head + st.alloc_sizes["lang_model.lm_head.weight"], 7) in segs2
+    for s, e, _ in segs2:
+        assert s % 64 == 0 and e % 64 == 0
+    # state round trip keeps copies, and refuses a torch.optim.AdamW state
+    opt.born, opt.step_count = dict(born), 9
+    sd = opt.state_dict()
+    assert sd["exp_avg"]["lm"].data_ptr() != st.exp_avg["lm"].data_ptr()
+    opt2 = FlatAdamW(_ParamModel(cfg), lr=1.0)
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 9 and opt2.born == born and abs(opt2.lr - 3e-5) < 1e-12
+    with pytest.raises(ValueError, match="not interchangeable"):
+        opt2.load_state_dict({"state": {}, "param_groups": []})
+
+
+def test_hf_checkpoint_reader_and_reference_scratch_init(tmp_path):
+    """navillm_amd/checkpoint.py (the args-constructor path must load the pretrained LM, not synthetic weights)."""
+    from safetensors.torch import save_file
+    from navillm_amd import checkpoint as ck
+    a = {"model.embed_tokens.weight": torch.randn(10, 4), "model.layers.0.self_attn.rotary_emb.inv_freq": torch.ones(2)}
+    b = {"lm_head.weight": torch.randn(10, 4).to(torch.bfloat16)}
+    save_file(a, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file(b, str(tmp_path / "model-00002-of-00002.safetensors"))
+    got = dict(ck.iter_hf_tensors(str(tmp_path)))
+    assert set(got) == set(a) | set(b) and torch.equal(got["lm_head.weight"], b["lm_head.weight"])
+    assert ck.hf_llama_name("model.layers.0.self_attn.rotary_emb.inv_freq") is None
+    assert ck.hf_llama_name("model.norm.weight") == "lang_model.model.norm.weight"
+    with pytest.raises(FileNotFoundError, match="from_scratch"):
+        list(ck.iter_hf_tensors(str(tmp_path / "nope")))
+    # .bin shards
+    d2 = tmp_path / "bin"
+    d2.mkdir()
+    torch.save(a, str(d2 / "pytorch_model-00001-of-00001.bin"))
+    assert set(dict(ck.iter_hf_tensors(str(d2)))) == set(a)
+    # scratch distributions follow the reference constructor's module defaults
+    t = ck.reference_scratch_tensor("lang_model.model.layers.0.mlp.up_proj.weight", (256, 128), 0)
+    assert abs(float(t.std()) - 0.02) < 2e-3
+    assert torch.equal(ck.reference_scratch_tensor("lang_model.model.norm.weight", (64,), 0), torch.ones(64))
+    assert torch.equal(ck.reference_scratch_tensor("img_embeddings.img_layer_norm.weight", (64,), 0), torch.ones(64))
+    assert torch.equal(ck.reference_scratch_tensor("gmap_pos_embeddings.1.bias", (64,), 0), torch.zeros(64))
+    w = ck.reference_scratch_tensor("img_embeddings.img_linear.weight", (128, 64), 0)
+    assert float(w.abs().max()) <= 1 / 8 + 1e-6 and float(w.abs().max()) > 0.1
+    e = ck.reference_scratch_tensor("gmap_step_embeddings.weight", (100, 64), 0)
+    assert abs(float(e.std()) - 1.0) < 0.05
+    assert ck.reference_scratch_tensor("img_embeddings.img_linear.bias", (128,), 0) is None       # needs fan_in: init_reference_scratch
