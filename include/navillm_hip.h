@@ -84,6 +84,9 @@ int nv_swiglu_fwd_bf16(const void* gu, void* h, int M, int ff, void* stream);
 int nv_swiglu_bwd_bf16(const void* gu, const void* dh, void* dgu, int M, int ff, void* stream);
 
 int nv_scale_bf16(const void* x, void* out, long n, float scale, void* stream);   /* n % 8 == 0 */
+/*   scale read from DEVICE memory; accumulate != 0: out = bf16(out + bf16(x*scale)) (the LM-loss coefficient applied to the
+ *   lm_head gradients without a host round trip, models/modified_lm.py:126-137 + mp3d_agent.py:865,901) */
+int nv_scale_dev_bf16(const void* x, void* out, long n, const float* scale_dev, int accumulate, void* stream);
 int nv_gather_rows_bf16(const void* src, const int* rows, void* out, int n, int d, void* stream);
 int nv_scatter_rows_bf16(const void* src, const int* rows, void* dst, int n, int d, void* stream);
 
@@ -104,6 +107,13 @@ int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int*
  *   each sample's own last 128-row block.  The LM then never computes the left-padding rows of a batch. */
 int nv_attn_fwd_varlen_bf16(const void* qkv, void* out, float* lse2, const int* cu, const int* pos0, int B, int S_max, int H,
                             int head_dim, int q_row_min, void* stream);
+/*   PARITY INSTRUMENT (tests only, not on the product path): the forward with the rounding points of HF's eager
+ *   LlamaAttention in bf16 -- scores = bf16(bf16(q k^T) * hd^-0.5), P = bf16(softmax_fp32(scores)), out = bf16(P v) -- computed in
+ *   two passes.  cu == NULL: padded layout (as nv_attn_fwd_bf16), else packed rows (as nv_attn_fwd_varlen_bf16, kv_start = pos0).
+ *   Used to show that the distance between the product kernel (fp32 scores, flash style) and the reference's bf16 run is this
+ *   difference in rounding points and nothing else. */
+int nv_attn_fwd_hfround_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, const int* cu, int B, int S, int H,
+                             int head_dim, int q_row_min, void* stream);
 int nv_attn_bwd_varlen_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* cu, const int* pos0,
                             void* dqkv, void* workspace, const void* rope_cos, const void* rope_sin, int B, int S_max, long rows,
                             int H, int head_dim, int q_row_min, void* stream);
@@ -162,6 +172,32 @@ int nv_rowscale_f32(const float* x, const float* s, float* out, long rows, int d
 int nv_gather_add_f32(const float* src, const int* idx, const float* base, float* out, long rows, int d, void* stream);
 int nv_index_sum_f32(const float* src, const int* idx, float* dst, int n, int R, int d, int accumulate, void* stream);
 int nv_masked_mean_f32(const float* x, const float* mask, float* out, int B, int N, int d, void* stream);
+
+/* ---- HOST side-car of the navigation step (pure host code, no device pointers): the topological map of
+ *      models/graph_utils.py:47-165 on dense matrices with integer node ids, and the per-step index tables of
+ *      models/nav_model.py:174-190,216-223,234-242.  Output buffers are plain host memory (pinned by the caller so the
+ *      following H2D copies are asynchronous). */
+typedef struct nv_graph nv_graph;
+nv_graph* nv_graph_create(void);
+void nv_graph_destroy(nv_graph* g);
+int nv_graph_add_node(nv_graph* g);                                   /* -> new node id 0,1,2,... */
+int nv_graph_num_nodes(const nv_graph* g);
+int nv_graph_set_position(nv_graph* g, int node, const double* xyz);
+int nv_graph_add_edge(nv_graph* g, int x, int y, double dist);        /* FloydGraph.add_edge, graph_utils.py:59-64 */
+int nv_graph_update(nv_graph* g, int k);                              /* FloydGraph.update,   graph_utils.py:66-75 */
+int nv_graph_visited(const nv_graph* g, int k);
+double nv_graph_distance(const nv_graph* g, int x, int y);            /* 95959595 = no path */
+int nv_graph_path(const nv_graph* g, int x, int y, int* out, int cap);/* FloydGraph.path: -> length, ids [v1..y] */
+/*   GraphMap.get_pos_fts (graph_utils.py:144-165) for n slots at once (ids[i] < 0 = the `None` slot): out [n, angle_feat_size+3] */
+int nv_graph_pos_fts(const nv_graph* g, int cur, const int* ids, int n, double cur_heading, double cur_elevation,
+                     int angle_feat_size, float* out);
+/*   nav_model.py:174-190: src [B*G] (view row feeding each map slot or -1), inv [B*Nv] (its inverse), ttype [B*G] */
+int nv_nav_match_tables(const int* gmap_ids, const unsigned char* gmap_visited, const int* cand_ids, int B, int G, int Nv, int* src,
+                        int* inv, int* ttype);
+/*   nav_model.py:216-223,234-242: candidate rows in LM order under the per-sample permutations, its inverse, and the head
+ *   column of every map slot; returns the number of selected rows */
+int nv_nav_perm_tables(const unsigned char* cand_mask, const long* perm, const int* perm_off, int B, int G, int* sel, int* inv_sel,
+                       long* col);
 
 /* ---- data-parallel exchange over RCCL (C0-C3): replaces the DDP gradient all-reduce behind tools/optims.py:52-54
  *      (+ its initial parameter broadcast) and the task-id broadcast of tasks/loaders.py:176-179.

@@ -7,7 +7,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnavillm_hip.so")
-SOURCES = ["gemm_bf16.hip", "lm_rowops.hip", "attention.hip", "enc_f32.hip", "head_loss_optim.hip", "comm_rccl.hip", "gemv_bf16.hip"]
+SOURCES = ["gemm_bf16.hip", "lm_rowops.hip", "attention.hip", "enc_f32.hip", "head_loss_optim.hip", "comm_rccl.hip", "gemv_bf16.hip",
+           "graph_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
@@ -24,7 +25,7 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         if force or _stale(o, [s, hdr]):
             cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
             if verbose:

@@ -149,6 +149,15 @@ __device__ __forceinline__ int lse_stride(const AttnArgs& p) { return p.cu ? p.S
 
 // =========================================================================== forward
 // grid (ceil(S/128), B*H), 256 threads: wave w owns queries q0 + w*32 .. +31 (two 16-query tiles)
+//
+// HFR = false: the product kernel (flash style: fp32 scores, unnormalised bf16 P, one pass).
+// HFR = true : PARITY INSTRUMENT, not on the product path.  Reproduces the rounding points of HF's eager LlamaAttention
+// in bf16 (transformers modeling_llama.py eager_attention_forward, reached from models/modified_lm.py:112-116):
+//   scores = bf16(q k^T) ; scores = bf16(scores * hd^-0.5) ; P = bf16(softmax_fp32(scores)) ; out = bf16(P v)
+// which needs the row's final max and sum before P can be rounded -> two passes over the key tiles (pass 0: statistics,
+// pass 1: normalised bf16 P and the PV product).  tests/test_round2_gpu.py uses it to show that the ~1e-2 distance
+// between the product kernel and the reference's bf16 run is exactly this difference in rounding points.
+template <bool HFR>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
@@ -194,6 +203,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             stage_rows<64, 256>(rs, smem + buf * 2 * TILE, kt * 64, kcol, ld, tid);
             stage_rows<64, 256>(rs, smem + buf * 2 * TILE + TILE, kt * 64, vcol, ld, tid);
         };
+        float hf_inv[2] = {0.f, 0.f};
+#pragma unroll 1
+        for (int pass = 0; pass < (HFR ? 2 : 1); ++pass) {
+        if (HFR && pass == 1) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float lt = grp_sum(l[j]);
+                hf_inv[j] = lt > 0.f ? 1.f / lt : 0.f;
+            }
+        }
         stage(kt_beg, 0);
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -220,7 +239,43 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
             }
             // ---- mask + online softmax (per query = per lane&15).  Key tiles entirely below this wave's first query and
             // entirely at/after the left padding need no mask at all (wave-uniform test): most tiles of a long prompt.
-            const bool interior = (kt * 64 + 63 <= q0 + wave * 32) && (kt * 64 >= kvs);
+            const bool interior = !HFR && (kt * 64 + 63 <= q0 + wave * 32) && (kt * 64 >= kvs);
+            if constexpr (HFR) {
+                constexpr float LOG2E = 1.4426950408889634f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kt * 64 + i * 16 + g * 4 + r;
+                            const bool ok = (key <= qpos[j]) && (key >= kvs);
+                            const float v = ok ? rbf(rbf(s[i][j][r]) * p.scale) * LOG2E : -INFINITY;   // HF's two bf16 roundings
+                            s[i][j][r] = v;
+                            mx = fmaxf(mx, v);
+                        }
+                    if (pass == 0) {
+                        mx = grp_max(mx);
+                        const float mn = fmaxf(m2[j], mx);
+                        const float msafe = (mn == -INFINITY) ? 0.f : mn;
+                        const float alpha = fast_exp2(m2[j] - msafe);
+                        m2[j] = mn;
+                        float rs_ = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) rs_ += fast_exp2(s[i][j][r] - msafe);
+                        l[j] = l[j] * alpha + rs_;
+                    } else {
+                        const float msafe = (m2[j] == -INFINITY) ? 0.f : m2[j];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s[i][j][r] = fast_exp2(s[i][j][r] - msafe) * hf_inv[j];   // normalised P (bf16 in pack_frag)
+                    }
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float mx = -INFINITY;                          // max of the RAW scores (scale2 > 0 commutes with max)
@@ -259,7 +314,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
                 for (int dt = 0; dt < 8; ++dt) o[dt][j] *= alpha;
             }
+            }
             // ---- O^T += V^T P^T : k = keys (two 32-key steps), 8 d tiles
+            if (!HFR || pass == 1) {
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 bf16x8 pf[2];
@@ -273,9 +330,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
                         o[dt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[j], o[dt][j], 0, 0, 0);
                 }
             }
+            }
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             cur ^= 1;
+        }
         }
     }
     // ---- finalize
@@ -283,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     for (int j = 0; j < 2; ++j) {
         const float lt = grp_sum(l[j]);
         const bool valid = qpos[j] < S;
-        const float inv = lt > 0.f ? 1.f / lt : 0.f;
+        const float inv = HFR ? (lt > 0.f ? 1.f : 0.f) : (lt > 0.f ? 1.f / lt : 0.f);   // HFR: P was normalised before the PV product
         if (valid) {
             bf16_t* op = p.out + (sq.row0 + qpos[j]) * (p.H * HD) + h * HD + g * 4;
 #pragma unroll
@@ -622,12 +681,12 @@ int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_star
     if (head_dim != HD || (q_row_min & 127) || q_row_min < 0 || (S > 0 && q_row_min >= S)) return NV_ERR_SHAPE;
     if (B == 0 || S == 0) return NV_OK;
     static bool once = false;
-    if (!once) { if (set_lds((const void*)attn_fwd_kernel, 65536)) return NV_ERR_LAUNCH; once = true; }
+    if (!once) { if (set_lds((const void*)attn_fwd_kernel<false>, 65536)) return NV_ERR_LAUNCH; once = true; }
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = kv_start;
     p.B = B; p.S = S; p.Sst = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
-    NV_LAUNCH(attn_fwd_kernel, dim3(B * H, (S - q_row_min + 127) / 128), dim3(256), 65536, (hipStream_t)stream, p);
+    NV_LAUNCH(attn_fwd_kernel<false>, dim3(B * H, (S - q_row_min + 127) / 128), dim3(256), 65536, (hipStream_t)stream, p);
     return nv_check_launch();
 }
 
@@ -639,12 +698,12 @@ int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int*
     if (head_dim != HD || (q_row_min & 127) || q_row_min < 0 || (S > 0 && q_row_min >= S) || S_stride < S) return NV_ERR_SHAPE;
     if (B == 0 || S == 0) return NV_OK;
     static bool once = false;
-    if (!once) { if (set_lds((const void*)attn_fwd_kernel, 65536)) return NV_ERR_LAUNCH; once = true; }
+    if (!once) { if (set_lds((const void*)attn_fwd_kernel<false>, 65536)) return NV_ERR_LAUNCH; once = true; }
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = kv_start;
     p.B = B; p.S = S; p.Sst = S_stride; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
-    NV_LAUNCH(attn_fwd_kernel, dim3(B * H, (S - q_row_min + 127) / 128), dim3(256), 65536, (hipStream_t)stream, p);
+    NV_LAUNCH(attn_fwd_kernel<false>, dim3(B * H, (S - q_row_min + 127) / 128), dim3(256), 65536, (hipStream_t)stream, p);
     return nv_check_launch();
 }
 
@@ -658,13 +717,32 @@ int nv_attn_fwd_varlen_bf16(const void* qkv, void* out, float* lse2, const int* 
     if (head_dim != HD || (q_row_min >= 0 && (q_row_min & 127)) || q_row_min < -1 || (S_max > 0 && q_row_min >= S_max)) return NV_ERR_SHAPE;
     if (B == 0 || S_max == 0) return NV_OK;
     static bool once = false;
-    if (!once) { if (set_lds((const void*)attn_fwd_kernel, 65536)) return NV_ERR_LAUNCH; once = true; }
+    if (!once) { if (set_lds((const void*)attn_fwd_kernel<false>, 65536)) return NV_ERR_LAUNCH; once = true; }
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = pos0; p.cu = cu;
     p.B = B; p.S = S_max; p.Sst = S_max; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
     const int qblocks = q_row_min < 0 ? 1 : (S_max - q_row_min + 127) / 128;
-    NV_LAUNCH(attn_fwd_kernel, dim3(B * H, qblocks), dim3(256), 65536, (hipStream_t)stream, p);
+    NV_LAUNCH(attn_fwd_kernel<false>, dim3(B * H, qblocks), dim3(256), 65536, (hipStream_t)stream, p);
+    return nv_check_launch();
+}
+
+// PARITY INSTRUMENT (tests only; never called by navillm_amd's forward): the same attention with HF's eager-attention rounding
+// points (attn_fwd_kernel<true>, two passes).  cu == NULL: padded [B, S] layout with kv_start; else packed rows (kv_start =
+// pos0).  Same outputs / layouts as nv_attn_fwd_bf16 resp. nv_attn_fwd_varlen_bf16.
+int nv_attn_fwd_hfround_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, const int* cu, int B, int S, int H,
+                             int head_dim, int q_row_min, void* stream) {
+    if (!qkv || !out || !lse2 || !kv_start) return NV_ERR_ARG;
+    if (head_dim != HD || (q_row_min >= 0 && (q_row_min & 127)) || q_row_min < (cu ? -1 : 0) || (S > 0 && q_row_min >= S)) return NV_ERR_SHAPE;
+    if (B == 0 || S == 0) return NV_OK;
+    static bool once = false;
+    if (!once) { if (set_lds((const void*)attn_fwd_kernel<true>, 65536)) return NV_ERR_LAUNCH; once = true; }
+    AttnArgs p{};
+    p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = kv_start; p.cu = cu;
+    p.B = B; p.S = S; p.Sst = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
+    p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
+    const int qblocks = q_row_min < 0 ? 1 : (S - q_row_min + 127) / 128;
+    NV_LAUNCH(attn_fwd_kernel<true>, dim3(B * H, qblocks), dim3(256), 65536, (hipStream_t)stream, p);
     return nv_check_launch();
 }
 

@@ -313,6 +313,27 @@ __global__ __launch_bounds__(256) void scale_bf16_kernel(const bf16_t* __restric
     }
 }
 
+// out = bf16(x * g)  or  out = bf16(out + bf16(x * g)), g read from device memory (the loss coefficient that arrives as the
+// upstream gradient of the LM loss: it never visits the host)
+__global__ __launch_bounds__(256) void scale_dev_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, long n8,
+                                                             const float* __restrict__ g, int accumulate) {
+    const float scale = *g;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
+        float f[8];
+        ld8(x + i * 8, f);
+        if (accumulate) {
+            float o[8];
+            ld8(out + i * 8, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = o[j] + rbf(f[j] * scale);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] *= scale;
+        }
+        st8(out + i * 8, f);
+    }
+}
+
 inline int grid_for(long total, int cap = 256 * 8) {
     long b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -422,6 +443,14 @@ int nv_scale_bf16(const void* x, void* out, long n, float scale, void* stream) {
     if (n == 0) return NV_OK;
     NV_LAUNCH(scale_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                        (bf16_t*)out, n / 8, scale);
+    return nv_check_launch();
+}
+
+int nv_scale_dev_bf16(const void* x, void* out, long n, const float* scale_dev, int accumulate, void* stream) {
+    if (!x || !out || !scale_dev || (n & 7)) return NV_ERR_ARG;
+    if (n == 0) return NV_OK;
+    NV_LAUNCH(scale_dev_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (bf16_t*)out, n / 8, scale_dev, accumulate);
     return nv_check_launch();
 }
 

@@ -3,6 +3,7 @@ stages (scene encoder -> fusion -> LM -> head -> loss); every forward and backwa
 sequence of libnavillm_hip.so launches (navillm_amd/ops.py)."""
 import os
 
+import numpy as np
 import torch
 from . import ops
 
@@ -247,8 +248,19 @@ class EmbedVis(torch.autograd.Function):
         E = ops.embed_vis(table, ids_i32, vis_idx_i32, vis, out=model.arena.scratch["E"][:M])
         ctx.model = model
         ctx.vis_rows = vis_rows_i32
-        ctx.ids_cpu = ids_cpu
         ctx.has_vis = vis is not None
+        ctx.group = None
+        if anchor is not None:
+            # table gradient: token rows grouped by id.  The ids are host data (tokenizer output) and known NOW, so the
+            # grouping (numpy) and its upload happen in the forward, off the backward's critical path
+            ids = np.asarray(ids_cpu).reshape(-1)
+            order = np.argsort(ids, kind="stable")
+            uniq, counts = np.unique(ids, return_counts=True)
+            seg = np.zeros(uniq.size + 1, dtype=np.int32)
+            np.cumsum(counts, out=seg[1:])
+            dev = E.device
+            ctx.group = (ops.h2d(torch.from_numpy(uniq.astype(np.int32)), dev), ops.h2d(torch.from_numpy(seg), dev),
+                         ops.h2d(torch.from_numpy(order.astype(np.int32)), dev))
         return E
 
     @staticmethod
@@ -256,15 +268,8 @@ class EmbedVis(torch.autograd.Function):
         dE = _c(dE)
         st = ctx.model.store
         dvis = ops.vis_grad(dE, ctx.vis_rows) if ctx.has_vis else None
-        # table gradient: group token rows by id on the host (ids are host data: tokenizer output)
-        ids = ctx.ids_cpu.view(-1).long()
-        order = torch.argsort(ids, stable=True)
-        uniq, counts = torch.unique_consecutive(ids[order], return_counts=True)
-        seg = torch.zeros(uniq.numel() + 1, dtype=torch.int32)
-        seg[1:] = torch.cumsum(counts, 0)
-        dev = dE.device
-        ops.embed_grad(dE, ops.h2d(uniq, dev, torch.int32), ops.h2d(seg, dev), ops.h2d(order, dev, torch.int32),
-                       st.g("lang_model.model.embed_tokens.weight"))
+        uniq, seg, order = ctx.group
+        ops.embed_grad(dE, uniq, seg, order, st.g("lang_model.model.embed_tokens.weight"))
         st.touch("lang_model.model.embed_tokens.weight")
         return dvis, None, None, None, None, None, None
 
@@ -355,6 +360,10 @@ class LlamaStack(torch.autograd.Function):
 
         def attention(qkv, a, qmin):
             lse = a["lse"][:B * H * Sm].view(B, H, Sm)
+            if model.attn_hf_rounding:       # parity instrument (tests): HF eager attention's rounding points, forward only
+                if cu is not None:
+                    return ops.attn_fwd_hfround(qkv, kv_start_i32, cu, B, Sm, H, hd, a["attn"][:M], lse, q_row_min=qmin)
+                return ops.attn_fwd_hfround(qkv, kv_start_i32, None, B, S, H, hd, a["attn"][:M], lse, q_row_min=max(qmin, 0))
             if cu is not None:
                 return ops.attn_fwd_varlen(qkv, cu, kv_start_i32, B, Sm, H, hd, out=a["attn"][:M], lse2=lse, q_row_min=qmin)
             return ops.attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=a["attn"][:M], lse2=lse, q_row_min=max(qmin, 0))
@@ -567,34 +576,64 @@ class HeadBF16(torch.autograd.Function):
         return dx, None, None
 
 
+LM_HEAD_CHUNK_ROWS = int(os.environ.get("NAVILLM_LMHEAD_CHUNK", "2048"))
+
+
 class LMHeadLoss(torch.autograd.Function):
-    """lm_head + special-id mask + shifted mean CE (modified_lm.py:119-137).  Logits are materialised
-    once in bf16 and overwritten by their gradient (round-1 form of K9)."""
+    """K9: lm_head + special-id mask + shifted mean CE (modified_lm.py:119-137) WITHOUT the [M, V] logits.
+
+    The token rows go through in chunks of LM_HEAD_CHUNK_ROWS: logits of one chunk ([2048, 32064] bf16 = 131 MB, which stays
+    in the 256 MB Infinity Cache) -> masked log-softmax + NLL, overwritten in place by d(logits) = (p - onehot) / n_valid ->
+    the chunk's dH = dl W and dW += dl^T H right away.  The full logits (M x 32006: 320 MB at B=8, S=650, and three more
+    passes over them) never exist.  Because the loss's upstream gradient g (the caller's `* gen_loss_coef / B / accum`,
+    mp3d_agent.py:865,901; llava.py:38-40) is not known in the forward, dH and dW are formed for g = 1 -- dW in a scratch
+    buffer -- and the backward applies g from DEVICE memory: dH * g, grad_W += g * dW (no host sync, no logits re-read)."""
 
     @staticmethod
     def forward(ctx, Hs, model, labels_shift_i32, n_valid):
         cfg, st = model.cfg, model.store
         W = st.lm_head_padded()                 # [V_pad, d], pad rows are zero
-        V = cfg.vocab_size
-        logits = ops.gemm_bf16(ops.NT, Hs, W)   # [M, V_pad]; pad columns are exactly 0
-        rows = ops.lm_ce_(logits, labels_shift_i32, V, cfg.special_token_ids[0], len(cfg.special_token_ids),
-                          1.0 / max(n_valid, 1), write_grad=True)
+        V, Vp, d = cfg.vocab_size, W.shape[0], W.shape[1]
+        M = Hs.shape[0]
+        need = ctx.needs_input_grad[0]
+        CH = min(LM_HEAD_CHUNK_ROWS, max(M, 1))
+        ws = getattr(model, "_lmhead_ws", None)
+        if ws is None or ws["buf"].shape[0] < CH:
+            ws = model._lmhead_ws = {"buf": torch.empty((CH, Vp), dtype=BF16, device=Hs.device), "dW": None}
+        rows = torch.empty((M,), dtype=F32, device=Hs.device)
+        dH = dW = None
+        if need:
+            if ws["dW"] is None:
+                ws["dW"] = torch.empty((Vp, d), dtype=BF16, device=Hs.device)
+            dW = ws["dW"]
+            dH = torch.empty_like(Hs)
+        inv = 1.0 / max(n_valid, 1)
+        for c0 in range(0, M, CH):
+            c1 = min(M, c0 + CH)
+            hc = Hs[c0:c1]
+            lg = ops.gemm_bf16(ops.NT, hc, W, out=ws["buf"][:c1 - c0])           # pad columns are exactly 0
+            ops.lm_ce_(lg, labels_shift_i32[c0:c1], V, cfg.special_token_ids[0], len(cfg.special_token_ids), inv,
+                       write_grad=need, loss_rows=rows[c0:c1])
+            if need:
+                ops.gemm_bf16(ops.NN, lg, W, out=dH[c0:c1])
+                ops.gemm_bf16(ops.TN, lg, hc, out=dW, epilogue=ops.EPI_STORE if c0 == 0 else ops.EPI_ACCUM)
         loss = (rows.sum() / max(n_valid, 1)).to(BF16)
-        ctx.save_for_backward(Hs, logits)
-        ctx.model = model
+        ctx.model, ctx.dH, ctx.gen = model, dH, None
+        if need:
+            ws["gen"] = ws.get("gen", 0) + 1
+            ctx.gen = ws["gen"]
         return loss
 
     @staticmethod
     def backward(ctx, g):
-        Hs, dl = ctx.saved_tensors              # dl: [M, V_pad], pad columns 0
-        st = ctx.model.store
-        gs = float(g)
-        if gs != 1.0:
-            ops.scale_bf16_(dl, gs)             # loss coefficient applied by the caller after .loss
-        dH = ops.gemm_bf16(ops.NN, dl, st.lm_head_padded())
-        ops.gemm_bf16(ops.TN, dl, Hs, out=st.lm_head_padded(grad=True), epilogue=ops.EPI_ACCUM)
+        ws, st = ctx.model._lmhead_ws, ctx.model.store
+        if ctx.gen != ws.get("gen"):
+            raise RuntimeError("the lm_head gradient scratch was reused by a later LM-loss forward before this backward ran; "
+                               "call backward() right after each loss (as the rollout loop does)")
+        gs = g.reshape(1).float()
+        ops.scale_dev_bf16(ws["dW"], gs, out=st.lm_head_padded(grad=True), accumulate=True)
         st.touch("lang_model.lm_head.weight")
-        return dH, None, None, None
+        return ops.scale_dev_bf16(ctx.dH, gs, out=ctx.dH), None, None, None
 
 
 class ActionCE(torch.autograd.Function):

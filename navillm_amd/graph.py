@@ -1,19 +1,36 @@
-"""Host-side topological map (CPU side-car of the hot path): restatement of
-models/graph_utils.py:18-165 (FloydGraph / GraphMap / relative pose features) on numpy arrays.
+"""Host-side topological map (the CPU side-car of the hot path): the reference's `FloydGraph` / `GraphMap`
+(models/graph_utils.py:47-165) and the per-step index tables of `forward_navigation` (models/nav_model.py:174-190,216-223,
+234-242), served by the C++ side-car behind the C ABI (`nv_graph_*`, `nv_nav_*`: navillm_amd/csrc/graph_host.cpp,
+include/navillm_hip.h).
 
-Same results as the reference's dict-of-dict implementation (pinned by tests/golden/g7_graph.npz),
-but the all-pairs state is a dense matrix so `update` is a vectorised O(n^2) relaxation and
-`get_pos_fts` evaluates all nodes at once (SURVEY.md §8f item 3 "vectorised graph side-car" starts here).
+Same Python surface as the reference classes (viewpoint-id strings in, numpy out), so the agent-side code that drives them
+is unchanged; underneath, nodes are interned to small integers once and every per-step operation is one C call on dense
+matrices: the O(n^2) relaxation per visit, all slots' 7-d pose features in one call, the candidate/map matching tables in one
+call per batch.  Results are pinned by tests/golden/g7_graph.npz (generated from the reference) through this C ABI.
 """
+import ctypes
+
 import numpy as np
+
+from . import lib as _lib
 
 MAX_DIST = 30
 MAX_STEP = 10
 _INF = 95959595  # the reference's "no edge" sentinel (graph_utils.py:49)
+_I32P = ctypes.POINTER(ctypes.c_int)
+
+
+def _L():
+    return _lib.load()
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
 
 
 def calculate_vp_rel_pos_fts(a, b, base_heading=0, base_elevation=0):
-    """graph_utils.py:18-35, vectorised over b: a (3,), b (n,3) -> heading, elevation, dist (n,)"""
+    """graph_utils.py:18-35, vectorised over b: a (3,), b (n,3) -> heading, elevation, dist (n,)  (numpy helper for callers
+    that hold raw positions; the map itself uses nv_graph_pos_fts)"""
     a = np.asarray(a, dtype=np.float64)
     b = np.atleast_2d(np.asarray(b, dtype=np.float64))
     dx, dy, dz = b[:, 0] - a[0], b[:, 1] - a[1], b[:, 2] - a[2]
@@ -33,62 +50,70 @@ def get_angle_fts(headings, elevations, angle_feat_size):
 
 
 class FloydGraph:
-    """graph_utils.py:47-96 on a growing dense matrix."""
+    """graph_utils.py:47-96 over `nv_graph_*`."""
 
     def __init__(self):
+        self._g = ctypes.c_void_p(_L().nv_graph_create())
+        if not self._g:
+            raise MemoryError("nv_graph_create failed")
         self.idx = {}
         self.names = []
-        self.dis = np.zeros((0, 0), dtype=np.float64)
-        self.point = np.zeros((0, 0), dtype=np.int64)   # -1 = direct edge
-        self._visited = set()
+
+    def __del__(self):
+        g, self._g = getattr(self, "_g", None), None
+        if g:
+            try:
+                _L().nv_graph_destroy(g)
+            except Exception:
+                pass
 
     def _id(self, x):
-        if x not in self.idx:
-            n = len(self.names)
-            self.idx[x] = n
+        i = self.idx.get(x)
+        if i is None:
+            i = _L().nv_graph_add_node(self._g)
+            assert i == len(self.names)
+            self.idx[x] = i
             self.names.append(x)
-            d = np.full((n + 1, n + 1), float(_INF))
-            p = np.full((n + 1, n + 1), -1, dtype=np.int64)
-            d[:n, :n] = self.dis
-            p[:n, :n] = self.point
-            self.dis, self.point = d, p
-        return self.idx[x]
+        return i
 
     def distance(self, x, y):
         if x == y:
             return 0
         if x not in self.idx or y not in self.idx:
             return _INF
-        return self.dis[self.idx[x], self.idx[y]]
+        return _L().nv_graph_distance(self._g, self.idx[x], self.idx[y])
 
     def add_edge(self, x, y, dis):
-        i, j = self._id(x), self._id(y)
-        if dis < self.dis[i, j]:
-            self.dis[i, j] = self.dis[j, i] = dis
-            self.point[i, j] = self.point[j, i] = -1
+        _lib.check(_L().nv_graph_add_edge(self._g, self._id(x), self._id(y), float(dis)), "nv_graph_add_edge")
 
     def update(self, k):
-        """relax every pair through k (graph_utils.py:66-75); the reference's sequential sweep and this
-        one-shot relaxation agree because dis[x,k] and dis[k,y] are not themselves improved via k."""
-        kk = self._id(k)
-        via = self.dis[:, kk][:, None] + self.dis[kk, :][None, :]
-        better = via < self.dis
-        np.fill_diagonal(better, False)
-        self.dis = np.where(better, via, self.dis)
-        self.point = np.where(better, kk, self.point)
-        self._visited.add(k)
+        _lib.check(_L().nv_graph_update(self._g, self._id(k)), "nv_graph_update")
 
     def visited(self, k):
-        return k in self._visited
+        i = self.idx.get(k)
+        return i is not None and bool(_L().nv_graph_visited(self._g, i))
 
     def path(self, x, y):
         if x == y:
             return []
-        i, j = self.idx[x], self.idx[y]
-        k = self.point[i, j]
-        if k < 0:
-            return [y]
-        return self.path(x, self.names[k]) + self.path(self.names[k], y)
+        n = len(self.names)
+        buf = (ctypes.c_int * (n + 1))()
+        ln = _L().nv_graph_path(self._g, self.idx[x], self.idx[y], buf, n + 1)
+        if ln < 0:
+            raise _lib.NaviLLMHipError("nv_graph_path failed")
+        return [self.names[buf[i]] for i in range(ln)]
+
+
+class _Positions(dict):
+    """`GraphMap.node_positions`: a dict whose writes are mirrored into the C graph"""
+
+    def __init__(self, owner):
+        super().__init__()
+        self._owner = owner
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v)
+        self._owner._push_position(k, v)
 
 
 class GraphMap:
@@ -96,18 +121,44 @@ class GraphMap:
 
     def __init__(self, start_vp):
         self.start_vp = start_vp
-        self.node_positions = {}
-        self.graph = FloydGraph()
+        self._graph = FloydGraph()
+        self._positions = _Positions(self)
         self.node_embeds = {}
         self.node_step_ids = {}
 
+    # the reference's attributes stay assignable (tests / callers replace them wholesale)
+    @property
+    def graph(self):
+        return self._graph
+
+    @graph.setter
+    def graph(self, g):
+        self._graph = g
+        for k, v in self._positions.items():
+            self._push_position(k, v)
+
+    @property
+    def node_positions(self):
+        return self._positions
+
+    @node_positions.setter
+    def node_positions(self, d):
+        self._positions = _Positions(self)
+        for k, v in dict(d).items():
+            self._positions[k] = v
+
+    def _push_position(self, vp, pos):
+        p = (ctypes.c_double * 3)(*[float(x) for x in pos])
+        _lib.check(_L().nv_graph_set_position(self._graph._g, self._graph._id(vp), p), "nv_graph_set_position")
+
     def update_graph(self, ob):
         self.node_positions[ob["viewpoint"]] = ob["position"]
+        a = np.asarray(ob["position"], dtype=np.float64)
         for cc in ob["candidate"]:
             self.node_positions[cc["viewpointId"]] = cc["position"]
-            a, b = np.asarray(ob["position"], dtype=np.float64), np.asarray(cc["position"], dtype=np.float64)
-            self.graph.add_edge(ob["viewpoint"], cc["viewpointId"], float(np.sqrt(((b - a) ** 2).sum())))
-        self.graph.update(ob["viewpoint"])
+            b = np.asarray(cc["position"], dtype=np.float64)
+            self._graph.add_edge(ob["viewpoint"], cc["viewpointId"], float(np.sqrt(((b - a) ** 2).sum())))
+        self._graph.update(ob["viewpoint"])
 
     def update_node_embed(self, vp, embed, rewrite=False):
         if rewrite or vp not in self.node_embeds:
@@ -127,17 +178,64 @@ class GraphMap:
             e[2] = e[0] / e[1]
         return e[2]
 
-    def get_pos_fts(self, cur_vp, gmap_vpids, cur_heading, cur_elevation, angle_feat_size=4):
-        n = len(gmap_vpids)
-        ang = np.zeros((n, 2), dtype=np.float32)
-        dist = np.zeros((n, 3), dtype=np.float32)
-        real = [i for i, v in enumerate(gmap_vpids) if v is not None]
-        if real:
-            pos = np.stack([np.asarray(self.node_positions[gmap_vpids[i]], dtype=np.float64) for i in real])
-            h, e, dd = calculate_vp_rel_pos_fts(self.node_positions[cur_vp], pos, cur_heading, cur_elevation)
-            ang[real, 0], ang[real, 1] = h, e
-            for r, i in enumerate(real):
-                vp = gmap_vpids[i]
-                dist[i] = [dd[r] / MAX_DIST, self.graph.distance(cur_vp, vp) / MAX_DIST,
-                           len(self.graph.path(cur_vp, vp)) / MAX_STEP]
-        return np.concatenate([get_angle_fts(ang[:, 0], ang[:, 1], angle_feat_size), dist], 1)
+    def node_ids(self, vpids):
+        """viewpoint ids -> int32 node ids (-1 for the reference's `None` slot)"""
+        idx = self._graph.idx
+        return np.fromiter((-1 if v is None else idx[v] for v in vpids), dtype=np.int32, count=len(vpids))
+
+    def get_pos_fts(self, cur_vp, gmap_vpids, cur_heading, cur_elevation, angle_feat_size=4, out=None):
+        """[len(gmap_vpids), angle_feat_size + 3] fp32, one C call; `out` may be a (pinned) buffer to fill in place"""
+        ids = self.node_ids(gmap_vpids)
+        if out is None:
+            out = np.empty((len(gmap_vpids), angle_feat_size + 3), dtype=np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.shape == (len(gmap_vpids), angle_feat_size + 3)
+        _lib.check(_L().nv_graph_pos_fts(self._graph._g, self._graph.idx[cur_vp], _ptr(ids), len(gmap_vpids), float(cur_heading),
+                                         float(cur_elevation), int(angle_feat_size), _ptr(out)), "nv_graph_pos_fts")
+        return out
+
+
+# ------------------------------------------------------------------ per-step index tables of forward_navigation
+def match_tables(gmap_ids, gmap_visited, cand_ids):
+    """nav_model.py:174-190 on integer ids ([B,G] int32 with -1 padding, [B,G] bool, [B,Nv] int32 with -1 at slot 0 / padding)
+    -> src [B*G] int32, inv [B*Nv] int32, ttype [B*G] int32"""
+    gmap_ids = np.ascontiguousarray(gmap_ids, dtype=np.int32)
+    vis = np.ascontiguousarray(gmap_visited, dtype=np.uint8)
+    cand_ids = np.ascontiguousarray(cand_ids, dtype=np.int32)
+    B, G = gmap_ids.shape
+    Nv = cand_ids.shape[1]
+    src, inv, tt = np.empty(B * G, np.int32), np.empty(B * Nv, np.int32), np.empty(B * G, np.int32)
+    _lib.check(_L().nv_nav_match_tables(_ptr(gmap_ids), _ptr(vis), _ptr(cand_ids), B, G, Nv, _ptr(src), _ptr(inv), _ptr(tt)),
+               "nv_nav_match_tables")
+    return src, inv, tt
+
+
+def intern_vpids(gmap_vpids, vp_cand_vpids, G, Nv):
+    """string viewpoint ids of one batch -> the integer tables `match_tables` takes (a per-call dictionary: ids only need to be
+    consistent within a sample).  Callers that already hold node ids (navillm_amd/synthetic.py) skip this."""
+    B = len(gmap_vpids)
+    gi = np.full((B, G), -1, dtype=np.int32)
+    ci = np.full((B, Nv), -1, dtype=np.int32)
+    for b in range(B):
+        table = {}
+        for j, v in enumerate(gmap_vpids[b]):
+            if v is not None:
+                gi[b, j] = table.setdefault(v, len(table))
+        for j, v in enumerate(vp_cand_vpids[b]):
+            if j > 0 and v is not None:
+                ci[b, j] = table.setdefault(v, len(table))
+    return gi, ci
+
+
+def perm_tables(cand_mask, perms):
+    """nav_model.py:216-223,234-242: cand_mask [B,G] bool, perms = list of B int64 permutations (torch.randperm results)
+    -> sel [n] int32 (fuse rows in LM order), inv_sel [B*G] int32, col [B,G] int64 (head column of every slot)"""
+    cm = np.ascontiguousarray(cand_mask, dtype=np.uint8)
+    B, G = cm.shape
+    off = np.zeros(B + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(p) for p in perms])
+    flat = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.int64) for p in perms]) if off[-1] else np.zeros(0, np.int64))
+    sel, inv_sel, col = np.empty(max(int(off[-1]), 1), np.int32), np.empty(B * G, np.int32), np.empty((B, G), np.int64)
+    n = _L().nv_nav_perm_tables(_ptr(cm), _ptr(flat), _ptr(off), B, G, _ptr(sel), _ptr(inv_sel), _ptr(col))
+    if n < 0:
+        raise _lib.NaviLLMHipError("nv_nav_perm_tables failed: invalid permutation / candidate mask")
+    return sel[:n], inv_sel, col

@@ -31,11 +31,13 @@ SIGNATURES = {
     "nv_swiglu_fwd_bf16": (i, [vp, vp, i, i, vp]),
     "nv_swiglu_bwd_bf16": (i, [vp, vp, vp, i, i, vp]),
     "nv_scale_bf16": (i, [vp, vp, l, f, vp]),
+    "nv_scale_dev_bf16": (i, [vp, vp, l, fp, i, vp]),
     "nv_gather_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
     "nv_scatter_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
     "nv_attn_fwd_bf16": (i, [vp, vp, fp, ip, i, i, i, i, i, vp]),
     "nv_attn_fwd_strided_bf16": (i, [vp, vp, fp, ip, i, i, i, i, i, i, vp]),
     "nv_attn_fwd_varlen_bf16": (i, [vp, vp, fp, ip, ip, i, i, i, i, i, vp]),
+    "nv_attn_fwd_hfround_bf16": (i, [vp, vp, fp, ip, ip, i, i, i, i, i, vp]),
     "nv_attn_bwd_varlen_bf16": (i, [vp, vp, vp, fp, ip, ip, vp, vp, vp, vp, i, i, l, i, i, i, vp]),
     "nv_attn_bwd_workspace_bytes": (sz, [i, i, i]),
     "nv_attn_bwd_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, i, vp]),
@@ -64,6 +66,20 @@ SIGNATURES = {
     "nv_gather_add_f32": (i, [fp, ip, fp, fp, l, i, vp]),
     "nv_index_sum_f32": (i, [fp, ip, fp, i, i, i, i, vp]),
     "nv_masked_mean_f32": (i, [fp, fp, fp, i, i, i, vp]),
+    # host side-car (nv_graph* travels as void*; all other pointers are HOST pointers)
+    "nv_graph_create": (vp, []),
+    "nv_graph_destroy": (None, [vp]),
+    "nv_graph_add_node": (i, [vp]),
+    "nv_graph_num_nodes": (i, [vp]),
+    "nv_graph_set_position": (i, [vp, i, vp]),
+    "nv_graph_add_edge": (i, [vp, i, i, C.c_double]),
+    "nv_graph_update": (i, [vp, i]),
+    "nv_graph_visited": (i, [vp, i]),
+    "nv_graph_distance": (C.c_double, [vp, i, i]),
+    "nv_graph_path": (i, [vp, i, i, vp, i]),
+    "nv_graph_pos_fts": (i, [vp, i, vp, i, C.c_double, C.c_double, i, vp]),
+    "nv_nav_match_tables": (i, [vp, vp, vp, i, i, i, vp, vp, vp]),
+    "nv_nav_perm_tables": (i, [vp, vp, vp, i, i, vp, vp, vp]),
     # data-parallel exchange over RCCL (nv_ctx* travels as void*)
     "nv_comm_unique_id_bytes": (i, []),
     "nv_comm_unique_id": (i, [vp]),

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import functions as Fn
+from . import graph
 from . import ops
 from .config import NavConfig
 from .flat import FlatStore
@@ -152,6 +153,7 @@ class NavModel(nn.Module):
         self.prune_last_layer = True     # navigation/grounding: last decoder layer computed for the <cls_1> rows only
         self.pack_rows = os.environ.get("NAVILLM_PACK_ROWS", "1") != "0"   # LM over the real tokens only (no left-padding rows)
         self._row_map = None
+        self.attn_hf_rounding = False    # tests only: attention forward through the parity instrument nv_attn_fwd_hfround_bf16
         self.kv = None                   # KVCacheLM (enable_kv_cache): prefix reuse across no-grad navigation steps + generation
         self._wgrad_stream = None
         self._dp = None
@@ -561,41 +563,24 @@ class NavModel(nn.Module):
         pm = ops.h2d(batch["pano_masks"], dev).to(F32).view(-1).contiguous()
         vp = Fn.RowScaleF32.apply(vp.view(B * Nv, d), pm)
 
-        # host: which current-view candidate feeds which map slot (:174-190)
-        src = torch.full((B * G,), -1, dtype=torch.int32)
-        inv = torch.full((B * Nv,), -1, dtype=torch.int32)
-        ttype = torch.zeros((B * G,), dtype=torch.int32)
-        for i in range(B):
-            visited = set(v for v, m in zip(g_vpids[i], gv_cpu[i].tolist()) if m)
-            tmp = {}
-            for j, cv in enumerate(vp_cand_vpids[i]):
-                if j > 0 and cv not in visited:
-                    tmp[cv] = j
-            for j, v in enumerate(g_vpids[i]):
-                if j > 0 and v not in visited:
-                    if v in tmp:
-                        src[i * G + j] = i * Nv + tmp[v]
-                        inv[i * Nv + tmp[v]] = i * G + j
-                    else:
-                        ttype[i * G + j] = 1
+        # host: which current-view candidate feeds which map slot (:174-190) -- one call into the C++ side-car on integer
+        # node ids (a caller that already holds them passes `_gmap_ids` / `_cand_ids`; else the strings are interned here)
+        if batch["_gmap_ids"] is not None:
+            gi, ci = batch["_gmap_ids"], batch["_cand_ids"]
+        else:
+            gi, ci = graph.intern_vpids(g_vpids, vp_cand_vpids, G, Nv)
+        src, inv, ttype = (torch.from_numpy(a) for a in graph.match_tables(gi, gv_cpu.numpy(), ci))
         fuse = Fn.GatherRowsF32.apply(vp, ops.h2d(src, dev), ops.h2d(inv, dev), gmap)
         fuse = Fn.EmbedAddF32.apply(self.P("token_type_embeddings.weight"), ops.h2d(ttype, dev), fuse)
         fuse = Fn.RowScaleF32.apply(fuse, keep_g_dev)                       # [B*G, d]
 
         cand_masks = keep_g
         cand_nums = cand_masks.sum(-1)
-        # candidate permutation with the reference's CPU RNG call order (:216-223)
-        sel, inv_sel, inv_perms = [], torch.full((B * G,), -1, dtype=torch.int32), []
-        for b in range(B):
-            slots = torch.nonzero(cand_masks[b]).view(-1)[1:]
-            rp = torch.randperm(slots.numel())
-            ip = torch.arange(slots.numel())
-            ip[rp] = torch.arange(slots.numel())
-            inv_perms.append(ip)
-            for s in slots[rp].tolist():
-                inv_sel[b * G + s] = len(sel)
-                sel.append(b * G + s)
-        cand_embeds = Fn.GatherRowsF32.apply(fuse, ops.h2d(torch.tensor(sel, dtype=torch.int32), dev), ops.h2d(inv_sel, dev), None)
+        # candidate permutation with the reference's CPU RNG call order (:216-223); the index tables around it
+        # (selection in LM order, its inverse, the head column of every map slot) come from the side-car in one call
+        perms = [torch.randperm(int(n) - 1) for n in cand_nums]
+        sel, inv_sel, col = (torch.from_numpy(a) for a in graph.perm_tables(cand_masks.numpy(), [p.numpy() for p in perms]))
+        cand_embeds = Fn.GatherRowsF32.apply(fuse, ops.h2d(sel, dev), ops.h2d(inv_sel, dev), None)
 
         hist_vis = self._stack_hist(batch["hist_vis"])
         ids, am, _ = self._tokens(batch, batch["prompts"])
@@ -607,12 +592,6 @@ class NavModel(nn.Module):
         pred = Fn.HeadBF16.apply(Hs_cls, self, "out_head.0")   # [B,100]
 
         # fuse_logits[b][cand slots] = [pred[b,0], pred[b,1:n][inv_perm]] ; -inf elsewhere (:234-242)
-        col = torch.zeros((B, G), dtype=torch.int64)
-        for b in range(B):
-            slots = torch.nonzero(cand_masks[b]).view(-1)
-            n = int(cand_nums[b])
-            col[b, slots[0]] = 0
-            col[b, slots[1:]] = 1 + inv_perms[b][: n - 1]
         logits = torch.gather(pred, 1, ops.h2d(col, dev)).masked_fill(ops.h2d(cand_masks.logical_not(), dev), float("-inf"))
         return {"fuse_embeds": fuse.detach().view(B, G, d), "fuse_logits": logits}
 

@@ -214,6 +214,16 @@ def scale_bf16_(x, scale):
     return x
 
 
+def scale_dev_bf16(x, scale_dev_f32, out=None, accumulate=False):
+    """out = bf16(x * s) or, accumulate: out = bf16(out + bf16(x * s)); s is a 1-element fp32 DEVICE tensor"""
+    if out is None:
+        assert not accumulate
+        out = torch.empty_like(x)
+    _lib.check(_L().nv_scale_dev_bf16(x.data_ptr(), out.data_ptr(), x.numel(), scale_dev_f32.data_ptr(), 1 if accumulate else 0, _st()),
+               "nv_scale_dev_bf16")
+    return out
+
+
 def gather_rows_bf16(src, rows_i32):
     n, d = rows_i32.numel(), src.shape[1]
     out = torch.empty((n, d), dtype=BF16, device=src.device)
@@ -236,6 +246,14 @@ def attn_fwd(qkv, kv_start_i32, B, S, H, hd, out=None, lse2=None, q_row_min=0):
     rc = _L().nv_attn_fwd_bf16(qkv.data_ptr(), out.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(), B, S, H, hd, q_row_min,
                                _st())
     _lib.check(rc, "nv_attn_fwd_bf16")
+    return out, lse2
+
+
+def attn_fwd_hfround(qkv, kv_start_i32, cu_i32, B, S, H, hd, out, lse2, q_row_min=0):
+    """PARITY INSTRUMENT (tests): attention forward with HF eager attention's bf16 rounding points (include/navillm_hip.h)"""
+    rc = _L().nv_attn_fwd_hfround_bf16(qkv.data_ptr(), out.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(), _p(cu_i32), B, S, H, hd,
+                                       q_row_min, _st())
+    _lib.check(rc, "nv_attn_fwd_hfround_bf16")
     return out, lse2
 
 
@@ -309,9 +327,10 @@ def action_ce(logits, targets_i64, gscale=1.0, want_grad=True, gscale_dev=None):
     return loss_rows, dl
 
 
-def lm_ce_(logits, labels_i32, V, special0, nspecial, gscale, write_grad=True):
+def lm_ce_(logits, labels_i32, V, special0, nspecial, gscale, write_grad=True, loss_rows=None):
     M = logits.shape[0]
-    loss_rows = torch.empty((M,), dtype=F32, device=logits.device)
+    if loss_rows is None:
+        loss_rows = torch.empty((M,), dtype=F32, device=logits.device)
     _lib.check(_L().nv_lm_ce_bf16(logits.data_ptr(), labels_i32.data_ptr(), loss_rows.data_ptr(), M, V, logits.stride(0), special0,
                                   nspecial, gscale, 1 if write_grad else 0, _st()), "nv_lm_ce_bf16")
     return loss_rows

@@ -68,8 +68,12 @@ def view_angle_features(angle_feat_size=4):
 class SyntheticEpisodes:
     """B lock-step episodes on one rank."""
 
-    def __init__(self, cfg, batch_size, seed, instr_len=512, n_views=36, device=None):
+    def __init__(self, cfg, batch_size, seed, instr_len=512, n_views=36, device=None, max_frontier=None):
+        """max_frontier: cap on the number of known-but-unvisited nodes per map (long-horizon episodes: in a real
+        Matterport graph most candidates of a late step are nodes seen before, so the frontier saturates; the action head is
+        100-way (nav_model.py:82-85), i.e. stop + at most 99 unvisited candidates)."""
         self.cfg, self.B, self.N = cfg, batch_size, n_views
+        self.max_frontier = max_frontier
         self.rng = np.random.RandomState(seed)
         self.tgen = torch.Generator().manual_seed(seed)
         self.device = device
@@ -99,8 +103,15 @@ class SyntheticEpisodes:
         K = int(self.rng.randint(2, 9))
         cands = []
         known = [v for v in self.pos[b] if v != self.cur[b]]
+        saturated = False
+        if self.max_frontier is not None:
+            gr = self.gmaps[b].graph
+            frontier = [v for v in known if not gr.visited(v)]
+            saturated = len(frontier) >= self.max_frontier
+            if saturated:
+                known = frontier + [v for v in known if gr.visited(v)][:2]     # mostly unvisited nodes: the walk can go on
         for j in range(K):
-            if known and self.rng.rand() < 0.25:
+            if known and (saturated or self.rng.rand() < 0.25):
                 vp = known[self.rng.randint(len(known))]
                 if any(c["viewpointId"] == vp for c in cands):
                     continue
@@ -139,7 +150,7 @@ class SyntheticEpisodes:
 
     def nav_inputs(self, pano_embeds, pano_masks, cand_vpids):
         B, d, dev = self.B, self.cfg.hidden_size, self.device
-        vpids, vis, steps, embeds, posf = [], [], [], [], []
+        vpids, vis, steps, embeds = [], [], [], []
         for b, gmap in enumerate(self.gmaps):
             visited = [k for k in gmap.node_positions if gmap.graph.visited(k)]
             unvisited = [k for k in gmap.node_positions if not gmap.graph.visited(k)]
@@ -149,25 +160,29 @@ class SyntheticEpisodes:
             steps.append([gmap.node_step_ids.get(v, 0) for v in gv])
             e = [gmap.get_node_embed(v) for v in gv[1:]]
             embeds.append(torch.stack([torch.zeros_like(e[0])] + e, 0))
-            posf.append(gmap.get_pos_fts(self.cur[b], gv, self.heading[b], 0.0))
         G = max(len(v) for v in vpids)
         gmask = torch.zeros(B, G, dtype=torch.bool)
         gvis = torch.zeros(B, G, dtype=torch.bool)
         gstep = torch.zeros(B, G, dtype=torch.int64)
         gpos = torch.zeros(B, G, 7)
+        gpos_np = gpos.numpy()
+        gids = np.full((B, G), -1, dtype=np.int32)                            # integer node ids for the side-car's match tables
         gimg = torch.zeros(B, G, d, device=dev)
-        for b in range(B):
+        for b, gmap in enumerate(self.gmaps):
             n = len(vpids[b])
             gmask[b, :n] = True
             gvis[b, :n] = torch.tensor(vis[b]).bool()
             gstep[b, :n] = torch.tensor(steps[b])
-            gpos[b, :n] = torch.from_numpy(posf[b])
+            gmap.get_pos_fts(self.cur[b], vpids[b], self.heading[b], 0.0, out=gpos_np[b, :n])   # all slots, one C call, in place
+            gids[b, :n] = gmap.node_ids(vpids[b])
             gimg[b, :n] = embeds[b]
         Nv = pano_embeds.shape[1] + 1
         vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
         pm = torch.cat([torch.ones_like(pano_masks[:, :1]), pano_masks], 1)
         vp_pos = np.zeros((B, Nv, 14), dtype=np.float32)
+        cids = np.full((B, Nv), -1, dtype=np.int32)
         for b, gmap in enumerate(self.gmaps):
+            cids[b, 1:len(cand_vpids[b]) + 1] = gmap.node_ids(cand_vpids[b])
             cf = gmap.get_pos_fts(self.cur[b], cand_vpids[b], self.heading[b], 0.0)
             sf = gmap.get_pos_fts(self.cur[b], [gmap.start_vp], self.heading[b], 0.0)
             vp_pos[b, :, :7] = sf
@@ -178,7 +193,7 @@ class SyntheticEpisodes:
                 "vp_nav_masks": torch.ones(B, Nv, dtype=torch.bool, device=dev),
                 "vp_cand_vpids": [[None] + x for x in cand_vpids], "hist_vis": self.hist_vis, "history": self.history,
                 "data_type": ["r2r"] * B, "instruction": ["{INSTR}"] * B,
-                "_gmask_cpu": gmask, "_gvis_cpu": gvis}
+                "_gmask_cpu": gmask, "_gvis_cpu": gvis, "_gmap_ids": gids, "_cand_ids": cids}
 
     def tokenise(self, nav, cls_token):
         cand_nums = (nav["_gmask_cpu"] & ~nav["_gvis_cpu"]).sum(-1)

@@ -17,6 +17,9 @@ Outputs (all small, committed):
     g7_graph.npz       graph_utils            (G7)
     g8_adamw.npz       clip + AdamW on bf16   (G8)
     g9_generate_*.npz  greedy generation through the reference's own generate() calls (3dqa free, summarization trie)
+    g10_grads_*.npz    loss + parameter gradients of object_grounding / summarization / fgr2r / 3dqa TRAINING steps on the
+                       G5 inputs (round 2: the backward of every mode, not only navigation)
+    g1_encoder_real_F{1024,768}.npz   scene encoder at its real size (h=1024, 16 heads, ff=4096, 36 ragged views)
 
 Three shims, all outside the reference tree (the third -- fp32 RoPE
 frequencies, see build_reference -- undoes a transformers 4.28 -> 5.15 drift): the bert-large-uncased
@@ -419,6 +422,22 @@ def gen_precision(prec, seed=11):
          hist_vis_flat=torch.stack([v for vis in hv for v in vis], 0), obj_embeds=po["obj_embeds"],
          obj_logits=oo["obj_logits"], meta=np.array(json.dumps(dict(hist_t=hist_t5, prompts=oprompts))))
 
+    # ---- G10 (round 2): the SAME inputs with autograd on -> loss -> backward, as the rollout does on an episode's last step
+    #      (mp3d_agent.py:788-842: panorama again, object_grounding, CE_sum * obj_loss_coef / B / accum, backward)
+    crit_sum = torch.nn.CrossEntropyLoss(ignore_index=-100, reduction="sum")
+    model.zero_grad()
+    po_g = model("panorama", dict(pin_o))
+    ob_g = dict(ob, obj_embeds=po_g["obj_embeds"], obj_masks=po_g["obj_masks"], obj_loc_fts=po_g["obj_loc_fts"])
+    oo_g = model("object_grounding", ob_g)
+    og_targets = torch.tensor([2, -100, 1])
+    og_loss = crit_sum(oo_g["obj_logits"], og_targets) * 0.5 / B / 1
+    og_loss.backward()
+    g10 = {"og/" + k: v for k, v in grad_fixture(model, [n for n in G10_COMMON if not n.startswith(("out_head.0.bias", "img_embeddings.img_linear",
+                                                              "img_embeddings.mapper", "img_embeddings.pano_encoder", "img_embeddings.layer_norm"))]
+                                                 + ["out_head.0.bias"] + G10_OG).items()}
+    g10["og/loss"] = og_loss
+    g10["og/targets"] = og_targets
+
     # ---- G5s summarization / embodied_qa(fgr2r) training losses (nav_model.py:251-319; on the training path
     #      with --enable_summarize / --enable_fgr2r, mp3d_agent.py:845-909)
     with torch.no_grad():
@@ -444,6 +463,27 @@ def gen_precision(prec, seed=11):
             labels_txt = [(answers[b] if dtype_ in ("eqa", "fgr2r") else instr[b]) + lm.tokenizer.eos_token for b in range(B)]
             tk = lm.tokenize([[prompts_s[b], labels_txt[b]] for b in range(B)])
             out_s[mode] = (o["loss"], tk, prompts_s, labels_txt)
+    # G10: summarization and fgr2r with autograd on (mp3d_agent.py:845-909: panorama -> mode -> loss * gen_loss_coef / B / accum
+    # -> backward); the encoder receives gradient through vp_img_embeds
+    for mode, dtype_, coef in (("summarization", "r2r", 1.0), ("embodied_qa", "fgr2r", 0.8)):
+        model.zero_grad()
+        ps_g = model("panorama", dict(pin_s))
+        vp_g = torch.cat([torch.zeros_like(ps_g["pano_embeds"][:, :1]), ps_g["pano_embeds"]], 1)
+        instr = INSTR if mode == "summarization" else ["where are we going with direction (1) ?"] * B
+        answers = ["", "", ""] if mode == "summarization" else ["turn left at the door", "go up the stairs", "wait near the sofa"]
+        hv_m = hvs if mode == "summarization" else [[] for _ in range(B)]
+        hist_n = hist_ts if mode == "summarization" else [0] * B
+        sb = dict(vp_img_embeds=vp_g, vp_pos_fts=torch.zeros(B, N + 1, 14), vp_nav_masks=nav_masks, vp_cand_vpids=[[None]] * B,
+                  instruction=instr, answer=answers, history=[["<hist>"] * t for t in hist_n], hist_vis=hv_m,
+                  data_type=[dtype_] * B, prompts=out_s[mode][2])
+        o = model(mode, sb, training=True)
+        l_ = o["loss"] * coef / B / 1
+        l_.backward()
+        key = "sum" if mode == "summarization" else "fgr2r"
+        g10.update({f"{key}/" + k: v for k, v in grad_fixture(model, G10_COMMON[2:] + G10_LM).items()})
+        g10[f"{key}/loss"] = l_
+        g10[f"{key}/coef"] = np.array(coef)
+
     hv_flat = torch.stack([v for vis in hvs for v in vis], 0)
     save(f"g5_sum_{tag}.npz", **pin_s, vp_nav_masks=nav_masks, hist_vis_flat=hv_flat,
          sum_input_ids=out_s["summarization"][1]["input_ids"], sum_attention_mask=out_s["summarization"][1]["attention_mask"],
@@ -469,12 +509,86 @@ def gen_precision(prec, seed=11):
     save(f"g5_qa_{tag}.npz", features=pad(feats), feat_lens=torch.tensor([f.shape[0] for f in feats]),
          input_ids=qtok["input_ids"], attention_mask=qtok["attention_mask"], token_type_ids=qtok["token_type_ids"],
          loss=qo.loss, meta=np.array(json.dumps(dict(prompts=qprompts, answers=answers))))
+    # G10: 3dqa with autograd on (llava.py:38-42: loss * coef / accum -> backward)
+    model.zero_grad()
+    qo_g = model("3dqa", qb, training=True)
+    q_l = qo_g.loss * 0.7 / 1
+    q_l.backward()
+    g10.update({"qa/" + k: v for k, v in grad_fixture(model, G10_COMMON[2:] + G10_LM).items()})
+    g10["qa/loss"] = q_l
+    g10["qa/coef"] = np.array(0.7)
+    model.zero_grad()
+    save(f"g10_grads_{tag}.npz", **g10)
     return model, cfg
+
+
+def grad_fixture(model, names, big=20000):
+    """selected parameter gradients after a backward(): small tensors whole, large 2-D ones as the strided sub-block
+    [::3, ::5] plus their Frobenius norm; plus the sorted list of every parameter that has a gradient at all."""
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    out = {}
+    for n in names:
+        g = grads[n]
+        if g.numel() > big and g.dim() == 2:
+            out["gradsub/" + n] = g[::3, ::5]
+            out["gradnorm/" + n] = g.float().norm()
+        else:
+            out["grad/" + n] = g
+    out["rownorm/lang_model.model.embed_tokens.weight"] = grads["lang_model.model.embed_tokens.weight"].float().norm(dim=1)
+    if "lang_model.lm_head.weight" in grads:
+        out["rownorm/lang_model.lm_head.weight"] = grads["lang_model.lm_head.weight"].float().norm(dim=1)
+    out["grad_names_with_grad"] = np.array(sorted(grads.keys()))
+    return out
+
+
+G10_COMMON = ["out_head.0.weight", "out_head.0.bias", "img_embeddings.img_linear.weight", "img_embeddings.mapper.weight",
+              "img_embeddings.pano_encoder.layers.0.self_attn.in_proj_weight", "img_embeddings.layer_norm.weight",
+              "lang_model.model.layers.0.self_attn.q_proj.weight", "lang_model.model.layers.1.mlp.down_proj.weight",
+              "lang_model.model.layers.1.mlp.gate_proj.weight", "lang_model.model.layers.0.input_layernorm.weight",
+              "lang_model.model.norm.weight"]
+G10_LM = ["vp_pos_embeddings.0.bias", "vp_pos_embeddings.1.weight", "token_type_embeddings.weight"]
+G10_OG = ["obj_pos_embeddings.0.weight", "obj_pos_embeddings.1.bias", "img_embeddings.obj_projector.0.weight",
+          "img_embeddings.obj_projector.1.weight"]
 
 
 def pad(ts):
     m = max(t.shape[0] for t in ts)
     return torch.stack([torch.cat([t, torch.zeros(m - t.shape[0], *t.shape[1:])], 0) for t in ts], 0)
+
+
+def gen_encoder_real_size(seed=11):
+    """G1 at the REAL scene-encoder size: h=1024, 16 heads x 64, ff=4096, 2 layers, 36 views, ragged view
+    counts, F=1024 (EVA-CLIP-L, with objects) and F=768 (the BASELINE synthetic width).  Only the mapper's output width is
+    tiny (d=256, the fixture LM) -- it is a plain Linear(1024 -> d) -- so the fixture stays < 1 MB."""
+    for F_ in (1024, 768):
+        cfg = nvcfg.tiny(precision="fp32", enc_hidden_size=1024, enc_num_heads=16, enc_intermediate_size=4096, image_feat_size=F_,
+                         obj_feat_size=768)
+        model = build_reference(cfg, seed)
+        g = torch.Generator().manual_seed(4242 + F_)
+        B, N = 3, 36
+        x = torch.randn(B, N, F_, generator=g)
+        lens = torch.tensor([36, 29, 33])
+        loc = torch.randn(B, N, 7, generator=g)
+        nav = torch.zeros(B, N, dtype=torch.long)
+        for b, k in enumerate((5, 2, 8)):
+            nav[b, :k] = 1
+            x[b, lens[b]:] = 0
+            loc[b, lens[b]:] = 0
+        pin = dict(view_img_fts=x, view_lens=lens, loc_fts=loc, nav_types=nav)
+        if F_ == 1024:
+            O = 6
+            ol = torch.tensor([6, 2, 4])
+            of = torch.randn(B, O, 768, generator=g)
+            olf = torch.randn(B, O, 7, generator=g)
+            for b in range(B):
+                of[b, ol[b]:] = 0
+                olf[b, ol[b]:] = 0
+            pin.update(obj_img_fts=of, obj_lens=ol, obj_loc_fts=olf)
+        with torch.no_grad():
+            out = model("panorama", dict(pin))
+        extra = dict(obj_embeds=out["obj_embeds"], obj_masks=out["obj_masks"]) if F_ == 1024 else {}
+        save(f"g1_encoder_real_F{F_}.npz", **pin, pano_embeds=out["pano_embeds"], pano_masks=out["pano_masks"], **extra)
+        del model
 
 
 def gen_prompts():
@@ -564,6 +678,9 @@ def main():
     cfg = nvcfg.tiny()
     make_tiny_llama_dir(cfg)
     meta = {}
+    if "--only-encoder-real" in sys.argv:        # add the real-size G1 without touching the other fixtures
+        gen_encoder_real_size()
+        return
     if "--only-generation" in sys.argv:          # add G9 without touching the other fixtures
         for prec in ("fp32", "amp_bf16"):
             c = nvcfg.tiny(precision=prec)
@@ -576,6 +693,7 @@ def main():
     # also record the key inventory for the configs with fuse_obj / no objects
     with open(os.path.join(HERE, "g_meta.json"), "w") as f:
         json.dump(meta, f, indent=0, sort_keys=True)
+    gen_encoder_real_size()
     gen_prompts()
     gen_graph()
     gen_adamw()

@@ -231,3 +231,141 @@ def test_hf_checkpoint_reader_and_reference_scratch_init(tmp_path):
     e = ck.reference_scratch_tensor("gmap_step_embeddings.weight", (100, 64), 0)
     assert abs(float(e.std()) - 1.0) < 0.05
     assert ck.reference_scratch_tensor("img_embeddings.img_linear.bias", (128,), 0) is None       # needs fan_in: init_reference_scratch
+
+
+def test_g7_through_the_c_abi_and_random_graphs_vs_reference_semantics():
+    """The side-car is C++ behind `nv_graph_*` now: the existing G7 test above goes through it (FloydGraph / GraphMap are
+    ctypes shells).  Here additionally (a) the raw C entry points on the G7 data, (b) random graphs against a literal
+    dict-of-dict restatement of models/graph_utils.py:47-96 (update order, tie handling, path recursion)."""
+    import ctypes
+    from collections import defaultdict
+    from navillm_amd import lib
+    L = lib.load()
+    z = gold("g7_graph.npz")
+    g = ctypes.c_void_p(L.nv_graph_create())
+    for i in range(7):
+        assert L.nv_graph_add_node(g) == i
+        p = (ctypes.c_double * 3)(*z["positions"][i])
+        assert L.nv_graph_set_position(g, i, p) == 0
+    for a, b in z["edges"]:
+        assert L.nv_graph_add_edge(g, int(a), int(b), float(np.linalg.norm(z["positions"][a] - z["positions"][b]))) == 0
+    for s, k in enumerate((1, 2, 4, 5)):
+        assert L.nv_graph_update(g, k) == 0 and L.nv_graph_visited(g, k) == 1
+        got = np.array([[L.nv_graph_distance(g, i, j) for j in range(7)] for i in range(7)])
+        want = z["dists_after"][s].copy()
+        want[want < 0] = 95959595.0                      # the fixture stores "no path" as -1
+        assert np.allclose(got, want, rtol=0, atol=1e-9), s
+    ids = np.array([-1, 0, 2, 3, 5], dtype=np.int32)
+    out = np.empty((5, 7), dtype=np.float32)
+    assert L.nv_graph_pos_fts(g, 1, ids.ctypes.data_as(ctypes.c_void_p), 5, 0.3, -0.1, 4, out.ctypes.data_as(ctypes.c_void_p)) == 0
+    # fp32 stage: the C path rounds sin/cos of the fp32 angle once from double; numpy's float32 sin/cos may differ in the last bit
+    assert np.abs(out - z["pos_fts"]).max() <= 1.2e-7, np.abs(out - z["pos_fts"]).max()
+    assert L.nv_graph_pos_fts(g, 1, ids.ctypes.data_as(ctypes.c_void_p), 5, 0.3, -0.1, 5, out.ctypes.data_as(ctypes.c_void_p)) == -1
+    assert L.nv_graph_add_edge(g, 0, 99, 1.0) == -1 and L.nv_graph_update(g, -3) == -1
+    L.nv_graph_destroy(g)
+
+    # (b) random graphs vs the reference algorithm, restated literally
+    from navillm_amd.graph import FloydGraph
+    rng = np.random.RandomState(0)
+    for trial in range(20):
+        n = int(rng.randint(3, 25))
+        dis = defaultdict(lambda: defaultdict(lambda: 95959595))
+        point = defaultdict(lambda: defaultdict(lambda: ""))
+        fg = FloydGraph()
+        names = [f"v{i}" for i in range(n)]
+        for _ in range(int(rng.randint(n, 3 * n))):
+            a, b = rng.randint(n, size=2)
+            if a == b:
+                continue
+            d = float(rng.choice([1.0, 2.0, 1.5, rng.rand() * 3 + 0.1]))      # repeated lengths: exercise ties
+            if d < dis[names[a]][names[b]]:
+                dis[names[a]][names[b]] = dis[names[b]][names[a]] = d
+                point[names[a]][names[b]] = point[names[b]][names[a]] = ""
+            fg.add_edge(names[a], names[b], d)
+        for k in rng.permutation(n)[: max(1, n // 2)]:
+            k = names[k]
+            if k not in dis:
+                continue
+            for x in list(dis):
+                for y in list(dis):
+                    if x != y and dis[x][k] + dis[k][y] < dis[x][y]:
+                        dis[x][y] = dis[y][x] = dis[x][k] + dis[k][y]
+                        point[x][y] = point[y][x] = k
+            fg.update(k)
+
+        def ref_path(x, y):
+            if x == y:
+                return []
+            if point[x][y] == "":
+                return [y]
+            return ref_path(x, point[x][y]) + ref_path(point[x][y], y)
+
+        nodes = list(dis)
+        for x in nodes:
+            for y in nodes:
+                want = 0 if x == y else dis[x][y]
+                assert abs(fg.distance(x, y) - want) <= 1e-12 * max(1.0, want), (trial, x, y)
+                if x != y and dis[x][y] < 95959595:
+                    assert fg.path(x, y) == ref_path(x, y), (trial, x, y)
+
+
+def test_navigation_index_tables_vs_reference_loops():
+    """`nv_nav_match_tables` / `nv_nav_perm_tables` against the python loops of models/nav_model.py:174-190,216-223,234-242
+    restated on strings (what forward_navigation did in round 1), on random maps incl. repeated candidates, visited
+    candidates, padding and a sample whose only candidate is stop."""
+    from navillm_amd import graph
+    rng = np.random.RandomState(1)
+    for trial in range(30):
+        B = int(rng.randint(1, 6))
+        sizes = [int(rng.randint(1, 12)) for _ in range(B)]              # map slots incl. stop
+        G = max(sizes)
+        Nv = int(rng.randint(2, 9))
+        g_vpids, vis, cands = [], np.zeros((B, G), bool), []
+        for b in range(B):
+            names = [None] + [f"n{b}_{i}" for i in range(sizes[b] - 1)]
+            g_vpids.append(names)
+            vis[b, 1:sizes[b]] = rng.rand(sizes[b] - 1) < 0.4
+            pool = names[1:] + [f"x{b}_{i}" for i in range(3)]          # candidates: map nodes and nodes not (yet) in the map
+            k = int(rng.randint(0, Nv))
+            cands.append([None] + [pool[rng.randint(len(pool))] for _ in range(k)] if pool else [None])
+        # ---- the reference's loops
+        src_w = np.full(B * G, -1, np.int32)
+        inv_w = np.full(B * Nv, -1, np.int32)
+        tt_w = np.zeros(B * G, np.int32)
+        for i in range(B):
+            visited = set(v for v, m in zip(g_vpids[i], vis[i].tolist()) if m)
+            tmp = {}
+            for j, cv in enumerate(cands[i]):
+                if j > 0 and cv not in visited:
+                    tmp[cv] = j
+            for j, v in enumerate(g_vpids[i]):
+                if j > 0 and v not in visited:
+                    if v in tmp:
+                        src_w[i * G + j] = i * Nv + tmp[v]
+                        inv_w[i * Nv + tmp[v]] = i * G + j
+                    else:
+                        tt_w[i * G + j] = 1
+        gi, ci = graph.intern_vpids(g_vpids, cands, G, Nv)
+        src, inv, tt = graph.match_tables(gi, vis, ci)
+        assert np.array_equal(src, src_w) and np.array_equal(inv, inv_w) and np.array_equal(tt, tt_w), trial
+        # ---- candidate permutation tables
+        gmask = np.zeros((B, G), bool)
+        for b in range(B):
+            gmask[b, :sizes[b]] = True
+        cm = gmask & ~vis
+        perms = [torch.randperm(int(cm[b].sum()) - 1) for b in range(B)]
+        sel_w, inv_sel_w, col_w = [], np.full(B * G, -1, np.int32), np.zeros((B, G), np.int64)
+        for b in range(B):
+            slots = np.flatnonzero(cm[b])
+            rp = perms[b].numpy()
+            ip = np.empty_like(rp)
+            ip[rp] = np.arange(rp.size)
+            for s_ in slots[1:][rp].tolist():
+                inv_sel_w[b * G + s_] = len(sel_w)
+                sel_w.append(b * G + s_)
+            col_w[b, slots[0]] = 0
+            col_w[b, slots[1:]] = 1 + ip
+        sel, inv_sel, col = graph.perm_tables(cm, [p.numpy() for p in perms])
+        assert sel.tolist() == sel_w and np.array_equal(inv_sel, inv_sel_w) and np.array_equal(col, col_w), trial
+    with pytest.raises(Exception):
+        graph.perm_tables(np.array([[True, True, True]]), [np.array([0, 5])])        # not a permutation

@@ -203,3 +203,69 @@ def test_g8_clip_adamw():
             O.adamw_step_(ps[i], gs[i], ms[i], vs[i], s + 1, lr=1e-3)
             ref = T(z[f"p{s + 1}_{i}"])
             assert torch.equal(ps[i].float(), ref.float()), (s, i, (ps[i].float() - ref.float()).abs().max())
+
+
+def test_g1_scene_encoder_real_size():
+    """the encoder at its real size (h=1024, 16 heads x 64, ff=4096, 36 ragged views; F=1024 with objects, F=768)."""
+    for F_ in (1024, 768):
+        z = gold(f"g1_encoder_real_F{F_}.npz")
+        cfg, P = tiny_weights("fp32", enc_hidden_size=1024, enc_num_heads=16, enc_intermediate_size=4096, image_feat_size=F_,
+                              obj_feat_size=768)
+        with torch.no_grad():
+            if F_ == 1024:
+                out = O.scene_encoder(P, cfg, T(z["view_img_fts"]), T(z["view_lens"]), T(z["loc_fts"]), T(z["nav_types"]),
+                                      T(z["obj_img_fts"]), T(z["obj_lens"]), T(z["obj_loc_fts"]))
+                close(out["obj_embeds"], z["obj_embeds"], 2e-5, what="obj_embeds")
+            else:
+                out = O.scene_encoder(P, cfg, T(z["view_img_fts"]), T(z["view_lens"]), T(z["loc_fts"]), T(z["nav_types"]))
+        close(out["pano_embeds"], z["pano_embeds"], 5e-5, what=f"pano_embeds F={F_}")
+        assert np.array_equal(out["pano_masks"].numpy(), z["pano_masks"])
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_g10_training_step_gradients_of_every_mode(tag):
+    """object_grounding / summarization / fgr2r / 3dqa: loss AND parameter gradients of one training step each, against
+    the reference's own backward (fixture G10; mp3d_agent.py:788-909, llava.py:38-42)."""
+    from util import grad_fixture_errors
+    z10 = gold(f"g10_grads_{tag}.npz")
+    cfg, P0 = tiny_weights(tag)
+    B = 3
+    ltol, gtol = (1e-5, 2e-4) if tag == "fp32" else (3e-2, 8e-2)
+
+    def fresh():
+        return {k: v.clone().requires_grad_(True) for k, v in P0.items()}
+
+    def check(prefix, P, loss):
+        close(loss, z10[prefix + "/loss"], ltol, what=prefix + " loss")
+        loss.backward()
+        errs = grad_fixture_errors(z10, prefix, lambda n: P[n].grad)
+        assert errs and max(errs.values()) < gtol, (prefix, {k: round(v, 5) for k, v in errs.items() if v >= gtol})
+        with_grad = {k for k, v in P.items() if v.grad is not None and bool((v.grad != 0).any())}
+        assert with_grad <= {str(s) for s in z10[prefix + "/grad_names_with_grad"]}
+
+    # object grounding
+    z = gold(f"g5_og_{tag}.npz")
+    m = meta_of(z)
+    P = fresh()
+    po = O.scene_encoder(P, cfg, T(z["view_img_fts"]), T(z["view_lens"]), T(z["loc_fts"]), T(z["nav_types"]),
+                         T(z["obj_img_fts"]), T(z["obj_lens"]), T(z["obj_loc_fts"]))
+    b = dict(obj_embeds=po["obj_embeds"], obj_masks=po["obj_masks"], obj_loc_fts=po["obj_loc_fts"],
+             hist_vis=hist_lists(T(z["hist_vis_flat"]), m["hist_t"]))
+    oo = O.object_grounding(P, cfg, b, T(z["input_ids"]), T(z["attention_mask"]))
+    check("og", P, O.action_loss(oo["obj_logits"], T(z10["og/targets"])) * 0.5 / B)
+    # summarization + fgr2r
+    z = gold(f"g5_sum_{tag}.npz")
+    m = meta_of(z)
+    for prefix, key, hv in (("sum", "sum", hist_lists(T(z["hist_vis_flat"]), m["hist_t"])), ("fgr2r", "qa", [[] for _ in range(B)])):
+        P = fresh()
+        ps = O.scene_encoder(P, cfg, T(z["view_img_fts"]), T(z["view_lens"]), T(z["loc_fts"]), T(z["nav_types"]))
+        vp = torch.cat([torch.zeros_like(ps["pano_embeds"][:, :1]), ps["pano_embeds"]], 1)
+        l_ = O.summarization_loss(P, cfg, vp, T(z["vp_nav_masks"]), hv, T(z[key + "_input_ids"]), T(z[key + "_attention_mask"]),
+                                  T(z[key + "_token_type_ids"]))
+        check(prefix, P, l_ * float(z10[prefix + "/coef"]) / B)
+    # 3dqa
+    q = gold(f"g5_qa_{tag}.npz")
+    feats = [T(q["features"])[i, :int(n)] for i, n in enumerate(q["feat_lens"])]
+    P = fresh()
+    l_ = O.qa_3d_loss(P, cfg, feats, T(q["input_ids"]), T(q["attention_mask"]), T(q["token_type_ids"]))
+    check("qa", P, l_ * float(z10["qa/coef"]))

@@ -14,10 +14,15 @@ import numpy as np
 import pytest
 import torch
 
-from util import gold, T, tiny_cfg, meta_of, hist_lists, nav_batch_from_gold, load_oracle, GOLDEN_SEED
+from util import gold, T, tiny_cfg, meta_of, hist_lists, nav_batch_from_gold, load_oracle, GOLDEN_SEED, bf16_ulps_at_scale
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+# End-to-end bf16 logits vs the reference's (or the bf16 oracle's) bf16 logits, in units of the bf16 spacing at the logits'
+# own magnitude.  Measured on MI355X (round 2): 0.8-1.5 at every size from the tiny fixtures to the 7B-shaped layer, i.e. the
+# two runs differ in the LAST BIT of the bf16 output -- not by a rounding-point deviation inside the model: switching the
+# attention kernel to HF's rounding points does not move it (tests/test_round2_gpu.py).  Asserted: measured x 1.5, rounded up.
+ULPS_LOGITS = 2.5
 
 
 def build(cfg, seed=GOLDEN_SEED):
@@ -120,8 +125,11 @@ def test_g3_g4_navigation_loss_grads_vs_reference():
     assert maxerr(out["fuse_embeds"], zb["fuse_embeds"]) < 2e-5
     lg, l16, l32 = out["fuse_logits"], T(zb["fuse_logits"]), T(zf["fuse_logits"])
     gap, e_hip, e_ref = maxerr(lg, l16), maxerr(lg, l32), maxerr(l16, l32)
-    print(f"[g3] logits max|hip-ref_bf16|={gap:.5f} |hip-ref_fp32|={e_hip:.5f} |ref_bf16-ref_fp32|={e_ref:.5f}")
-    assert gap <= 1e-2 and e_hip <= 1.5 * e_ref + 2e-3
+    ulps = bf16_ulps_at_scale(lg, l16)
+    print(f"[g3] logits max|hip-ref_bf16|={gap:.5f} = {ulps:.2f} bf16 ulps of the logit scale; |hip-ref_fp32|={e_hip:.5f} "
+          f"|ref_bf16-ref_fp32|={e_ref:.5f}")
+    # the logits are bf16 numbers: the distance to the reference's bf16 run is counted in their own last bits (measured 0.8)
+    assert ulps <= ULPS_LOGITS and e_hip <= 1.5 * e_ref + 2e-3
     # argmax-exact where the reference margin exceeds the gap
     top2 = torch.topk(l16.masked_fill(~torch.isfinite(l16), -1e9), 2, dim=1).values
     for b in range(l16.shape[0]):
@@ -140,9 +148,9 @@ def test_g3_g4_navigation_loss_grads_vs_reference():
         g = m.store.g(n)
         r16, r32, base = relerr(g, zb[k]), relerr(g, zf[k]), relerr(T(zb[k]), zf[k])
         worst[n] = (r16, r32)
-        # bf16-vs-bf16 (same rounding points) within 8%; and as close to the fp32 reference as the
-        # reference's own bf16 run is (its relative error `base`), x1.5
-        assert r16 < 8e-2 and r32 < 1.5 * base + 5e-2, (n, r16, r32, base)
+        # bf16-vs-bf16 (same rounding points): measured <= 0.014 relative on MI355X (x1.5); and as close to the fp32
+        # reference as the reference's own bf16 run is (its relative error `base`), x1.5
+        assert r16 < 2.1e-2 and r32 < 1.5 * base + 2e-2, (n, r16, r32, base)
     print("[g4] grad rel errs (vs ref bf16, vs ref fp32):", {k: (round(a, 4), round(b, 4)) for k, (a, b) in worst.items()})
     # embedding-table gradient row norms
     gn = m.store.g("lang_model.model.embed_tokens.weight").float().norm(dim=1).cpu()
@@ -170,8 +178,9 @@ def test_g5_object_grounding_and_qa_vs_reference():
         oc2 = m("object_grounding", b)                  # second call: everything up to the object tokens is reused
         assert max(m.kv.last_stats["prefix"]) > 0
         m.kv = None
-    assert maxerr(oo["obj_logits"], z["obj_logits"]) < 1e-2
-    assert maxerr(oc["obj_logits"], z["obj_logits"]) < 1e-2 and maxerr(oc2["obj_logits"], z["obj_logits"]) < 1e-2
+    u = [bf16_ulps_at_scale(o["obj_logits"], z["obj_logits"]) for o in (oo, oc, oc2)]
+    print(f"[g5 og] obj_logits vs ref bf16, in bf16 ulps of the logit scale: plain {u[0]:.2f}, K/V cache {u[1]:.2f}, cached again {u[2]:.2f}")
+    assert max(u) <= ULPS_LOGITS
     q = gold("g5_qa_bf16.npz")
     feats = [dev(q["features"])[i, :int(n)] for i, n in enumerate(q["feat_lens"])]
     with torch.no_grad():
@@ -282,8 +291,11 @@ def _nav_vs_oracle(cfg, B, S_instr, steps, tag, expect_S=None):
         lg = out["fuse_logits"]
         gap, e_hip, e_ref = maxerr(lg, outs["bf16"]["fuse_logits"]), maxerr(lg, outs["fp32"]["fuse_logits"]), \
             maxerr(outs["bf16"]["fuse_logits"], outs["fp32"]["fuse_logits"])
-        print(f"[{tag} step {step}] S={ids.shape[1]} logits |hip-orc16|={gap:.5f} |hip-orc32|={e_hip:.5f} |orc16-orc32|={e_ref:.5f}")
-        assert e_hip <= 1.5 * e_ref + 3e-3 and gap <= 2.5 * e_ref + 3e-3
+        ulps = bf16_ulps_at_scale(lg, outs["bf16"]["fuse_logits"])
+        print(f"[{tag} step {step}] S={ids.shape[1]} logits |hip-orc16|={gap:.5f} = {ulps:.2f} bf16 ulps of the logit scale, "
+              f"|hip-orc32|={e_hip:.5f} |orc16-orc32|={e_ref:.5f}")
+        # as close to the fp32 truth as the bf16 oracle is (x1.5), and within a couple of last bits of the bf16 oracle's logits
+        assert e_hip <= 1.5 * e_ref + 3e-3 and ulps <= ULPS_LOGITS
         targets = ep.teacher_targets(nav, last=False)
         ep.advance(nav, targets, out["fuse_embeds"])
     del m

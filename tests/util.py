@@ -68,3 +68,36 @@ def nav_batch_from_gold(z, pano_embeds):
         history=[["<hist>"] * t for t in m["hist_t"]], data_type=["r2r"] * len(m["hist_t"]),
         prompts=m["prompts"],
     ), m
+
+
+def grad_fixture_errors(z, prefix, get_grad):
+    """relative errors of the gradients stored by make_golden.grad_fixture under `prefix/`:
+    -> {name: rel err} over `grad/` (whole tensor), `gradsub/` ([::3, ::5] sub-block) and `rownorm/` entries."""
+    errs = {}
+    for k in z:
+        if not k.startswith(prefix + "/"):
+            continue
+        kind, _, name = k[len(prefix) + 1:].partition("/")
+        if kind not in ("grad", "gradsub", "rownorm"):
+            continue
+        ref = torch.from_numpy(np.ascontiguousarray(z[k])).float()
+        g = get_grad(name).detach().float().cpu()
+        if kind == "gradsub":
+            g = g[::3, ::5]
+        elif kind == "rownorm":
+            g = g.norm(dim=1)
+        errs[f"{kind}/{name}"] = ((g - ref).norm() / (ref.norm() + 1e-20)).item()
+    return errs
+
+
+def bf16_ulps_at_scale(a, ref):
+    """max |a - ref| over the finite entries, in units of the bf16 spacing at the magnitude of the largest |ref| (bf16 has 8
+    significant bits: values in [2^k, 2^(k+1)) are 2^(k-7) apart).  For a vector of logits / hidden states whose entries share
+    one scale this is the natural unit of "how many roundings apart": 1.0 = the last bit of the largest entries."""
+    a = torch.as_tensor(a).float().cpu()
+    ref = torch.as_tensor(ref).float().cpu()
+    fin = torch.isfinite(ref)
+    assert torch.equal(torch.isfinite(a), fin), "inf pattern differs"
+    scale = ref[fin].abs().max().item()
+    ulp = 2.0 ** (int(np.floor(np.log2(max(scale, 1e-30)))) - 7)
+    return (a[fin] - ref[fin]).abs().max().item() / ulp
