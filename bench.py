@@ -40,6 +40,7 @@ def parse():
                     "first-use kernel/attribute/allocator/RCCL initialisation)")
     ap.add_argument("--infer-steps", type=int, default=6, help="extra, untimed-for-`value` forward-only steps reported aside")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config-3 (mixed tasks) and config-4 (64-step) extra measurements")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch GEMM event timing")
     return ap.parse_args()
 
@@ -142,6 +143,99 @@ def inference_extras(a, model, wrapped, crit, ep):
                 "steps": STEPS_PER_EPISODE, "last_step_new_tokens": model.kv.last_stats["new"],
                 "what": "one whole episode (first step = full prefill), K/V of the prompt prefix reused from step to step"}
     return infer, infer_kv
+
+
+def algorithmic_flops(cfg, log):
+    """SURVEY.md §8d: F_fwd = tokens * 2 * P_blk + L * 2 * sum_b S_b^2 * d (causal attention) per LM call, x3 with its backward;
+    lm_head (2 d V per token) only where the LM-loss modes compute it.  `log` = NavModel.flop_log entries."""
+    d, ff, L, V = cfg.hidden_size, cfg.intermediate_size, cfg.num_layers, cfg.vocab_size
+    p_blk = L * (4 * d * d + 3 * d * ff)
+    tot = 0.0
+    for kind, n, sq, grad in log:
+        f = (2.0 * p_blk * n + 2.0 * L * d * sq) if kind == "lm" else 2.0 * d * V * n
+        tot += f * (3.0 if grad else 1.0)
+    return tot
+
+
+def mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed):
+    """BASELINE config 3 on this rank: one meta-step per task of the multi-task mix (R2R + fine-grained R2R + summarization;
+    REVERIE and SOON with the object-grounding sub-task + summarization; CVDN; a ScanQA batch), each a full episode with every
+    backward the reference runs, then clip + AdamW.  One untimed warm pass, one timed pass."""
+    from navillm_amd.synthetic import SyntheticEpisodes, mixed_task_episode, qa_step
+    eps = {t: SyntheticEpisodes(cfg, a.batch, seed=seed + i, instr_len=(a.instr_len if t != "soon" else min(a.instr_len, 256)),
+                                device=device, task=t) for i, t in enumerate(("r2r", "reverie", "soon", "cvdn"))}
+    res = {}
+    for rep in range(2):
+        model.flop_log = []
+        nav_steps = 0
+        per_task = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t, ep in eps.items():
+            ep.reset()
+            t1 = time.perf_counter()
+            mixed_task_episode(wrapped, crit, ep, STEPS_PER_EPISODE)
+            opt.clip_grad_norm_(40.0); opt.step(); opt.zero_grad()
+            nav_steps += STEPS_PER_EPISODE * a.batch
+            torch.cuda.synchronize()
+            per_task[t] = round((time.perf_counter() - t1) * 1e3, 1)
+        t1 = time.perf_counter()
+        qa_step(wrapped, eps["r2r"], sync="final")
+        opt.clip_grad_norm_(40.0); opt.step(); opt.zero_grad()
+        torch.cuda.synchronize()
+        per_task["scanqa"] = round((time.perf_counter() - t1) * 1e3, 1)
+        dt = time.perf_counter() - t0
+        fl = algorithmic_flops(cfg, model.flop_log)
+        res = {"meta_steps": 5, "seconds": round(dt, 3), "ms_per_meta_step": per_task, "nav_steps_per_s_per_gpu": round(nav_steps / dt, 2),
+               "episodes_per_s_per_gpu": round((4 * a.batch + a.batch) / dt, 2),
+               "algorithmic_tflops": round(fl / dt / 1e12, 1), "frac_of_mfma_peak": round(fl / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+               "what": f"one episode each of r2r (+fgr2r on steps 0,2,4 +summarization), reverie and soon (+object grounding +summarization), "
+                       f"cvdn, {STEPS_PER_EPISODE} nav steps each with per-step backward, and one ScanQA batch; B={a.batch}; clip+AdamW after each; "
+                       f"algorithmic FLOPs per SURVEY.md §8d incl. lm_head in the LM-loss modes"}
+    model.flop_log = None
+    return res
+
+
+def long_horizon_extra(a, cfg, model, wrapped, crit, device, seed, T=64):
+    """BASELINE config 4: a 64-step episode.  (i) the validation rollout with history K/V reuse (what "history-KV caching" buys:
+    only the new suffix of each prompt is computed), (ii) training steps at the far end of the horizon (history of 58..63
+    tokens, map of ~100 slots)."""
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step
+    ep = SyntheticEpisodes(cfg, a.batch, seed=seed, instr_len=a.instr_len, device=device, max_frontier=35)
+    model.eval()
+    model.enable_kv_cache(a.batch, capacity=1024)
+    out = {}
+    with torch.no_grad():
+        for rep in range(2):
+            ep.reset(); model.reset_kv_cache()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(T):
+                nav_step(wrapped, crit, ep, train=False)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    out["inference_kv_reuse"] = {"nav_steps_per_s_per_gpu": round(a.batch * T / dt, 2), "steps": T, "S_last": int(ep.S_hist[-1]),
+                                 "new_tokens_last_step": model.kv.last_stats["new"]}
+    model.kv = None
+    model.train()
+    # training at the far end: the episode state above is at t = 64; run 6 more training steps there
+    model.flop_log = []
+    for i in range(2):
+        nav_step(wrapped, crit, ep, train=True, last=False)
+    model.flop_log = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 6
+    for i in range(n):
+        nav_step(wrapped, crit, ep, train=True, last=(i == n - 1))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fl = algorithmic_flops(cfg, model.flop_log)
+    model.flop_log = None
+    model.zero_grad()
+    out["training_at_t64"] = {"nav_steps_per_s_per_gpu": round(a.batch * n / dt, 2), "ms_per_step": round(dt / n * 1e3, 1),
+                              "S": int(ep.S_hist[-1]), "algorithmic_tflops": round(fl / dt / 1e12, 1)}
+    return out
 
 
 def cpu_baseline(a, cfg, seed):
@@ -292,6 +386,18 @@ def main():
             infer_kv = None
         model.kv = None
         model.train()
+    extras = {}
+    if not a.no_extras and a.model != "tiny":
+        for name, fn in (("mixed_task_training_config3", lambda: mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed + 100)),
+                         ("long_horizon_config4", lambda: long_horizon_extra(a, cfg, model, wrapped, crit, device, seed + 200))):
+            try:        # never take the headline line (or a rank) down
+                extras[name] = fn()
+            except Exception as e:
+                extras[name] = {"error": f"{type(e).__name__}: {e}"}
+            model.kv = None
+            model.flop_log = None
+            model.train()
+            model.zero_grad()
 
     if rank == 0:
         value = a.batch * a.steps * world / dt
@@ -316,6 +422,7 @@ def main():
             line["inference_forward_only"] = infer
         if infer_kv is not None:
             line["inference_prefix_kv_reuse"] = infer_kv
+        line.update(extras)
         if g is not None:
             allg = timer.summary(layouts=(0, 1, 2))
             # the dominant kernel is ONE template (gemm_bf16_kernel) in three operand layouts.  With the backward on a

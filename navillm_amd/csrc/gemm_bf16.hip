@@ -604,14 +604,19 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
             __hip_atomic_store(p.counters + tail_u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
         }
         __syncthreads();
+        // Sum the slices in SLICE ORDER 0,1,..,nsplit-1 whichever block arrived last (its own partial is re-read from its
+        // slab: same lane, same address it just stored): fp32 addition is not associative, and an arrival-order sum made the
+        // result depend on block timing -- last-bit flips of the bf16 outputs that a 32-layer model amplifies to visible
+        // run-to-run differences (tests/test_round2_gpu.py::test_full_vicuna_7b_training_step_invariants).
         for (int o = 0; o < nsplit; ++o) {
-            if (o == ks) continue;
-            const float* other = p.slabs + (size_t)(tail_u * p.split + o) * SLAB;
+            const float* part = p.slabs + (size_t)(tail_u * p.split + o) * SLAB;
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j)
-                    acc[i][j] += *(const f32x4*)(other + (size_t)(((wave * TN + i) * TM + j) * 64 + lane) * 4);
+                for (int j = 0; j < TM; ++j) {
+                    const f32x4 v = *(const f32x4*)(part + (size_t)(((wave * TN + i) * TM + j) * 64 + lane) * 4);
+                    acc[i][j] = (o == 0) ? v : acc[i][j] + v;
+                }
         }
     }
 

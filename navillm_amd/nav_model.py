@@ -153,6 +153,7 @@ class NavModel(nn.Module):
         self.prune_last_layer = True     # navigation/grounding: last decoder layer computed for the <cls_1> rows only
         self.pack_rows = os.environ.get("NAVILLM_PACK_ROWS", "1") != "0"   # LM over the real tokens only (no left-padding rows)
         self._row_map = None
+        self.flop_log = None             # bench: list of ("lm", tokens, sum of S_b^2, backward?) / ("lm_head", rows, backward?) per LM call
         self.attn_hf_rounding = False    # tests only: attention forward through the parity instrument nv_attn_fwd_hfround_bf16
         self.kv = None                   # KVCacheLM (enable_kv_cache): prefix reuse across no-grad navigation steps + generation
         self._wgrad_stream = None
@@ -397,6 +398,8 @@ class NavModel(nn.Module):
         kv_np = (S - lens_np).astype(np.int32)
         assert bool((am_np == (np.arange(S)[None] >= kv_np[:, None])).all()), "attention_mask must be left padding"
         kv_start = torch.from_numpy(kv_np)
+        if self.flop_log is not None:
+            self.flop_log.append(("lm", int(lens_np.sum()), int((lens_np.astype(np.int64) ** 2).sum()), torch.is_grad_enabled()))
         packed = None
         self._row_map = None
         flat = ids_cpu.reshape(-1)
@@ -506,6 +509,8 @@ class NavModel(nn.Module):
         shift[:, :-1] = labels_cpu[:, 1:]
         n_valid = int((shift != -100).sum())
         shift = shift.view(-1)
+        if self.flop_log is not None:
+            self.flop_log.append(("lm_head", int(Hs.shape[0]), 0, torch.is_grad_enabled()))
         if self._row_map is not None:          # Hs holds the real tokens only (see _lm); a padding row never carries a label
             assert int((shift[self._row_map] != -100).sum()) == n_valid
             shift = shift[self._row_map]

@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 from .graph import GraphMap, get_angle_fts
-from .prompts import navigation_prompt
+from .prompts import navigation_prompt, object_grounding_prompt, summarization_prompt, embodied_qa_prompt, qa3d_prompt
 
 
 # --------------------------------------------------------------------------- stub tokenizer
@@ -46,15 +46,26 @@ class StubTokenizer:
                 ids.append(self._word(w))
         return ids
 
-    def pad_left(self, seqs, max_length=1024):
+    def pad_left(self, seqs, max_length=1024, types=None):
+        """left pad / left truncate (modified_lm.py:57,77-87); `types`: per-token segment ids (0 = prompt, 1 = answer) ->
+        also returns token_type_ids (padding = 0), as the tokenizer does for a [prompt, answer] text pair"""
         seqs = [s[-max_length:] for s in seqs]              # truncation_side='left'
         S = max(len(s) for s in seqs)
         ids = torch.full((len(seqs), S), self.pad, dtype=torch.int64)
         am = torch.zeros((len(seqs), S), dtype=torch.int64)
+        tt = torch.zeros((len(seqs), S), dtype=torch.int64)
         for i, s in enumerate(seqs):
             ids[i, S - len(s):] = torch.tensor(s)
             am[i, S - len(s):] = 1
-        return ids, am
+            if types is not None:
+                tt[i, S - len(s):] = torch.tensor(types[i][-max_length:])
+        return (ids, am) if types is None else (ids, am, tt)
+
+    def encode_pair(self, prompt, answer_ids, instr_ids=None, eos=2):
+        """[prompt, answer + eos] as one sequence (nav_model.py:299-306, 370-377) -> ids, segment ids"""
+        p = self.encode(prompt, instr_ids)
+        a = list(answer_ids) + [eos]
+        return p + a, [0] * len(p) + [1] * len(a)
 
 
 # --------------------------------------------------------------------------- view geometry
@@ -68,12 +79,13 @@ def view_angle_features(angle_feat_size=4):
 class SyntheticEpisodes:
     """B lock-step episodes on one rank."""
 
-    def __init__(self, cfg, batch_size, seed, instr_len=512, n_views=36, device=None, max_frontier=None):
+    def __init__(self, cfg, batch_size, seed, instr_len=512, n_views=36, device=None, max_frontier=None, task="r2r"):
         """max_frontier: cap on the number of known-but-unvisited nodes per map (long-horizon episodes: in a real
         Matterport graph most candidates of a late step are nodes seen before, so the frontier saturates; the action head is
         100-way (nav_model.py:82-85), i.e. stop + at most 99 unvisited candidates)."""
         self.cfg, self.B, self.N = cfg, batch_size, n_views
         self.max_frontier = max_frontier
+        self.task = task                  # which agent's prompts: r2r | reverie | soon | cvdn (tasks/agents/*.py)
         self.rng = np.random.RandomState(seed)
         self.tgen = torch.Generator().manual_seed(seed)
         self.device = device
@@ -124,19 +136,38 @@ class SyntheticEpisodes:
                 "elevation": 0.0, "candidate": cands}
 
     # ---- tensor builders (mp3d_agent.py:143-212, 264-371)
-    def panorama_inputs(self):
+    def panorama_inputs(self, objects=None, first12=False):
+        """objects=(lo, hi): also O ~ U{lo..hi} object features per sample (panorama_feature_variable_object, mp3d_agent.py:143-212);
+        first12: the 12-view variant of mp3d_agent.py:214-248 (all 36 views, the first 12 flagged navigable, no candidates)"""
         B, N, F = self.B, self.N, self.cfg.image_feat_size
         x = torch.randn(B, N, F, generator=self.tgen)
         nav = torch.zeros(B, N, dtype=torch.int64)
         cand_vpids = []
         for b, ob in enumerate(self.obs):
+            if first12:
+                nav[b, :min(12, N)] = 1
+                cand_vpids.append([None] * N)
+                continue
             k = len(ob["candidate"])
             nav[b, :k] = 1
             cand_vpids.append([c["viewpointId"] for c in ob["candidate"]])
         d = self.device
-        return {"view_img_fts": ops.h2d(x, d), "loc_fts": ops.h2d(self.loc_fts.unsqueeze(0).repeat(B, 1, 1), d),
-                "nav_types": ops.h2d(nav, d), "view_lens": ops.h2d(torch.full((B,), N, dtype=torch.int64), d),
-                "cand_vpids": cand_vpids}
+        out = {"view_img_fts": ops.h2d(x, d), "loc_fts": ops.h2d(self.loc_fts.unsqueeze(0).repeat(B, 1, 1), d),
+               "nav_types": ops.h2d(nav, d), "view_lens": ops.h2d(torch.full((B,), N, dtype=torch.int64), d),
+               "cand_vpids": cand_vpids}
+        if objects is not None:
+            lens = self.rng.randint(objects[0], objects[1] + 1, size=B)
+            O = int(lens.max())
+            of = torch.randn(B, O, self.cfg.obj_feat_size, generator=self.tgen)
+            ang = self.rng.rand(B, O, 2) * np.array([2 * math.pi, 1.0]) - np.array([0.0, 0.5])
+            olf = np.concatenate([get_angle_fts(ang[..., 0].reshape(-1), ang[..., 1].reshape(-1), self.cfg.angle_feat_size).reshape(B, O, -1),
+                                  self.rng.rand(B, O, 3).astype(np.float32)], 2).astype(np.float32)
+            for b in range(B):
+                of[b, lens[b]:] = 0
+                olf[b, lens[b]:] = 0
+            out.update(obj_img_fts=ops.h2d(of, d), obj_lens=torch.from_numpy(lens.astype(np.int64)),
+                       obj_loc_fts=ops.h2d(torch.from_numpy(olf), d))
+        return out
 
     def update_maps(self, pano_embeds, pano_masks, cand_vpids):
         avg = ops.masked_mean_f32(pano_embeds.detach().contiguous(), pano_masks.to(torch.float32).contiguous())
@@ -199,7 +230,7 @@ class SyntheticEpisodes:
         cand_nums = (nav["_gmask_cpu"] & ~nav["_gvis_cpu"]).sum(-1)
         seqs = []
         for b in range(self.B):
-            p = navigation_prompt("r2r", "{INSTR}", len(self.history[b]), int(cand_nums[b]), cls_token)
+            p = navigation_prompt(self.task, "{INSTR}", len(self.history[b]), int(cand_nums[b]), cls_token)
             seqs.append(self.tok.encode(p, self.instr[b]))
         ids, am = self.tok.pad_left(seqs)
         self.S_hist.append(ids.shape[1])
@@ -267,3 +298,115 @@ def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accu
             actions = logits.float().argmax(1).cpu()
         ep.advance(nav, actions, out["fuse_embeds"])
     return loss, logits
+
+
+# --------------------------------------------------------------------------- the other training sub-tasks of a rollout
+def _sync_ctx(model, sync):
+    """sync: 'no_sync' (a non-last step), 'plain' (synced, but more backwards follow before the optimizer step) or 'final'"""
+    if sync == "no_sync" and hasattr(model, "no_sync"):
+        return model.no_sync
+    if sync == "final" and hasattr(model, "final_backward"):
+        return model.final_backward
+    return contextlib.nullcontext
+
+
+def og_step(model, criterion, ep, train=True, sync="plain", coef=1.0, accum=1, objects=(5, 40)):
+    """Object-prediction sub-task of an episode's last step (SOON / REVERIE, mp3d_agent.py:788-842): panorama with objects ->
+    model('object_grounding') -> CE_sum * obj_loss_coef / B / accum -> backward.  Returns (loss, obj_logits)."""
+    with _sync_ctx(model, sync if train else "plain")():
+        pin = ep.panorama_inputs(objects=objects)
+        pano = model("panorama", pin)
+        lens = pin["obj_lens"]
+        seqs = [ep.tok.encode(object_grounding_prompt(ep.task, "{INSTR}", len(ep.history[b]), int(lens[b]) + 1, "<cls_1>"), ep.instr[b])
+                for b in range(ep.B)]
+        ids, am = ep.tok.pad_left(seqs)
+        batch = {"obj_embeds": pano["obj_embeds"], "obj_masks": pano["obj_masks"], "obj_loc_fts": pano["obj_loc_fts"],
+                 "hist_vis": ep.hist_vis, "history": ep.history, "input_ids": ids, "attention_mask": am}
+        logits = model("object_grounding", batch)["obj_logits"]
+        # teacher_object (mp3d_agent.py:458-472): the target object's index + 1, or ignore
+        tg = torch.tensor([int(ep.rng.randint(1, int(lens[b]) + 1)) if ep.rng.rand() < 0.8 else -100 for b in range(ep.B)])
+        loss = None
+        if train:
+            loss = criterion(logits, ops.h2d(tg, logits.device)) * coef / ep.B / accum
+            loss.backward()
+    return loss, logits
+
+
+def lm_aux_step(model, ep, mode, train=True, sync="plain", coef=1.0, accum=1, answer_len=24, **gen):
+    """The LM-loss sub-tasks of a rollout: 'summarization' (last step, mp3d_agent.py:871-909: the label is the episode's
+    instruction) and 'embodied_qa' (fine-grained R2R on a non-last step, :845-868: a short answer, no history).  12-view
+    panorama -> vp tokens -> model(mode, training=True) -> loss * gen_loss_coef / B / accum -> backward."""
+    B = ep.B
+    with _sync_ctx(model, sync if train else "plain")():
+        pin = ep.panorama_inputs(first12=True)
+        pano = model("panorama", pin)
+        pe = pano["pano_embeds"]
+        vp_img = torch.cat([torch.zeros_like(pe[:, :1]), pe], 1)
+        nav_masks = torch.cat([torch.ones(B, 1, dtype=torch.bool), (pin["nav_types"] == 1).cpu()], 1)
+        cn = int(nav_masks[0, 1:].sum())
+        seqs, types = [], []
+        for b in range(B):
+            if mode == "summarization":
+                prompt, hv, ans = summarization_prompt(ep.task, "", len(ep.history[b]), cn), ep.hist_vis, ep.instr[b]
+            else:
+                prompt, hv = embodied_qa_prompt("r2r", "where are we going with direction (1) ?", 0, cn), [[] for _ in range(B)]
+                ans = ep.rng.randint(3, ep.cfg.base_vocab_size, size=answer_len).tolist()
+            s_, t_ = ep.tok.encode_pair(prompt, ans)
+            seqs.append(s_)
+            types.append(t_)
+        ids, am, tt = ep.tok.pad_left(seqs, types=types)
+        batch = {"vp_img_embeds": vp_img, "vp_nav_masks": nav_masks, "hist_vis": hv, "data_type": [ep.task if mode == "summarization" else "fgr2r"] * B,
+                 "input_ids": ids, "attention_mask": am, "token_type_ids": tt, "instruction": [""] * B, "answer": [""] * B}
+        out = model(mode, batch, training=train, **gen)
+        loss = None
+        if train:
+            loss = out["loss"] * coef / B / accum
+            loss.backward()
+    return loss, out
+
+
+def qa_step(model, ep, train=True, sync="final", coef=1.0, accum=1, answer_len=8, n_rows=1, **gen):
+    """ScanQA / LLaVA batch (tasks/agents/llava.py:19-42): one feature row per `<cand>`, question -> answer, loss * coef / accum."""
+    B, F, cfg = ep.B, ep.cfg.image_feat_size, ep.cfg
+    with _sync_ctx(model, sync if train else "plain")():
+        feats = [ops.h2d(torch.randn(n_rows, F, generator=ep.tgen), ep.device) for _ in range(B)]
+        seqs, types = [], []
+        for b in range(B):
+            q = " ".join("w%d" % int(w) for w in ep.rng.randint(0, 500, size=int(ep.rng.randint(6, 14))))
+            prompt = qa3d_prompt(q) if n_rows == 1 else " ".join(["<cand>"] * n_rows) + " ### Question: " + q + " ### Answer: "
+            s_, t_ = ep.tok.encode_pair(prompt, ep.rng.randint(3, cfg.base_vocab_size, size=answer_len).tolist())
+            seqs.append(s_)
+            types.append(t_)
+        ids, am, tt = ep.tok.pad_left(seqs, types=types)
+        out = model("3dqa", {"features": feats, "question": [""] * B, "input_ids": ids, "attention_mask": am, "token_type_ids": tt},
+                    training=train, **gen)
+        loss = None
+        if train:
+            loss = out.loss * coef / accum
+            loss.backward()
+    return loss, out
+
+
+def mixed_task_episode(model, criterion, ep, steps, enable_og=None, enable_summarize=True, enable_fgr2r=True, accum=1, train=True):
+    """One training meta-step of the multi-task mix (BASELINE config 3; rollout of tasks/agents/mp3d_agent.py:593-964 for the
+    task `ep.task`): `steps` navigation steps, each with its backward inside `no_sync` except the last; fine-grained R2R
+    (embodied_qa + LM loss) on the non-last steps of an R2R episode; on the last step the object-grounding sub-task (SOON /
+    REVERIE) and the summarization sub-task (not CVDN), each with its own backward -- the last of them is the `final` one a
+    data-parallel wrapper exchanges gradients from.  Returns the losses of the episode."""
+    if enable_og is None:
+        enable_og = ep.task in ("soon", "reverie")
+    enable_summarize = enable_summarize and ep.task != "cvdn"
+    enable_fgr2r = enable_fgr2r and ep.task == "r2r"
+    losses = {"nav": [], "og": None, "sum": None, "fgr2r": []}
+    for t in range(steps):
+        last = t == steps - 1
+        more = last and (enable_og or enable_summarize)
+        l, _ = nav_step(model, criterion, ep, train=train, last=last, accum=accum, final=last and not more)
+        losses["nav"].append(l)
+        if enable_fgr2r and not last and t % 2 == 0 and train:
+            losses["fgr2r"].append(lm_aux_step(model, ep, "embodied_qa", sync="no_sync", accum=accum)[0])
+        if last and enable_og and train:
+            losses["og"] = og_step(model, criterion, ep, sync="plain" if enable_summarize else "final", accum=accum)[0]
+        if last and enable_summarize and train:
+            losses["sum"] = lm_aux_step(model, ep, "summarization", sync="final", accum=accum)[0]
+    return losses

@@ -81,15 +81,16 @@ def test_flat_store_layout():
 
 
 def test_g6_prompt_strings():
-    from navillm_amd.prompts import navigation_prompt
+    from navillm_amd import prompts as P
     g = json.load(open(os.path.join(GOLD, "g6_prompts.json")))
-    n = 0
-    for k, v in g.items():
+    fns = {"navigation": P.navigation_prompt, "object_grounding": P.object_grounding_prompt,
+           "summarization": P.summarization_prompt, "embodied_qa": P.embodied_qa_prompt}
+    for k, v in g.items():           # every agent x mode x (hist, cand) the reference's own get_*_prompt produced
         agent, mode, h, c = k.split("/")
-        if mode == "navigation" and agent in ("r2r", "reverie"):
-            assert navigation_prompt(agent, "INSTR", int(h), int(c)) == v
-            n += 1
-    assert n >= 6
+        args = (agent, "INSTR", int(h), int(c)) + (("<cls_1>",) if mode in ("navigation", "object_grounding") else ())
+        assert fns[mode](*args) == v, k
+    assert len(g) == 30
+    assert P.qa3d_prompt("what ?") == "### Image: <cand>\n### Instruction: what ?\n### Output: "       # llava.py:13-17
 
 
 def test_g7_graph_sidecar_matches_reference():

