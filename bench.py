@@ -238,6 +238,76 @@ def long_horizon_extra(a, cfg, model, wrapped, crit, device, seed, T=64):
     return out
 
 
+def fp8_13b_extra(a, device, seed):
+    """BASELINE config 5 on this rank: Vicuna-13B + scene encoder, inference.  The same episodes first on the bf16 model, then after
+    `to_fp8_weight_only()` (decoder Linear weights as e4m3fn codes + per-output-channel scales, navillm_amd/fp8.py): forward-only
+    nav steps, nav steps with prefix-K/V reuse, and greedy decoding (the decode steps stream the fp8 codes)."""
+    import types
+    from navillm_amd import config as C
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.losses import CrossEntropyLoss
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step, qa_step
+    cfg13 = C.vicuna_13b(image_feat_size=a.feat)
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated(device)
+    m = NavModel(nav_config=cfg13, device=device, seed=0)
+    m.eval()
+    m.lang_model.tokenizer = types.SimpleNamespace(eos_token_id=2, unk_token_id=0)
+    crit = CrossEntropyLoss()
+    out = {"model": "vicuna-13b (d=5120, L=40, H=40, ff=13824)"}
+
+    def measure(tag):
+        r = {}
+        for B in (4, 8):
+            ep = SyntheticEpisodes(cfg13, B, seed=seed, instr_len=a.instr_len, device=device)
+            with torch.no_grad():
+                for rep in range(2):
+                    ep.reset()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(STEPS_PER_EPISODE):
+                        nav_step(m, crit, ep, train=False)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                r[f"forward_only_B{B}"] = round(B * STEPS_PER_EPISODE / dt, 2)
+                m.enable_kv_cache(B, capacity=1024)
+                for rep in range(2):
+                    ep.reset(); m.reset_kv_cache()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for i in range(STEPS_PER_EPISODE):
+                        nav_step(m, crit, ep, train=False)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                r[f"kv_reuse_B{B}"] = round(B * STEPS_PER_EPISODE / dt, 2)
+                m.kv = None
+        ep = SyntheticEpisodes(cfg13, 8, seed=seed, instr_len=32, device=device)
+        with torch.no_grad():
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                g = qa_step(m, ep, train=False, max_new_tokens=24, do_sample=False)[1]
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+        r["greedy_decode_tokens_per_s_B8"] = round(sum(len(x) for x in g["generated_ids"]) / dt, 1)
+        out[tag] = r
+
+    measure("bf16_nav_steps_per_s")
+    lm_bf16 = m.store.param["lm"].numel() * 2
+    f8 = m.to_fp8_weight_only()
+    torch.cuda.synchronize()
+    out["decoder_weight_bytes"] = {"bf16": int(sum(2 * q.numel() for c in f8.codes for q in c.values())), "fp8_codes_plus_scales": int(f8.bytes)}
+    out["resident_bytes_after_quantisation"] = int(torch.cuda.memory_allocated(device) - base)
+    out["lm_buffer_bytes_bf16_before"] = int(lm_bf16)
+    measure("fp8_weight_only_nav_steps_per_s")
+    out["what"] = ("inference nav steps/s per GPU over one 6-step episode (panorama + navigation forward, argmax actions) at B=4 and 8, and "
+                   "greedy decoding of 24 tokens at B=8; prefill GEMMs run on the de-quantised bf16 scratch panel (3 B/weight pre-pass), "
+                   "decode steps stream the fp8 codes (nv_gemv_fp8w)")
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(a, cfg, seed):
     """The oracle (CPU restatement, kind='port') timed on this box's host cores on a bounded sample:
     ONE episode, ONE nav step, forward + backward, with 8 of the 32 decoder layers (the LM is 99.9% of
@@ -300,6 +370,14 @@ def relaunch_one_rank_per_gpu(a):
     return subprocess.call(cmd, env=env)
 
 
+_T0 = time.perf_counter()
+
+
+def phase(msg):
+    """progress on stderr (the JSON line on stdout stays alone)"""
+    print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -350,6 +428,7 @@ def main():
             ep.reset()
         return loss
 
+    phase("model built")
     for i in range(a.prewarm):          # setup, not part of the protocol's W/K accounting
         one_step(i)
     ep.reset()
@@ -357,6 +436,7 @@ def main():
         one_step(i)
     if not a.no_profile:
         timer.install(ops)
+    phase("warm; timing starts")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -376,6 +456,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    phase(f"timed region done: {dt:.2f} s")
     # ---- untimed extra: the same nav step without loss/backward (validation rollout, mp3d_agent.py:530-590)
     infer = infer_kv = None
     if a.infer_steps > 0:
@@ -386,12 +467,27 @@ def main():
             infer_kv = None
         model.kv = None
         model.train()
+    cpu_line = None
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        # BEFORE the extras: measured after them the same oracle step took 150-160 s instead of 9 s (cause not isolated: the long extra
+        # episodes leave many pinned staging buffers and helper threads behind)
+        phase("cpu baseline")
+        try:
+            cpu_line = cpu_baseline(a, cfg, 1234)
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            cpu_line = {"value": None, "unit": "nav-steps/s", "cores": os.cpu_count(), "kind": "port",
+                        "sample": f"failed: {type(e).__name__}: {e}"}
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))
     extras = {}
     if not a.no_extras and a.model != "tiny":
         for name, fn in (("mixed_task_training_config3", lambda: mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed + 100)),
-                         ("long_horizon_config4", lambda: long_horizon_extra(a, cfg, model, wrapped, crit, device, seed + 200))):
+                         ("long_horizon_config4", lambda: long_horizon_extra(a, cfg, model, wrapped, crit, device, seed + 200)),
+                         ("fp8_weight_only_13b_config5", lambda: fp8_13b_extra(a, device, seed + 300) if world == 1 else None)):
+            phase(name)
             try:        # never take the headline line (or a rank) down
-                extras[name] = fn()
+                r = fn()
+                if r is not None:
+                    extras[name] = r
             except Exception as e:
                 extras[name] = {"error": f"{type(e).__name__}: {e}"}
             model.kv = None
@@ -446,12 +542,9 @@ def main():
                                 "note": "peak = nominal dense bf16 MFMA; with N(0,1) operands the MFMA pipe of this part sustains "
                                         "1.87-2.0 PFLOP/s (power-limited clock; tools/ubench/mix_rate.hip, DESIGN.md §4); "
                                         "traffic = 2*FETCH_SIZE+WRITE_SIZE per forward launch from the PMC passes in profiles/"}
-        if not a.no_cpu_baseline and world == 1:
-            try:
-                line["cpu_baseline"] = cpu_baseline(a, cfg, 1234)
-            except Exception as e:  # the baseline must never take the GPU number down with it
-                line["cpu_baseline"] = {"value": None, "unit": "nav-steps/s", "cores": os.cpu_count(), "kind": "port",
-                                        "sample": f"failed: {type(e).__name__}: {e}"}
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
+        phase("done")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -54,6 +54,18 @@ int nv_gemv_bf16(const void* A, const void* W, void* C, const void* R, int M, in
 int nv_gemm_bf16_rope(const void* A, const void* W, void* C, const void* rope_cos, const void* rope_sin, const int* pos, int M,
                       int N, int K, int lda, int ldw, int ldc, int S, int rope_cols, void* workspace, void* stream);
 
+/* ---- weight-only fp8 (OCP e4m3fn, one fp32 scale per output channel) for the LM's Linear layers: SURVEY.md §8f item 4 /
+ *      BASELINE config 5 (Vicuna-13B inference).  W[n,:] ~= s[n]*q[n,:], s[n] = max|W[n,:]|/448, q = e4m3fn(W/s) (RNE).  The
+ *      arithmetic everywhere is the bf16 GEMM on the de-quantised weight bf16(s*q) ("the reference run on de-quantised weights").
+ *   quant: bf16 [N,K] -> codes u8 [N,K] + scales [N]  (K % 8 == 0)    dequant: -> bf16 [N,K]  (K % 16 == 0) */
+int nv_fp8_quant_rows(const void* W, void* Q, float* scales, int N, int K, int ldw, int ldq, void* stream);
+int nv_fp8_dequant_rows(const void* Q, const float* scales, void* out, int N, int K, int ldq, int ldo, void* stream);
+/*   the in-register decode of all 256 codes (bf16 out[256]); pinned against torch.float8_e4m3fn by the tests */
+int nv_fp8_decode_table(void* out256_bf16, void* stream);
+/*   decode-step weight streamer on fp8 weights: C[M<=16,N] = A[M,K] @ bf16(s*q)^T (+R); K % 64 == 0; epilogue 0 | 2 as nv_gemv_bf16 */
+int nv_gemv_fp8w(const void* A, const void* Wq, const float* scales, void* C, const void* R, int M, int N, int K, int lda, int ldw,
+                 int ldc, int ldr, int epilogue, void* stream);
+
 /* ---- K6: embedding gather + visual-token add, models/modified_lm.py:100-110.
  *   out[m] = table[ids[m]]  or  bf16(f32(table[ids[m]]) + vis[vis_idx[m]])  when vis_idx[m] >= 0 */
 int nv_embed_vis_bf16(const void* table, const int* ids, const int* vis_idx, const float* vis, void* out, int M, int d,
@@ -168,6 +180,9 @@ int nv_gelu_fwd_f32(const float* x, float* y, long n, void* stream);
 int nv_gelu_bwd_f32(const float* x, const float* dy, float* dx, long n, void* stream);
 int nv_add_f32(const float* a, const float* b, float* out, long n, int d, int b_bcast, void* stream);
 int nv_mul_f32(const float* a, const float* b, float* out, long n, void* stream);
+/*   nn.Dropout(p) with an in-kernel Philox4x32-10 mask: out = keep ? x/(1-p) : 0, keep(i) from (seed, offset + i/4).  The
+ *   backward is the same call on the gradient with the same (seed, offset): the mask is regenerated, never stored. */
+int nv_dropout_f32(const float* x, float* out, long n, float p, unsigned long long seed, unsigned long long offset, void* stream);
 int nv_rowscale_f32(const float* x, const float* s, float* out, long rows, int d, void* stream);
 int nv_gather_add_f32(const float* src, const int* idx, const float* base, float* out, long rows, int d, void* stream);
 int nv_index_sum_f32(const float* src, const int* idx, float* dst, int n, int R, int d, int accumulate, void* stream);

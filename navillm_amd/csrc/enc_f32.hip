@@ -418,6 +418,37 @@ __global__ __launch_bounds__(256) void mul_f32_kernel(const float* __restrict__ 
                                                       float* __restrict__ out, long n) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) out[i] = a[i] * b[i];
 }
+// nn.Dropout with the keep mask drawn IN the kernel (Philox4x32-10, counter = element group, key = seed): one launch instead of
+// torch.rand + compare + cast + scale + multiply, and nothing to store for the backward -- it calls the same kernel with the same
+// (seed, offset) on the incoming gradient and regenerates the identical mask.  (nav_model.py:91,99-102 drop_env p=0.4;
+// image_embedding.py:73-74 and detr_transformer.py:170-182 p=0.1.)  The reference's mask stream is torch's CUDA Philox
+// generator: a different, equally valid stream (dropout cannot be bit-matched across devices anyway).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ x, float* __restrict__ out, long n, float p,
+                                                          float scale, uint64_t seed, uint64_t offset) {
+    const long groups = (n + 3) / 4;
+    for (long gi = blockIdx.x * 256L + threadIdx.x; gi < groups; gi += gridDim.x * 256L) {
+        const uint64_t ctr = offset + (uint64_t)gi;
+        uint32_t r[4];
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        const long i = gi * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i + j < n) {
+                const float u = (float)(r[j] >> 8) * (1.0f / 16777216.0f);     // uniform on [0, 1), 24 bits
+                out[i + j] = u >= p ? x[i + j] * scale : 0.f;
+            }
+    }
+}
 // out[m,:] = x[m,:] * s[m]
 __global__ __launch_bounds__(256) void rowscale_f32_kernel(const float* __restrict__ x, const float* __restrict__ s,
                                                            float* __restrict__ out, long n, int d) {
@@ -616,6 +647,13 @@ int nv_mul_f32(const float* a, const float* b, float* out, long n, void* stream)
     if (!a || !b || !out) return NV_ERR_ARG;
     if (n == 0) return NV_OK;
     NV_LAUNCH(mul_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    return nv_check_launch();
+}
+int nv_dropout_f32(const float* x, float* out, long n, float p, unsigned long long seed, unsigned long long offset, void* stream) {
+    if (!x || !out || !(p >= 0.f) || !(p < 1.f)) return NV_ERR_ARG;
+    if (n == 0) return NV_OK;
+    NV_LAUNCH(dropout_f32_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, out, n, p, 1.f / (1.f - p),
+              (uint64_t)seed, (uint64_t)offset);
     return nv_check_launch();
 }
 int nv_rowscale_f32(const float* x, const float* s, float* out, long rows, int d, void* stream) {

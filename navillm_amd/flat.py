@@ -80,13 +80,19 @@ class FlatStore:
         return store[g][o:o + n].view(self.shape_of[name])
 
     def p(self, name):
+        if name in getattr(self, "released", ()):
+            raise RuntimeError(f"{name}: released by to_fp8_weight_only() (weight-only fp8 deployment); use NavModel.lm_w / lm_linear")
         return self._view(self.param, name)
 
     def g(self, name):
+        if self.grad is None:
+            raise RuntimeError("gradient buffers were released by to_fp8_weight_only(): the fp8 deployment is inference only")
         return self._view(self.grad, name)
 
     def _packed(self, store, first, last):
         """[rows_total, cols] view spanning adjacent tensors first..last (same cols)."""
+        if first in getattr(self, "released", ()):
+            raise RuntimeError(f"{first}: the bf16 decoder weights were released by to_fp8_weight_only(); use NavModel.lm_w / lm_linear")
         cols = self.shape_of[first][1]
         o0 = self.offsets[first]
         o1 = self.offsets[last] + self.sizes[last]
@@ -129,8 +135,34 @@ class FlatStore:
             self.touched.update(n for n in self.names["lm"] if n.startswith("lang_model.model.layers.") or n == "lang_model.model.norm.weight")
 
     def zero_grad(self):
-        for g in self.grad.values():
-            g.zero_()
+        if self.grad is not None:
+            for g in self.grad.values():
+                g.zero_()
+
+    def release_decoder_layers_and_grads(self, named_params):
+        """Inference deployment with weight-only fp8 decoder weights (navillm_amd/fp8.py): drop the bf16 copies of the decoder's
+        Linear weights and every gradient buffer.  The remaining LM-dtype tensors (embeddings, norms, lm_head, heads) move to
+        a compact buffer; the nn.Parameters are re-pointed at it (released ones become empty)."""
+        gone = lambda n: n.startswith("lang_model.model.layers.") and n.endswith("_proj.weight")
+        keep = [n for n in self.names["lm"] if not gone(n)]
+        off, new_off = 0, {}
+        for n in keep:
+            new_off[n] = off
+            off += self.alloc_sizes[n]
+        new = torch.zeros(off, dtype=self.lm_dtype, device=self.device)
+        for n in keep:
+            new[new_off[n]:new_off[n] + self.alloc_sizes[n]].copy_(self.param["lm"][self.offsets[n]:self.offsets[n] + self.alloc_sizes[n]])
+        self.param["lm"] = new
+        self.offsets.update(new_off)
+        self.released = {n for n in self.names["lm"] if gone(n)}
+        self.names["lm"] = keep
+        self.total["lm"] = off
+        self.grad = None
+        self.exp_avg = self.exp_avg_sq = None
+        for n, p in named_params.items():
+            p.grad = None
+            p.requires_grad_(False)
+            p.data = torch.empty(0, dtype=p.dtype, device=self.device) if n in self.released else self.p(n)
 
     def init_optimizer_state(self):
         if self.exp_avg is None:

@@ -1,0 +1,86 @@
+"""Weight-only fp8 (OCP e4m3fn) deployment of the LM (BASELINE config 5: Vicuna-13B inference).
+
+`NavModel.to_fp8_weight_only()` quantises the decoder's seven Linear weights per layer -- as the four packed GEMM operands
+q|k|v, o, gate|up, down -- to one byte per weight plus one fp32 scale per output channel (12.7 of 13.0 B parameters at 13B: 25.4 GB
+of bf16 weights become 12.7 GB), and releases the bf16 copies and every gradient buffer.  Inference only: a forward with autograd
+enabled raises.
+
+Arithmetic: every GEMM multiplies with the de-quantised weight bf16(s[n] * q[n,k]) -- "the reference run on de-quantised
+weights", the semantics tests/golden/g11_fp8_*.npz pin:
+  * prefill / K/V-reuse steps (M > 16 rows): `nv_fp8_dequant_rows` writes the operand into ONE bf16 scratch panel (reused by every
+    GEMM of the stream, 141 MB at 13B) in front of the bf16 MFMA GEMM.  HBM-bound pre-pass of 3 B per weight: 5-12 % of the GEMM
+    it feeds at B = 4..8 (DESIGN.md §4 has the measurement);
+  * decode steps (M <= 16): `nv_gemv_fp8w` streams the codes themselves -- half the bytes per generated token.
+"""
+import torch
+
+from . import lib as _lib
+from . import ops
+
+BF16, F32, U8 = torch.bfloat16, torch.float32, torch.uint8
+KINDS = ("qkv", "o", "gate_up", "down")
+
+
+def quantize_rows(W):
+    """bf16 [N,K] (device) -> (codes u8 [N,K], scales fp32 [N])"""
+    ops._chk2d(W, BF16)
+    N, K = W.shape
+    q = torch.empty((N, K), dtype=U8, device=W.device)
+    s = torch.empty((N,), dtype=F32, device=W.device)
+    _lib.check(ops._L().nv_fp8_quant_rows(W.data_ptr(), q.data_ptr(), s.data_ptr(), N, K, W.stride(0), q.stride(0), ops._st()),
+               "nv_fp8_quant_rows")
+    return q, s
+
+
+def dequantize_rows(q, s, out=None):
+    N, K = q.shape
+    if out is None:
+        out = torch.empty((N, K), dtype=BF16, device=q.device)
+    _lib.check(ops._L().nv_fp8_dequant_rows(q.data_ptr(), s.data_ptr(), out.data_ptr(), N, K, q.stride(0), out.stride(0), ops._st()),
+               "nv_fp8_dequant_rows")
+    return out
+
+
+def decode_table(device):
+    t = torch.empty((256,), dtype=BF16, device=device)
+    _lib.check(ops._L().nv_fp8_decode_table(t.data_ptr(), ops._st()), "nv_fp8_decode_table")
+    return t
+
+
+def gemv_fp8w(x, q, s, out=None, R=None, epilogue=ops.EPI_STORE):
+    M, K = x.shape
+    N = q.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=x.device)
+    rc = ops._L().nv_gemv_fp8w(x.data_ptr(), q.data_ptr(), s.data_ptr(), out.data_ptr(), ops._p(R), M, N, K, x.stride(0), q.stride(0),
+                               out.stride(0), 0 if R is None else R.stride(0), epilogue, ops._st())
+    _lib.check(rc, "nv_gemv_fp8w")
+    return out
+
+
+class Fp8DecoderWeights:
+    def __init__(self, model):
+        cfg, st = model.cfg, model.store
+        self.codes, self.scales = [], []
+        with torch.no_grad():
+            for i in range(cfg.num_layers):
+                p = f"lang_model.model.layers.{i}."
+                mats = {"qkv": st.qkv(i), "o": st.p(p + "self_attn.o_proj.weight"), "gate_up": st.gate_up(i),
+                        "down": st.p(p + "mlp.down_proj.weight")}
+                qs = {k: quantize_rows(v) for k, v in mats.items()}
+                self.codes.append({k: v[0] for k, v in qs.items()})
+                self.scales.append({k: v[1] for k, v in qs.items()})
+        n_max = max(q.shape[0] * q.shape[1] for q in self.codes[0].values())
+        self._scratch = torch.empty((n_max,), dtype=BF16, device=model.device)
+        self.bytes = sum(q.numel() + s.numel() * 4 for c, sc in zip(self.codes, self.scales) for q, s in zip(c.values(), sc.values()))
+
+    def weight(self, i, kind):
+        """the de-quantised operand bf16(s*q) in the shared scratch panel (valid until the next call, stream-ordered)"""
+        q, s = self.codes[i][kind], self.scales[i][kind]
+        return dequantize_rows(q, s, out=self._scratch[:q.numel()].view(q.shape))
+
+    def linear(self, x, i, kind, out=None, R=None, epilogue=ops.EPI_STORE):
+        q, s = self.codes[i][kind], self.scales[i][kind]
+        if x.shape[0] <= 16 and epilogue in (ops.EPI_STORE, ops.EPI_RESID) and q.shape[1] % 64 == 0:
+            return gemv_fp8w(x, q, s, out=out, R=R, epilogue=epilogue)
+        return ops.gemm_bf16(ops.NT, x, self.weight(i, kind), out=out, R=R, epilogue=epilogue)

@@ -151,15 +151,47 @@ class MulMaskF32(torch.autograd.Function):
         return ops.mul_f32(_c(g), mask), None
 
 
+class DropoutF32(torch.autograd.Function):
+    """nn.Dropout(p) as ONE launch: the keep mask comes from Philox4x32-10 inside the kernel, keyed by (seed, offset); the
+    backward regenerates it (nothing is stored)."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed, offset):
+        ctx.key = (p, seed, offset)
+        return ops.dropout_f32(_c(x), p, seed, offset)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.dropout_f32(_c(g), *ctx.key), None, None, None
+
+
+class _DropoutStream:
+    """Philox counter space of this process: seeded from torch's seed (so `torch.manual_seed` controls it), every call takes
+    the next ceil(n/4) counters."""
+
+    def __init__(self):
+        self.seed, self.offset = None, 0
+
+    def take(self, n):
+        s = torch.initial_seed()
+        if s != self.seed:
+            self.seed, self.offset = s, 0
+        o = self.offset
+        self.offset += (n + 3) // 4
+        return self.seed, o
+
+
+_drop_stream = _DropoutStream()
+
+
 def dropout(x, p, training, mask=None):
-    """nn.Dropout. `mask` (0/1 keep flags) may be injected for parity tests, otherwise it is
-    drawn from torch's device generator."""
+    """nn.Dropout. `mask` (0/1 keep flags) may be injected for parity tests, otherwise it is drawn inside the HIP kernel."""
     if not training or p == 0.0:
         return x
-    if mask is None:
-        mask = (torch.rand(x.shape, device=x.device) >= p)
-    m = mask.to(torch.float32) * (1.0 / (1.0 - p))
-    return MulMaskF32.apply(x, m)
+    if mask is not None:
+        return MulMaskF32.apply(x, mask.to(torch.float32) * (1.0 / (1.0 - p)))
+    seed, off = _drop_stream.take(x.numel())
+    return DropoutF32.apply(x, p, seed, off)
 
 
 class EmbedAddF32(torch.autograd.Function):
@@ -344,6 +376,8 @@ class LlamaStack(torch.autograd.Function):
         reference's frame (it numbers positions over the padding), kv_start = position of each sample's first token."""
         cfg, st, ar = model.cfg, model.store, model.arena
         H, hd, eps = cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps
+        if model.fp8 is not None and ctx.needs_input_grad[0]:
+            raise RuntimeError("the weight-only fp8 model is inference only: run it under torch.no_grad()")
         M = E.shape[0]
         cu, pos, Sm = packed if packed is not None else (None, None, S)
         ar.reserve(max(M, B * Sm))
@@ -352,8 +386,8 @@ class LlamaStack(torch.autograd.Function):
 
         def qkv_proj(n1, i, a):
             if FUSE_ROPE_FWD and M > 16:
-                return ops.gemm_qkv_rope(n1, st.qkv(i), model.rope_cos, model.rope_sin, S, 2 * H * hd, out=a["qkv"][:M], pos_i32=pos)
-            qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i), out=a["qkv"][:M])
+                return ops.gemm_qkv_rope(n1, model.lm_w(i, "qkv"), model.rope_cos, model.rope_sin, S, 2 * H * hd, out=a["qkv"][:M], pos_i32=pos)
+            qkv = model.lm_linear(n1, i, "qkv", out=a["qkv"][:M])
             if pos is not None:
                 return ops.rope_rows_(qkv, model.rope_cos, model.rope_sin, pos, H, hd)
             return ops.rope_(qkv, model.rope_cos, model.rope_sin, S, H, hd)
@@ -375,12 +409,12 @@ class LlamaStack(torch.autograd.Function):
             n1, rstd1 = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps, out=a["n1"][:M], rstd=a["rstd1"][:M])
             qkv = qkv_proj(n1, i, a)
             attn, lse = attention(qkv, a, 0)
-            x1 = ops.gemm_bf16(ops.NT, attn, st.p(p + "self_attn.o_proj.weight"), out=a["x1"][:M], R=x, epilogue=ops.EPI_RESID)
+            x1 = model.lm_linear(attn, i, "o", out=a["x1"][:M], R=x, epilogue=ops.EPI_RESID)
             n2, rstd2 = ops.rmsnorm_fwd(x1, st.p(p + "post_attention_layernorm.weight"), eps, out=a["n2"][:M],
                                         rstd=a["rstd2"][:M])
-            gu = ops.gemm_bf16(ops.NT, n2, st.gate_up(i), out=a["gu"][:M])
+            gu = model.lm_linear(n2, i, "gate_up", out=a["gu"][:M])
             h = ops.swiglu_fwd(gu, out=a["h"][:M])
-            x = ops.gemm_bf16(ops.NT, h, st.p(p + "mlp.down_proj.weight"), out=a["x2"][:M], R=x1, epilogue=ops.EPI_RESID)
+            x = model.lm_linear(h, i, "down", out=a["x2"][:M], R=x1, epilogue=ops.EPI_RESID)
         ctx.tail = None
         if tail_rows is not None:
             i = cfg.num_layers - 1
@@ -393,11 +427,11 @@ class LlamaStack(torch.autograd.Function):
             attn, _ = attention(qkv, a, qmin)
             attn_r = ops.gather_rows_bf16(attn, tail_rows)
             x_r = ops.gather_rows_bf16(x, tail_rows)
-            x1_r = ops.gemm_bf16(ops.NT, attn_r, st.p(p + "self_attn.o_proj.weight"), R=x_r, epilogue=ops.EPI_RESID)
+            x1_r = model.lm_linear(attn_r, i, "o", R=x_r, epilogue=ops.EPI_RESID)
             n2_r, rstd2_r = ops.rmsnorm_fwd(x1_r, st.p(p + "post_attention_layernorm.weight"), eps)
-            gu_r = ops.gemm_bf16(ops.NT, n2_r, st.gate_up(i))
+            gu_r = model.lm_linear(n2_r, i, "gate_up")
             h_r = ops.swiglu_fwd(gu_r)
-            x = ops.gemm_bf16(ops.NT, h_r, st.p(p + "mlp.down_proj.weight"), R=x1_r, epilogue=ops.EPI_RESID)
+            x = model.lm_linear(h_r, i, "down", R=x1_r, epilogue=ops.EPI_RESID)
             ctx.tail = (tail_rows, qmin, attn_r, x1_r, rstd2_r, n2_r, gu_r, h_r, x)
         Hs, rstdf = ops.rmsnorm_fwd(x, st.p("lang_model.model.norm.weight"), eps)
         ctx.model, ctx.E, ctx.rstdf = model, E, rstdf

@@ -107,16 +107,16 @@ class KVCacheLM:
         for i in range(cfg.num_layers):
             p = f"lang_model.model.layers.{i}."
             n1, _ = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps)
-            qkv = ops.gemm_bf16(ops.NT, n1, st.qkv(i))
+            qkv = m.lm_linear(n1, i, "qkv")
             ops.rope_rows_(qkv, m.rope_cos, m.rope_sin, pos_d, H, hd)
             ops.scatter_rows_bf16_(qkv, crow_d, self.qkv[i])
             ops.attn_fwd_strided(self.qkv[i], self.kv0, B, Lmax, cap, H, hd, out=self.attn, lse2=self.lse, q_row_min=qmin)
             attn = ops.gather_rows_bf16(self.attn, grow_d)
-            x1 = ops.gemm_bf16(ops.NT, attn, st.p(p + "self_attn.o_proj.weight"), R=x, epilogue=ops.EPI_RESID)
+            x1 = m.lm_linear(attn, i, "o", R=x, epilogue=ops.EPI_RESID)
             n2, _ = ops.rmsnorm_fwd(x1, st.p(p + "post_attention_layernorm.weight"), eps)
-            gu = ops.gemm_bf16(ops.NT, n2, st.gate_up(i))
+            gu = m.lm_linear(n2, i, "gate_up")
             h = ops.swiglu_fwd(gu)
-            x = ops.gemm_bf16(ops.NT, h, st.p(p + "mlp.down_proj.weight"), R=x1, epilogue=ops.EPI_RESID)
+            x = m.lm_linear(h, i, "down", R=x1, epilogue=ops.EPI_RESID)
         for b in range(B):
             self.ids[b], self.keys[b] = list(ids_list[b]), list(keys_list[b])
         self.last_stats = {"prefix": P, "new": n, "block_rows": M}

@@ -20,6 +20,10 @@ SIGNATURES = {
     "nv_gemm_bf16_ws": (i, [i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp, vp]),
     "nv_gemm_bf16_rope": (i, [vp, vp, vp, vp, vp, ip, i, i, i, i, i, i, i, i, vp, vp]),
     "nv_gemv_bf16": (i, [vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp]),
+    "nv_fp8_quant_rows": (i, [vp, vp, fp, i, i, i, i, vp]),
+    "nv_fp8_dequant_rows": (i, [vp, fp, vp, i, i, i, i, vp]),
+    "nv_fp8_decode_table": (i, [vp, vp]),
+    "nv_gemv_fp8w": (i, [vp, vp, fp, vp, vp, i, i, i, i, i, i, i, i, vp]),
     "nv_embed_vis_bf16": (i, [vp, ip, ip, fp, vp, i, i, vp]),
     "nv_vis_grad_f32": (i, [vp, ip, fp, i, i, vp]),
     "nv_embed_grad_bf16": (i, [vp, ip, ip, ip, vp, i, i, vp]),
@@ -62,6 +66,7 @@ SIGNATURES = {
     "nv_gelu_bwd_f32": (i, [fp, fp, fp, l, vp]),
     "nv_add_f32": (i, [fp, fp, fp, l, i, i, vp]),
     "nv_mul_f32": (i, [fp, fp, fp, l, vp]),
+    "nv_dropout_f32": (i, [fp, fp, l, f, C.c_ulonglong, C.c_ulonglong, vp]),
     "nv_rowscale_f32": (i, [fp, fp, fp, l, i, vp]),
     "nv_gather_add_f32": (i, [fp, ip, fp, fp, l, i, vp]),
     "nv_index_sum_f32": (i, [fp, ip, fp, i, i, i, i, vp]),

@@ -153,6 +153,7 @@ class NavModel(nn.Module):
         self.prune_last_layer = True     # navigation/grounding: last decoder layer computed for the <cls_1> rows only
         self.pack_rows = os.environ.get("NAVILLM_PACK_ROWS", "1") != "0"   # LM over the real tokens only (no left-padding rows)
         self._row_map = None
+        self.fp8 = None                  # Fp8DecoderWeights after to_fp8_weight_only()
         self.flop_log = None             # bench: list of ("lm", tokens, sum of S_b^2, backward?) / ("lm_head", rows, backward?) per LM call
         self.attn_hf_rounding = False    # tests only: attention forward through the parity instrument nv_attn_fwd_hfround_bf16
         self.kv = None                   # KVCacheLM (enable_kv_cache): prefix reuse across no-grad navigation steps + generation
@@ -196,6 +197,39 @@ class NavModel(nn.Module):
                 self._named[k].copy_(v.to(self._named[k].dtype))
                 n += 1
         return n
+
+    # ---- the decoder's four packed GEMM operands per layer: bf16 views of the flat store, or their weight-only fp8 form
+    _LM_W = {"o": "self_attn.o_proj.weight", "down": "mlp.down_proj.weight"}
+
+    def lm_w(self, i, kind):
+        if self.fp8 is not None:
+            return self.fp8.weight(i, kind)
+        if kind == "qkv":
+            return self.store.qkv(i)
+        if kind == "gate_up":
+            return self.store.gate_up(i)
+        return self.store.p(f"lang_model.model.layers.{i}.{self._LM_W[kind]}")
+
+    def lm_linear(self, x, i, kind, out=None, R=None, epilogue=ops.EPI_STORE):
+        """y = x W^T (+ R) with W = decoder layer i's `kind` operand (forward only)"""
+        if self.fp8 is not None:
+            return self.fp8.linear(x, i, kind, out=out, R=R, epilogue=epilogue)
+        return ops.gemm_bf16(ops.NT, x, self.lm_w(i, kind), out=out, R=R, epilogue=epilogue)
+
+    @torch.no_grad()
+    def to_fp8_weight_only(self):
+        """Deployment form for inference: decoder Linear weights -> e4m3fn codes + per-output-channel
+        scales (navillm_amd/fp8.py); the bf16 copies of those weights and ALL gradient buffers are released.  Irreversible;
+        training / backward / state_dict() of the decoder layers are not available afterwards."""
+        from .fp8 import Fp8DecoderWeights
+        if self.fp8 is not None:
+            return self.fp8
+        torch.cuda.synchronize(self.device)
+        self.fp8 = Fp8DecoderWeights(self)
+        self.store.release_decoder_layers_and_grads(self._named)
+        self.eval()
+        torch.cuda.empty_cache()
+        return self.fp8
 
     def reserve_activations(self, batch, seq_len):
         """size the LM activation arena once, up front (B*S rows)"""

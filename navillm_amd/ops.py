@@ -454,6 +454,14 @@ def mul_f32(a, b):
     return out
 
 
+def dropout_f32(x, p, seed, offset):
+    """keep-mask drawn in the kernel from (seed, offset); same call on the gradient = the backward"""
+    out = torch.empty_like(x)
+    _lib.check(_L().nv_dropout_f32(x.data_ptr(), out.data_ptr(), x.numel(), float(p), int(seed) & (2 ** 64 - 1), int(offset), _st()),
+               "nv_dropout_f32")
+    return out
+
+
 def rowscale_f32(x, s):
     """x [rows, d] * s [rows] (fp32 0/1 masks)."""
     out = torch.empty_like(x)

@@ -374,7 +374,11 @@ def qa_step(model, ep, train=True, sync="final", coef=1.0, accum=1, answer_len=8
         for b in range(B):
             q = " ".join("w%d" % int(w) for w in ep.rng.randint(0, 500, size=int(ep.rng.randint(6, 14))))
             prompt = qa3d_prompt(q) if n_rows == 1 else " ".join(["<cand>"] * n_rows) + " ### Question: " + q + " ### Answer: "
-            s_, t_ = ep.tok.encode_pair(prompt, ep.rng.randint(3, cfg.base_vocab_size, size=answer_len).tolist())
+            if train:
+                s_, t_ = ep.tok.encode_pair(prompt, ep.rng.randint(3, cfg.base_vocab_size, size=answer_len).tolist())
+            else:                                                   # generation: the prompt only
+                s_ = ep.tok.encode(prompt)
+                t_ = [0] * len(s_)
             seqs.append(s_)
             types.append(t_)
         ids, am, tt = ep.tok.pad_left(seqs, types=types)

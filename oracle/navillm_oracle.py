@@ -428,3 +428,42 @@ def adamw_step_(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01)
     bc2 = 1 - beta2 ** step
     denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
     p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+# --------------------------------------------------------------------------- weight-only fp8
+# No reference counterpart: the reference has no quantised path (models/nav_model.py:40-47 builds a bf16/fp32 LM).  The
+# semantics are "the reference run on de-quantised weights", pinned by tests/golden/g11_fp8_*.npz (the reference model
+# loaded with weights that make_golden.py fake-quantises with torch's own float8_e4m3fn conversion).
+FP8_MAX = 448.0      # largest finite OCP e4m3fn value
+
+
+def fp8_quantize_rows(W):
+    """per-OUTPUT-channel (row) symmetric quantisation: s[n] = max|W[n,:]| / 448 (1 for an all-zero row),
+    q = e4m3fn(W / s) round-to-nearest-even -> (q as torch.float8_e4m3fn [N,K], s fp32 [N])"""
+    Wf = W.float()
+    s = Wf.abs().amax(1) / FP8_MAX
+    s = torch.where(s > 0, s, torch.ones_like(s))
+    return (Wf / s[:, None]).to(torch.float8_e4m3fn), s
+
+
+def fp8_dequantize(q, s, dtype=torch.bfloat16):
+    """the weight every GEMM of the fp8 path multiplies with: dtype(s[n] * q[n,k])"""
+    return (q.float() * s[:, None]).to(dtype)
+
+
+def is_fp8_weight(name):
+    """the decoder's seven Linear weights per layer (12.7 of Vicuna-13B's 13.0 B parameters); embeddings, norms, lm_head and
+    the fp32 encoder stay as they are"""
+    return name.startswith("lang_model.model.layers.") and name.endswith("_proj.weight")
+
+
+def fp8_weight_only_state_dict(P):
+    """state dict with every decoder Linear weight replaced by its de-quantised fp8 version"""
+    out = {}
+    for k, v in P.items():
+        if is_fp8_weight(k):
+            q, s = fp8_quantize_rows(v)
+            out[k] = fp8_dequantize(q, s, v.dtype)
+        else:
+            out[k] = v
+    return out

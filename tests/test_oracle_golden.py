@@ -269,3 +269,30 @@ def test_g10_training_step_gradients_of_every_mode(tag):
     P = fresh()
     l_ = O.qa_3d_loss(P, cfg, feats, T(q["input_ids"]), T(q["attention_mask"]), T(q["token_type_ids"]))
     check("qa", P, l_ * float(z10["qa/coef"]))
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_g11_fp8_weight_only(tag):
+    """weight-only fp8: the oracle's quantiser against torch's float8_e4m3fn vector (bit-exact codes and scales), and the
+    oracle navigation on de-quantised weights against the reference run on de-quantised weights."""
+    z = gold(f"g11_fp8_{tag}.npz")
+    q, s = O.fp8_quantize_rows(T(z["quant_w"]).bfloat16())
+    assert np.array_equal(q.view(torch.uint8).numpy(), z["quant_codes"])
+    assert np.array_equal(s.numpy(), z["quant_scales"])
+    assert torch.equal(O.fp8_dequantize(q, s).float(), T(z["quant_dequant"]).float())
+    assert float(s[5]) == 1.0 and int(q.view(torch.uint8)[5].max()) == 0                 # all-zero row
+    # navigation on the de-quantised weights (G3 inputs)
+    z3 = gold(f"g3_nav_{tag}.npz")
+    cfg, P = tiny_weights(tag)
+    Pq = O.fp8_weight_only_state_dict(P)
+    assert not torch.equal(Pq["lang_model.model.layers.0.self_attn.q_proj.weight"], P["lang_model.model.layers.0.self_attn.q_proj.weight"])
+    assert Pq["lang_model.lm_head.weight"] is P["lang_model.lm_head.weight"]
+    with torch.no_grad():
+        pano = O.scene_encoder(Pq, cfg, T(z3["view_img_fts"]), T(z3["view_lens"]), T(z3["loc_fts"]), T(z3["nav_types"]))
+        batch, m = nav_batch_from_gold(z3, pano["pano_embeds"])
+        torch.manual_seed(m["seed_before_nav"])
+        out = O.navigation(Pq, cfg, batch, T(z3["input_ids"]), T(z3["attention_mask"]))
+    close(out["fuse_logits"], z["fuse_logits"], 2e-5 if tag == "fp32" else 1e-2, what="fp8 fuse_logits")
+    # and the quantisation really changes the result (the fixture is not the unquantised G3 again)
+    fin = np.isfinite(z["fuse_logits"])
+    assert np.abs(z["fuse_logits"][fin] - z3["fuse_logits"][fin]).max() > 5e-3

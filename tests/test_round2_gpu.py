@@ -180,12 +180,58 @@ def test_full_vicuna_7b_training_step_invariants():
         o, k = st.offsets[n], st.sizes[n]
         assert float(g1[st.group_of[n]][o:o + k].float().abs().max()) > 0, n
     assert "lang_model.lm_head.weight" not in st.touched and "og_head.0.weight" not in st.touched
+    # packed rows vs the reference's padded [B, S] layout at full depth.  The two layouts run different GEMM tilings, i.e. differ in
+    # the last bit of some bf16 activations; a RANDOM-weight 32-layer decoder (per-layer gain 0.02*sqrt(4096) = 1.28) amplifies
+    # such flips layer after layer, so at full depth only statistical closeness can be asserted (a wrong position / mask /
+    # row map would decorrelate the outputs completely: gap ~ logit scale, gradient error ~ 1.4).  The tight equality is
+    # asserted where it is meaningful: test_packed_rows_match_padded_layout (3 layers) and the two-layer 7B-width test below.
     lp, gp, _, _ = run(False)
     assert torch.equal(torch.isfinite(lp), fin)
     gap = (lp[fin] - l1[fin]).abs().max().item()
+    scale = l1[fin].abs().max().item()
     rels = {g: ((gp[g].float() - g1[g].float()).norm() / (g1[g].float().norm() + 1e-20)).item() for g in g1}
-    print(f"[7b full] S={S} loss={loss1:.4f}  packed vs padded: logits {gap:.5f}, grad rel {rels}")
-    assert gap < 2e-2 and max(rels.values()) < 3e-2
+    print(f"[7b full] S={S} loss={loss1:.4f} logit scale {scale:.2f}; packed vs padded: logits {gap:.4f}, grad rel {rels}")
+    assert gap < 0.25 * scale and max(rels.values()) < 0.5
+    m.pack_rows = True
+    del m
+    torch.cuda.empty_cache()
+
+
+def test_7b_width_two_layers_packed_rows_equal_padded_layout():
+    """packed rows == padded layout at the FULL Vicuna-7B width (d=4096, 32 heads, ff=11008, B=8, S~650, ragged prompts), with two
+    decoder layers so that rounding flips are not amplified: logits and gradients must agree tightly."""
+    from navillm_amd import config as nvcfg
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.synthetic import SyntheticEpisodes
+    from navillm_amd.losses import CrossEntropyLoss
+    cfg = nvcfg.vicuna_7b(image_feat_size=768, num_layers=2)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=0)
+    m.eval()
+    crit = CrossEntropyLoss()
+    B, res = 8, {}
+    for pack in (True, False):
+        m.pack_rows = pack
+        m.zero_grad()
+        ep = SyntheticEpisodes(cfg, B, seed=1234, instr_len=512, device=torch.device(DEV))
+        for b in range(B):
+            ep.instr[b] = ep.instr[b][: 512 - 9 * b]
+        pin = ep.panorama_inputs()
+        pano = m("panorama", pin)
+        ep.update_maps(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+        nav = ep.nav_inputs(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+        nav["input_ids"], nav["attention_mask"] = ep.tokenise(nav, "<cls_1>")
+        torch.manual_seed(3)
+        out = m("navigation", nav)
+        (crit(out["fuse_logits"], ep.teacher_targets(nav, last=False).to(DEV)) / B).backward()
+        torch.cuda.synchronize()
+        res[pack] = (out["fuse_logits"].detach().float().cpu(), {g: t.detach().float().clone() for g, t in m.store.grad.items()})
+    lp, lf = res[True][0], res[False][0]
+    fin = torch.isfinite(lf)
+    assert torch.equal(torch.isfinite(lp), fin)
+    gap, u = (lp[fin] - lf[fin]).abs().max().item(), bf16_ulps_at_scale(lp, lf)
+    rels = {g: ((res[True][1][g] - res[False][1][g]).norm() / (res[False][1][g].norm() + 1e-20)).item() for g in ("lm", "f32")}
+    print(f"[7b width x2 layers] packed vs padded: logits {gap:.5f} = {u:.2f} bf16 ulps, grad rel {rels}")
+    assert u <= 3.0 and max(rels.values()) < 2e-2
     m.pack_rows = True
     del m
     torch.cuda.empty_cache()
@@ -517,3 +563,40 @@ def test_mixed_task_meta_steps_run_every_backward_of_the_rollout():
     torch.cuda.synchronize()
     assert np.isfinite(float(loss.detach())) and nz("lang_model.lm_head.weight") and nz("img_embeddings.mapper.weight")
     assert "out_head.0.weight" not in st.touched and not nz("out_head.0.weight")
+
+
+# ------------------------------------------------------------------------------------------------ in-kernel dropout
+def test_philox_dropout_kernel_statistics_and_backward_mask():
+    """nv_dropout_f32: keep rate, scaling, reproducibility from (seed, offset), independent streams for different offsets, and the
+    backward regenerating exactly the forward's mask (dropout masks came from torch.rand + torch elementwise ops)."""
+    from navillm_amd import ops, functions as Fn
+    n = 1 << 20
+    x = torch.ones(n, device=DEV)
+    for p in (0.1, 0.4):
+        y = ops.dropout_f32(x, p, seed=1234, offset=0)
+        keep = (y != 0)
+        rate = keep.float().mean().item()
+        assert abs(rate - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-4, (p, rate)
+        assert torch.allclose(y[keep], torch.full_like(y[keep], 1 / (1 - p)))
+        assert torch.equal(y, ops.dropout_f32(x, p, 1234, 0))                          # same key -> same mask
+        y2, y3 = ops.dropout_f32(x, p, 1234, n // 4), ops.dropout_f32(x, p, 99, 0)
+        for other in (y2, y3):                                                          # other counters / other seed: independent
+            agree = ((other != 0) == keep).float().mean().item()
+            assert abs(agree - (p * p + (1 - p) * (1 - p))) < 5e-3, agree
+        # no structure along the 4-element counter groups or in blocks
+        k4 = keep.view(-1, 4).float().mean(0)
+        assert (k4 - (1 - p)).abs().max().item() < 5e-3
+        assert (keep.view(256, -1).float().mean(1) - (1 - p)).abs().max().item() < 2e-2
+    # autograd: d(out)/dx is the same mask, regenerated in the backward
+    torch.manual_seed(7)
+    xg = torch.randn(3, 36, 768, device=DEV, requires_grad=True)
+    out = Fn.dropout(xg, 0.4, True)
+    out.backward(torch.ones_like(out))
+    assert torch.equal(xg.grad != 0, out != 0) and torch.allclose(xg.grad[out != 0], torch.full_like(xg.grad[out != 0], 1 / 0.6))
+    o2 = Fn.dropout(xg, 0.4, True)
+    assert not torch.equal(o2 != 0, out != 0)                                           # the stream advances from call to call
+    torch.manual_seed(7)
+    assert torch.equal(Fn.dropout(xg, 0.4, True) != 0, out != 0)                        # torch.manual_seed re-keys it
+    assert Fn.dropout(xg, 0.4, False) is xg and n % 4 == 0
+    t = torch.ones(1001, device=DEV)                                                    # n % 4 != 0 tail
+    assert ops.dropout_f32(t, 0.5, 1, 0).shape == t.shape
