@@ -214,6 +214,25 @@ int nv_nav_match_tables(const int* gmap_ids, const unsigned char* gmap_visited, 
 int nv_nav_perm_tables(const unsigned char* cand_mask, const long* perm, const int* perm_off, int B, int G, int* sel, int* inv_sel,
                        long* col);
 
+/* ---- the inference-time decoder stack as one native call (navillm_amd/csrc/decoder_runtime.cpp): a
+ *      table of layer pointers (bf16 operands or weight-only fp8 codes + scales, norms, the layer's K/V cache) and one entry
+ *      point that enqueues every launch of a K/V-reuse / decode step on `stream`, intermediates carved from `workspace`.
+ *      Counterpart: HF LlamaModel.forward with past_key_values, reached from models/modified_lm.py:184-199. */
+typedef struct nv_decoder nv_decoder;
+nv_decoder* nv_decoder_create(int L, int d, int H, int head_dim, int ff, float eps);
+void nv_decoder_destroy(nv_decoder* p);
+/*   kind: 0 q|k|v [3d,d], 1 o [d,d], 2 gate|up [2ff,d], 3 down [d,ff]; either w (bf16) or codes + scales (e4m3fn, per output channel) */
+int nv_decoder_set_weight(nv_decoder* p, int layer, int kind, const void* w, const void* codes, const float* scales);
+int nv_decoder_set_layer(nv_decoder* p, int layer, const void* input_norm, const void* post_attn_norm, void* kv_cache);
+int nv_decoder_set_shared(nv_decoder* p, const void* rope_cos, const void* rope_sin, const void* final_norm, void* gemm_workspace,
+                          void* fp8_scratch);
+size_t nv_decoder_workspace_bytes(const nv_decoder* p, int max_rows);
+/*   x_in [M,d] new-row embeddings; pos/crow/grow [M] (position, cache row written, cache row read back); kv0 [B] zeros; attn_buf
+ *   [B*cap,d]; lse [B,H,cap]; last [B] -> hs_out [B,d] final-norm hidden states of those block rows; hs_all optional [M,d] */
+int nv_decoder_extend(const nv_decoder* p, const void* x_in, const int* pos, const int* crow, const int* grow, const int* kv0,
+                      void* attn_buf, float* lse, const int* last, void* hs_out, void* hs_all, int M, int B, int Lmax, int cap,
+                      int q_row_min, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- data-parallel exchange over RCCL (C0-C3): replaces the DDP gradient all-reduce behind tools/optims.py:52-54
  *      (+ its initial parameter broadcast) and the task-id broadcast of tasks/loaders.py:176-179.
  *      One communicator per process/GPU; RCCL is bound at run time (the copy torch loaded, else /opt/rocm's).

@@ -1,0 +1,153 @@
+// nv_decoder_*: the inference-time decoder stack as ONE native call ("runtime in native code").
+//
+// A K/V-reuse navigation step or a decode step of generation pushes a few new token rows through all L decoder layers:
+// 9 kernel launches per layer.  Driven from Python that is ~290 ctypes calls + as many tensor allocations per step, and the
+// host -- not the GPU -- set the pace (262 nav-steps/s in round 1 for ~800 new rows).  Here the layer loop lives in C++:
+// one call walks a table of layer pointers and enqueues every launch of the step on the given stream, with all intermediates
+// carved from one caller-provided workspace.  The kernels are the same C-ABI entry points the training path uses
+// (nv_rmsnorm_fwd_bf16, nv_gemm_bf16_ws / nv_gemv_bf16, nv_rope_rows_bf16, nv_scatter/gather_rows_bf16,
+// nv_attn_fwd_strided_bf16, nv_swiglu_fwd_bf16) plus the weight-only fp8 pair (nv_fp8_dequant_rows + GEMM, nv_gemv_fp8w).
+// Reference counterpart: HF LlamaModel.forward with past_key_values, reached from models/modified_lm.py:184-199 (generation)
+// -- the per-step prompt recompute of tasks/agents/mp3d_agent.py:726 has no cache at all.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/navillm_hip.h"
+
+namespace {
+
+struct Layer {
+    const void *norm1 = nullptr, *norm2 = nullptr;
+    const void* w[4] = {nullptr, nullptr, nullptr, nullptr};        // bf16 operands: qkv [3d,d], o [d,d], gate|up [2ff,d], down [d,ff]
+    const void* q[4] = {nullptr, nullptr, nullptr, nullptr};        // or e4m3fn codes ...
+    const float* s[4] = {nullptr, nullptr, nullptr, nullptr};       // ... + per-output-channel scales
+    void* kv = nullptr;                                             // this layer's packed post-RoPE qkv cache [B*cap + 1, 3d]
+};
+
+inline size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+struct nv_decoder {
+    int L, d, H, hd, ff;
+    float eps;
+    std::vector<Layer> layers;
+    const void *rope_cos = nullptr, *rope_sin = nullptr, *final_norm = nullptr;
+    void* gemm_ws = nullptr;        // zero-filled split-K workspace of nv_gemm_bf16_ws (may be NULL)
+    void* fp8_scratch = nullptr;    // bf16 panel for de-quantised operands (needed when a layer carries codes)
+};
+
+extern "C" {
+
+nv_decoder* nv_decoder_create(int L, int d, int H, int head_dim, int ff, float eps) {
+    if (L <= 0 || d <= 0 || H <= 0 || head_dim != 128 || H * head_dim != d || ff <= 0) return nullptr;
+    nv_decoder* p = new (std::nothrow) nv_decoder();
+    if (!p) return nullptr;
+    p->L = L; p->d = d; p->H = H; p->hd = head_dim; p->ff = ff; p->eps = eps;
+    p->layers.resize(L);
+    return p;
+}
+
+void nv_decoder_destroy(nv_decoder* p) { delete p; }
+
+// weights of layer i.  kind: 0 qkv, 1 o, 2 gate|up, 3 down.  Either `w` (bf16 [N,K]) or `codes` + `scales` (weight-only fp8).
+int nv_decoder_set_weight(nv_decoder* p, int i, int kind, const void* w, const void* codes, const float* scales) {
+    if (!p || i < 0 || i >= p->L || kind < 0 || kind > 3) return NV_ERR_ARG;
+    if (!w && !(codes && scales)) return NV_ERR_ARG;
+    p->layers[i].w[kind] = w; p->layers[i].q[kind] = codes; p->layers[i].s[kind] = scales;
+    return NV_OK;
+}
+
+int nv_decoder_set_layer(nv_decoder* p, int i, const void* input_norm, const void* post_attn_norm, void* kv_cache) {
+    if (!p || i < 0 || i >= p->L || !input_norm || !post_attn_norm || !kv_cache) return NV_ERR_ARG;
+    p->layers[i].norm1 = input_norm; p->layers[i].norm2 = post_attn_norm; p->layers[i].kv = kv_cache;
+    return NV_OK;
+}
+
+int nv_decoder_set_shared(nv_decoder* p, const void* rope_cos, const void* rope_sin, const void* final_norm, void* gemm_workspace,
+                          void* fp8_scratch) {
+    if (!p || !rope_cos || !rope_sin || !final_norm) return NV_ERR_ARG;
+    p->rope_cos = rope_cos; p->rope_sin = rope_sin; p->final_norm = final_norm; p->gemm_ws = gemm_workspace; p->fp8_scratch = fp8_scratch;
+    return NV_OK;
+}
+
+// bytes of workspace for steps of up to max_rows new token rows
+size_t nv_decoder_workspace_bytes(const nv_decoder* p, int max_rows) {
+    if (!p || max_rows <= 0) return 0;
+    const size_t M = (size_t)max_rows, d = p->d, ff = p->ff;
+    // n | attn | x1 | out0 | out1 : [M,d] each;  qkv [M,3d];  gu [M,2ff];  h [M,ff];  rstd [M] fp32
+    return align_up(M * d * 2) * 5 + align_up(M * 3 * d * 2) + align_up(M * 2 * ff * 2) + align_up(M * ff * 2) + align_up(M * 4) + 256;
+}
+
+static int linear(const nv_decoder* p, const Layer& ly, int kind, const void* x, void* out, const void* R, int M, int N, int K,
+                  void* stream) {
+    const int epi = R ? 2 : 0;                                       // residual add or plain store
+    if (ly.q[kind]) {
+        if (M <= 16 && (K & 63) == 0) return nv_gemv_fp8w(x, ly.q[kind], ly.s[kind], out, R, M, N, K, K, K, N, N, epi, stream);
+        if (!p->fp8_scratch) return NV_ERR_ARG;
+        int rc = nv_fp8_dequant_rows(ly.q[kind], ly.s[kind], p->fp8_scratch, N, K, K, K, stream);
+        if (rc) return rc;
+        return nv_gemm_bf16_ws(0, x, p->fp8_scratch, out, R, M, N, K, K, K, N, N, epi, 0, p->gemm_ws, stream);
+    }
+    if (M <= 16 && (K & 31) == 0) return nv_gemv_bf16(x, ly.w[kind], out, R, M, N, K, K, K, N, N, epi, stream);
+    return nv_gemm_bf16_ws(0, x, ly.w[kind], out, R, M, N, K, K, K, N, N, epi, 0, p->gemm_ws, stream);
+}
+
+// One incremental step over the K/V cache (navillm_amd/kvcache.py::KVCacheLM.extend is the host side):
+//   x        [M, d] bf16   embeddings of the new rows (block layout: sample b owns rows b*N .. b*N+N-1, padded rows allowed)
+//   pos      [M] int32     position of every row;  crow [M]: cache row it is scattered to (a junk row for padding);
+//   grow     [M] int32     cache row whose attention output it reads back
+//   kv0      [B] int32     zeros (samples are left-aligned in the cache);  attn_buf [B*cap, d] bf16, lse [B, H, cap] fp32
+//   last     [B] int32     block row of each sample's last token -> hs_out [B, d] = final-norm hidden state of those rows
+//   hs_all   optional [M, d]: final-norm hidden states of ALL block rows (generation reads none; tests may)
+int nv_decoder_extend(const nv_decoder* p, const void* x_in, const int* pos, const int* crow, const int* grow, const int* kv0,
+                      void* attn_buf, float* lse, const int* last, void* hs_out, void* hs_all, int M, int B, int Lmax, int cap,
+                      int q_row_min, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p || !x_in || !pos || !crow || !grow || !kv0 || !attn_buf || !lse || !workspace || M <= 0 || B <= 0) return NV_ERR_ARG;
+    if ((last == nullptr) != (hs_out == nullptr)) return NV_ERR_ARG;
+    if (workspace_bytes < nv_decoder_workspace_bytes(p, M)) return NV_ERR_ARG;
+    const size_t d = p->d, ff = p->ff, Ms = (size_t)M;
+    char* w = (char*)workspace;
+    auto carve = [&](size_t bytes) { void* r = w; w += align_up(bytes); return r; };
+    void* n = carve(Ms * d * 2);
+    void* attn = carve(Ms * d * 2);
+    void* x1 = carve(Ms * d * 2);
+    void* outb[2] = {carve(Ms * d * 2), carve(Ms * d * 2)};           // layer outputs alternate between the two
+    void* qkv = carve(Ms * 3 * d * 2);
+    void* gu = carve(Ms * 2 * ff * 2);
+    void* h = carve(Ms * ff * 2);
+    float* rstd = (float*)carve(Ms * 4);
+    const void* x = x_in;
+    int rc = NV_OK;
+#define NV_TRY(call) do { rc = (call); if (rc != NV_OK) return rc; } while (0)
+    for (int i = 0; i < p->L; ++i) {
+        const Layer& ly = p->layers[i];
+        if (!ly.norm1 || !ly.norm2 || !ly.kv) return NV_ERR_ARG;
+        void* x2 = outb[i & 1];                                       // != x (the previous layer wrote the other one) and != x1
+        NV_TRY(nv_rmsnorm_fwd_bf16(x, ly.norm1, n, rstd, M, (int)d, p->eps, stream));
+        NV_TRY(linear(p, ly, 0, n, qkv, nullptr, M, 3 * (int)d, (int)d, stream));
+        NV_TRY(nv_rope_rows_bf16(qkv, p->rope_cos, p->rope_sin, pos, M, p->H, p->hd, 3 * (int)d, stream));
+        NV_TRY(nv_scatter_rows_bf16(qkv, crow, ly.kv, M, 3 * (int)d, stream));
+        NV_TRY(nv_attn_fwd_strided_bf16(ly.kv, attn_buf, lse, kv0, B, Lmax, cap, p->H, p->hd, q_row_min, stream));
+        NV_TRY(nv_gather_rows_bf16(attn_buf, grow, attn, M, (int)d, stream));
+        NV_TRY(linear(p, ly, 1, attn, x1, x, M, (int)d, (int)d, stream));                    // x1 = x + o_proj(attn)
+        NV_TRY(nv_rmsnorm_fwd_bf16(x1, ly.norm2, n, rstd, M, (int)d, p->eps, stream));
+        NV_TRY(linear(p, ly, 2, n, gu, nullptr, M, 2 * (int)ff, (int)d, stream));
+        NV_TRY(nv_swiglu_fwd_bf16(gu, h, M, (int)ff, stream));
+        NV_TRY(linear(p, ly, 3, h, x2, x1, M, (int)d, (int)ff, stream));                     // x2 = x1 + down(h)
+        x = x2;
+    }
+    if (hs_all) NV_TRY(nv_rmsnorm_fwd_bf16(x, p->final_norm, hs_all, rstd, M, (int)d, p->eps, stream));
+    if (hs_out) {
+        NV_TRY(nv_gather_rows_bf16(x, last, n, B, (int)d, stream));
+        NV_TRY(nv_rmsnorm_fwd_bf16(n, p->final_norm, hs_out, rstd, B, (int)d, p->eps, stream));
+    }
+#undef NV_TRY
+    return NV_OK;
+}
+
+}  // extern "C"

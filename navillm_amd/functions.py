@@ -165,23 +165,13 @@ class DropoutF32(torch.autograd.Function):
         return ops.dropout_f32(_c(g), *ctx.key), None, None, None
 
 
-class _DropoutStream:
-    """Philox counter space of this process: seeded from torch's seed (so `torch.manual_seed` controls it), every call takes
-    the next ceil(n/4) counters."""
-
-    def __init__(self):
-        self.seed, self.offset = None, 0
-
-    def take(self, n):
-        s = torch.initial_seed()
-        if s != self.seed:
-            self.seed, self.offset = s, 0
-        o = self.offset
-        self.offset += (n + 3) // 4
-        return self.seed, o
-
-
-_drop_stream = _DropoutStream()
+def _philox_take(device, n):
+    """(seed, offset) for n draws from torch's own CUDA generator state, advanced like a torch kernel would (Philox counter
+    space in units of 4 draws): `torch.manual_seed` re-keys and rewinds it, exactly as it does for torch's dropout."""
+    g = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+    off = g.get_offset()
+    g.set_offset(off + 4 * ((n + 3) // 4))
+    return g.initial_seed(), off // 4
 
 
 def dropout(x, p, training, mask=None):
@@ -190,7 +180,7 @@ def dropout(x, p, training, mask=None):
         return x
     if mask is not None:
         return MulMaskF32.apply(x, mask.to(torch.float32) * (1.0 / (1.0 - p)))
-    seed, off = _drop_stream.take(x.numel())
+    seed, off = _philox_take(x.device, x.numel())
     return DropoutF32.apply(x, p, seed, off)
 
 

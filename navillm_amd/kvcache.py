@@ -19,8 +19,12 @@ agree up to bf16 rounding of the rotated q/k (tests/test_kvcache_gpu.py bounds i
 Everything arithmetic is a launch of the same HIP kernels as the training path (plus `nv_rope_rows_bf16` and
 `nv_attn_fwd_strided_bf16`); there is no autograd here.
 """
+import ctypes
+
+import numpy as np
 import torch
 
+from . import lib as _lib
 from . import ops
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
@@ -37,24 +41,70 @@ class KVCacheLM:
         self.attn = torch.zeros((batch_size * capacity, d), dtype=BF16, device=dev)
         self.lse = torch.empty((batch_size, cfg.num_heads, capacity), dtype=F32, device=dev)
         self.kv0 = torch.zeros((batch_size,), dtype=I32, device=dev)
+        self._dec, self._dec_key, self._ws = None, None, None
+        self._key_ids = {}                                     # reuse key (hashable) -> small int
         self.reset()
+
+    def __del__(self):
+        d, self._dec = getattr(self, "_dec", None), None
+        if d:
+            try:
+                ops._L().nv_decoder_destroy(d)
+            except Exception:
+                pass
 
     def reset(self, b=None):
         """forget the cached tokens (of sample b, or of every sample) -- e.g. at an episode boundary"""
+        empty = (np.zeros(0, np.int64), np.zeros(0, np.int64))
         if b is None:
-            self.ids = [[] for _ in range(self.B)]
-            self.keys = [[] for _ in range(self.B)]
+            self.state = [empty for _ in range(self.B)]
+            self._key_ids.clear()
         else:
-            self.ids[b], self.keys[b] = [], []
+            self.state[b] = empty
 
-    # ------------------------------------------------------------------
-    def _common_prefix(self, b, ids, keys):
-        old_i, old_k = self.ids[b], self.keys[b]
-        n = min(len(old_i), len(ids) - 1)                      # keep >= 1 new token: its hidden state is the output
-        j = 0
-        while j < n and old_i[j] == ids[j] and old_k[j] == keys[j] and keys[j] is not False:
-            j += 1
-        return j
+    # compatibility views (tests / callers read the cached ids)
+    @property
+    def ids(self):
+        return [s[0].tolist() for s in self.state]
+
+    # ------------------------------------------------------------------ the native layer loop (navillm_amd/csrc/decoder_runtime.cpp)
+    def _decoder(self):
+        m, cfg, st = self.model, self.model.cfg, self.model.store
+        key = (id(m.fp8), ops._st())
+        if self._dec is not None and self._dec_key == key:
+            return self._dec
+        L = ops._L()
+        if self._dec is not None:
+            L.nv_decoder_destroy(self._dec)
+        dec = ctypes.c_void_p(L.nv_decoder_create(cfg.num_layers, cfg.hidden_size, cfg.num_heads, cfg.head_dim, cfg.intermediate_size,
+                                                  cfg.rms_norm_eps))
+        if not dec:
+            raise _lib.NaviLLMHipError("nv_decoder_create failed")
+        kinds = ("qkv", "o", "gate_up", "down")
+        for i in range(cfg.num_layers):
+            p = f"lang_model.model.layers.{i}."
+            _lib.check(L.nv_decoder_set_layer(dec, i, st.p(p + "input_layernorm.weight").data_ptr(),
+                                              st.p(p + "post_attention_layernorm.weight").data_ptr(), self.qkv[i].data_ptr()), "nv_decoder_set_layer")
+            for k, kind in enumerate(kinds):
+                if m.fp8 is not None:
+                    rc = L.nv_decoder_set_weight(dec, i, k, None, m.fp8.codes[i][kind].data_ptr(), m.fp8.scales[i][kind].data_ptr())
+                else:
+                    rc = L.nv_decoder_set_weight(dec, i, k, m.lm_w(i, kind).data_ptr(), None, None)
+                _lib.check(rc, "nv_decoder_set_weight")
+        scratch = m.fp8._scratch.data_ptr() if m.fp8 is not None else None
+        _lib.check(L.nv_decoder_set_shared(dec, m.rope_cos.data_ptr(), m.rope_sin.data_ptr(), st.p("lang_model.model.norm.weight").data_ptr(),
+                                           ops._gemm_ws(m.device) if ops.SPLITK_TAIL else None, scratch), "nv_decoder_set_shared")
+        self._dec, self._dec_key = dec, key
+        return dec
+
+    def _key_codes(self, vis_idx, vis_keys):
+        """per-token reuse code: 0 = plain token, -1 = visual row that must be recomputed, > 0 = interned key of a constant row"""
+        codes = np.zeros(len(vis_idx), dtype=np.int64)
+        for j, r in enumerate(vis_idx):
+            if r >= 0:
+                k = False if vis_keys is None else vis_keys[r]
+                codes[j] = -1 if k is False else self._key_ids.setdefault(k, len(self._key_ids) + 1)
+        return codes
 
     @torch.no_grad()
     def extend(self, ids_list, vis_idx_list=None, vis_all=None, vis_keys=None, return_rows="last"):
@@ -64,68 +114,69 @@ class KVCacheLM:
         vis_idx_list[b][j] = row of `vis_all` ([R, d] fp32, device) added to token j's embedding, or -1;
         vis_keys[r] identifies row r across calls: equal keys = the same constant embedding (a `<hist>` token of an
         earlier step), `False` = never reusable (candidates change every step).  Tokens are reused from the cache while
-        ids and keys match; the rest is recomputed."""
+        ids and keys match; the rest is recomputed.  The decoder layers run as ONE native call (nv_decoder_extend)."""
         m, cfg = self.model, self.model.cfg
         st, dev = m.store, m.device
-        B, cap, H, hd, d, eps = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.hidden_size, cfg.rms_norm_eps
+        B, cap, H, d = self.B, self.cap, cfg.num_heads, cfg.hidden_size
         assert len(ids_list) == B
-        keys_list = []
+        new_state, P, n = [], [], []
         for b in range(B):
-            L = len(ids_list[b])
-            assert 0 < L <= cap, f"prompt of {L} tokens does not fit the cache capacity {cap}"
-            if vis_idx_list is None:
-                keys_list.append([None] * L)
-            else:
-                keys_list.append([None if r < 0 else (False if vis_keys is None else vis_keys[r]) for r in vis_idx_list[b]])
-        P = [self._common_prefix(b, ids_list[b], keys_list[b]) for b in range(B)]
-        n = [len(ids_list[b]) - P[b] for b in range(B)]
+            ids = np.asarray(ids_list[b], dtype=np.int64)
+            Lb = ids.size
+            assert 0 < Lb <= cap, f"prompt of {Lb} tokens does not fit the cache capacity {cap}"
+            codes = np.zeros(Lb, np.int64) if vis_idx_list is None else self._key_codes(vis_idx_list[b], vis_keys)
+            old_i, old_c = self.state[b]
+            k = min(old_i.size, Lb - 1)                        # keep >= 1 new token: its hidden state is the output
+            diff = np.flatnonzero((old_i[:k] != ids[:k]) | (old_c[:k] != codes[:k]) | (codes[:k] < 0))
+            P.append(int(diff[0]) if diff.size else k)
+            n.append(Lb - P[-1])
+            new_state.append((ids, codes))
         N = max(n)
         M = B * N
         junk = B * cap
-        ids_new = torch.full((M,), cfg.pad_token_id, dtype=I32)
-        vix_new = torch.full((M,), -1, dtype=I32)
-        pos_new = torch.zeros((M,), dtype=I32)
-        crow = torch.full((M,), junk, dtype=I32)               # cache row each block row scatters to
-        grow = torch.zeros((M,), dtype=I32)                    # cache row each block row gathers its attention output from
-        last = torch.zeros((B,), dtype=I32)
+        ids_new = np.full(M, cfg.pad_token_id, np.int32)
+        vix_new = np.full(M, -1, np.int32)
+        pos_new = np.zeros(M, np.int32)
+        crow = np.full(M, junk, np.int32)                      # cache row each block row scatters to
+        grow = np.zeros(M, np.int32)                           # cache row each block row gathers its attention output from
+        last = np.zeros(B, np.int32)
         for b in range(B):
             s, e = b * N, b * N + n[b]
-            ids_new[s:e] = torch.tensor(ids_list[b][P[b]:], dtype=I32)
+            ids_new[s:e] = new_state[b][0][P[b]:]
             if vis_idx_list is not None:
-                vix_new[s:e] = torch.tensor(vis_idx_list[b][P[b]:], dtype=I32)
-            ar = torch.arange(P[b], P[b] + n[b], dtype=I32)
+                vix_new[s:e] = vis_idx_list[b][P[b]:]
+            ar = np.arange(P[b], P[b] + n[b], dtype=np.int32)
             pos_new[s:e] = ar
             crow[s:e] = b * cap + ar
             grow[s:e] = b * cap + ar
             grow[e:b * N + N] = b * cap
             last[b] = e - 1
-        ids_d, vix_d, pos_d, crow_d, grow_d, last_d = (ops.h2d(t, dev) for t in (ids_new, vix_new, pos_new, crow, grow, last))
-        Lmax = max(len(x) for x in ids_list)
+        # one pinned staging buffer, one H2D copy for all six index arrays
+        packed = np.concatenate([ids_new, vix_new, pos_new, crow, grow, last])
+        idx = ops.h2d(torch.from_numpy(packed), dev)
+        ids_d, vix_d, pos_d, crow_d, grow_d = (idx[k * M:(k + 1) * M] for k in range(5))
+        last_d = idx[5 * M:5 * M + B]
+        Lmax = max(s[0].size for s in new_state)
         qmin = (min(P) // 128) * 128
 
         x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_d, vix_d, vis_all)
-        for i in range(cfg.num_layers):
-            p = f"lang_model.model.layers.{i}."
-            n1, _ = ops.rmsnorm_fwd(x, st.p(p + "input_layernorm.weight"), eps)
-            qkv = m.lm_linear(n1, i, "qkv")
-            ops.rope_rows_(qkv, m.rope_cos, m.rope_sin, pos_d, H, hd)
-            ops.scatter_rows_bf16_(qkv, crow_d, self.qkv[i])
-            ops.attn_fwd_strided(self.qkv[i], self.kv0, B, Lmax, cap, H, hd, out=self.attn, lse2=self.lse, q_row_min=qmin)
-            attn = ops.gather_rows_bf16(self.attn, grow_d)
-            x1 = m.lm_linear(attn, i, "o", R=x, epilogue=ops.EPI_RESID)
-            n2, _ = ops.rmsnorm_fwd(x1, st.p(p + "post_attention_layernorm.weight"), eps)
-            gu = m.lm_linear(n2, i, "gate_up")
-            h = ops.swiglu_fwd(gu)
-            x = m.lm_linear(h, i, "down", R=x1, epilogue=ops.EPI_RESID)
-        for b in range(B):
-            self.ids[b], self.keys[b] = list(ids_list[b]), list(keys_list[b])
+        dec = self._decoder()
+        L = ops._L()
+        need = L.nv_decoder_workspace_bytes(dec, M)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        want_all = return_rows == "all"
+        hs = torch.empty((B, d), dtype=BF16, device=dev)
+        hs_all = torch.empty((M, d), dtype=BF16, device=dev) if want_all else None
+        rc = L.nv_decoder_extend(dec, x.data_ptr(), pos_d.data_ptr(), crow_d.data_ptr(), grow_d.data_ptr(), self.kv0.data_ptr(),
+                                 self.attn.data_ptr(), self.lse.data_ptr(), last_d.data_ptr(), hs.data_ptr(), ops._p(hs_all), M, B, Lmax, cap,
+                                 qmin, self._ws.data_ptr(), self._ws.numel(), ops._st())
+        _lib.check(rc, "nv_decoder_extend")
+        self.state = new_state
         self.last_stats = {"prefix": P, "new": n, "block_rows": M}
-        if return_rows == "all":
-            Hs, _ = ops.rmsnorm_fwd(x, st.p("lang_model.model.norm.weight"), eps)
-            return Hs, (N, n)
-        x_last = ops.gather_rows_bf16(x, last_d)
-        Hs, _ = ops.rmsnorm_fwd(x_last, st.p("lang_model.model.norm.weight"), eps)
-        return Hs
+        if want_all:
+            return hs_all, (N, n)
+        return hs
 
     # ------------------------------------------------------------------ generation
     @torch.no_grad()

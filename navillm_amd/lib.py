@@ -85,6 +85,14 @@ SIGNATURES = {
     "nv_graph_pos_fts": (i, [vp, i, vp, i, C.c_double, C.c_double, i, vp]),
     "nv_nav_match_tables": (i, [vp, vp, vp, i, i, i, vp, vp, vp]),
     "nv_nav_perm_tables": (i, [vp, vp, vp, i, i, vp, vp, vp]),
+    # native inference runtime (nv_decoder* travels as void*)
+    "nv_decoder_create": (vp, [i, i, i, i, i, f]),
+    "nv_decoder_destroy": (None, [vp]),
+    "nv_decoder_set_weight": (i, [vp, i, i, vp, vp, fp]),
+    "nv_decoder_set_layer": (i, [vp, i, vp, vp, vp]),
+    "nv_decoder_set_shared": (i, [vp, vp, vp, vp, vp, vp]),
+    "nv_decoder_workspace_bytes": (sz, [vp, i]),
+    "nv_decoder_extend": (i, [vp, vp, ip, ip, ip, ip, vp, fp, ip, vp, vp, i, i, i, i, i, vp, sz, vp]),
     # data-parallel exchange over RCCL (nv_ctx* travels as void*)
     "nv_comm_unique_id_bytes": (i, []),
     "nv_comm_unique_id": (i, [vp]),

@@ -156,9 +156,13 @@ class GradSlices:
         return self.layer + self.rest
 
 
-class NavDataParallel(torch.nn.Module):
+class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
+    """Subclasses DistributedDataParallel ONLY so that the reference's `isinstance(model, DistributedDataParallel)` checks
+    (tasks/agents/mp3d_agent.py:661; tools/optims.py:66-67 reads `.module`) accept it unchanged; DDP's constructor, reducer and
+    buckets are never built -- the state is a plain nn.Module's plus what is set below."""
+
     def __init__(self, module, group=None, overlap=True, comm=None, force_sync=False, reduce=None, algo=None):
-        super().__init__()
+        torch.nn.Module.__init__(self)
         self.module = module
         self.group = group
         on_gpu = module.store.device.type == "cuda"

@@ -71,6 +71,8 @@ def _worker(rank, world, port, q):
     ddp.train(); ddp.eval(); model.train(); model.eval()
     ddp.state_dict(); model.state_dict()
     ok &= model._dp is ddp and "_dp" not in dict(model.named_children())
+    # the reference's own type check (mp3d_agent.py:661) accepts the wrapper unchanged
+    ok &= isinstance(ddp, torch.nn.parallel.DistributedDataParallel) and ddp.module is model
     st = model.store
     x = torch.ones(1, requires_grad=True)
     mean_rank = sum(r_ + 1 for r_ in range(world)) / world          # mean of (rank+1)

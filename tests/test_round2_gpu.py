@@ -586,7 +586,7 @@ def test_philox_dropout_kernel_statistics_and_backward_mask():
         # no structure along the 4-element counter groups or in blocks
         k4 = keep.view(-1, 4).float().mean(0)
         assert (k4 - (1 - p)).abs().max().item() < 5e-3
-        assert (keep.view(256, -1).float().mean(1) - (1 - p)).abs().max().item() < 2e-2
+        assert (keep.view(256, -1).float().mean(1) - (1 - p)).abs().max().item() < 3.5e-2     # 4096 draws per block: sigma 0.008
     # autograd: d(out)/dx is the same mask, regenerated in the backward
     torch.manual_seed(7)
     xg = torch.randn(3, 36, 768, device=DEV, requires_grad=True)
