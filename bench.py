@@ -104,12 +104,14 @@ class GemmTimer:
 def gemm_traffic_from_profile():
     """HBM bytes per forward-GEMM launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2
     per the gfx950 correction + WRITE_SIZE; separate --pmc runs of this same command); None if absent."""
-    pth = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-    try:
-        with open(pth) as f:
-            return json.load(f)["hbm_bytes_per_forward_gemm_launch"]
-    except Exception:
-        return None
+    for name in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            return d.get("hbm_bytes_per_gemm_launch_all_layouts", d["hbm_bytes_per_forward_gemm_launch"])
+        except Exception:
+            continue
+    return None
 
 
 def inference_extras(a, model, wrapped, crit, ep):
@@ -308,6 +310,24 @@ def fp8_13b_extra(a, device, seed):
     return out
 
 
+def usable_cpus():
+    """CPUs this process may actually use: min(cpu_count, affinity mask, cgroup quota).  The MI355X boxes show 256 hardware
+    threads but a cgroup quota of 16 CPUs (cpu.max = 1600000/100000): 256 torch threads then spend their time throttled --
+    the same two oracle layers took 36 s with 256 threads and 0.7 s with 32 (tools/cpu_probe.py, profiles/r02_cpu_probe.txt)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(a, cfg, seed):
     """The oracle (CPU restatement, kind='port') timed on this box's host cores on a bounded sample:
     ONE episode, ONE nav step, forward + backward, with 8 of the 32 decoder layers (the LM is 99.9% of
@@ -319,9 +339,9 @@ def cpu_baseline(a, cfg, seed):
     spec = importlib.util.spec_from_file_location("navillm_oracle", os.path.join(ROOT, "oracle", "navillm_oracle.py"))
     O = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(O)
-    Ls = min(8, cfg.num_layers)
+    Ls = min(16, cfg.num_layers)
     c = NavConfig(**{**cfg.__dict__, "num_layers": Ls})
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     torch.set_num_threads(cores)
     P = {k: v.requires_grad_(True) for k, v in synth_state_dict(c, seed).items()}
     ep = SyntheticEpisodes(c, 1, seed=seed, instr_len=a.instr_len, device=torch.device("cpu"))
@@ -347,7 +367,7 @@ def cpu_baseline(a, cfg, seed):
     return {"value": 1.0 / scaled, "unit": "nav-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle/navillm_oracle.py, 1 episode x 1 nav step, forward+backward, S={ids.shape[1]}, "
                       f"{Ls} of {cfg.num_layers} decoder layers timed ({dt:.1f} s) and scaled linearly in layers; "
-                      f"torch CPU bf16, {cores} threads"}
+                      f"torch CPU bf16, {cores} threads = the CPUs this container may use (cpu_count {os.cpu_count()}, cgroup quota applied)"}
 
 
 def relaunch_one_rank_per_gpu(a):
@@ -388,7 +408,7 @@ def main():
     # Host threads for torch's CPU-side glue ops (masks, index lists): a handful.  With the default (all 256 hardware
     # threads) a barrier of the intra-op pool now and then takes 80-100 ms on a tiny tensor (tools/pack_probe.py), longer
     # than a whole forward; and with one process per GPU the ranks must share the host anyway.  (cpu_baseline sets its own.)
-    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))
+    torch.set_num_threads(max(1, min(16, usable_cpus() // max(world, 1))))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: the line would not describe the job that ran")
     from navillm_amd import ops
@@ -469,15 +489,13 @@ def main():
         model.train()
     cpu_line = None
     if rank == 0 and not a.no_cpu_baseline and world == 1:
-        # BEFORE the extras: measured after them the same oracle step took 150-160 s instead of 9 s (cause not isolated: the long extra
-        # episodes leave many pinned staging buffers and helper threads behind)
         phase("cpu baseline")
         try:
             cpu_line = cpu_baseline(a, cfg, 1234)
         except Exception as e:  # the baseline must never take the GPU number down with it
             cpu_line = {"value": None, "unit": "nav-steps/s", "cores": os.cpu_count(), "kind": "port",
                         "sample": f"failed: {type(e).__name__}: {e}"}
-        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))
+        torch.set_num_threads(max(1, min(16, usable_cpus() // max(world, 1))))
     extras = {}
     if not a.no_extras and a.model != "tiny":
         for name, fn in (("mixed_task_training_config3", lambda: mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed + 100)),
@@ -541,7 +559,8 @@ def main():
                                 "gemm_share_of_step": round(allg["gemm_seconds"] / dt, 3),
                                 "note": "peak = nominal dense bf16 MFMA; with N(0,1) operands the MFMA pipe of this part sustains "
                                         "1.87-2.0 PFLOP/s (power-limited clock; tools/ubench/mix_rate.hip, DESIGN.md §4); "
-                                        "traffic = 2*FETCH_SIZE+WRITE_SIZE per forward launch from the PMC passes in profiles/"}
+                                        "traffic = 2*FETCH_SIZE+WRITE_SIZE per launch, averaged over the same launches as `achieved`, from the separate "
+                                        "rocprofv3 --pmc passes of this command committed under profiles/ (r02_gemm_pmc_traffic.txt)"}
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         phase("done")

@@ -12,6 +12,7 @@
 //                            v_cvt_pk_f32_fp8 -- gfx950 decodes OCP e4m3fn -- then v_cvt_pk_bf16_f32)
 // nv_fp8_decode_table exposes the in-register decode for all 256 codes so a test can pin it against torch.float8_e4m3fn.
 #include "nv_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -121,9 +122,8 @@ __global__ void fp8_decode_table_kernel(bf16_t* __restrict__ out) {
 // Semantics = the de-quantised weight bf16(s[n] * q[n,k]) exactly as nv_fp8_dequant_rows writes it (lane (n, kg) always works on row
 // n, so s[n] is a per-lane constant multiplied in before the bf16 pack): decode and prefill see the same weights.
 constexpr int GF_WAVES = 8;
-constexpr int GF_UNROLL = 4;
 
-template <bool RESID>
+template <bool RESID, int GF_UNROLL>
 __global__ __launch_bounds__(GF_WAVES * 64) void gemv_fp8w_kernel(const bf16_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                                   const float* __restrict__ S, bf16_t* __restrict__ C,
                                                                   const bf16_t* __restrict__ R, int M, int N, int K, int lda, int ldw,
@@ -236,12 +236,12 @@ int nv_gemv_fp8w(const void* A, const void* Wq, const float* scales, void* C, co
     if (epilogue == 2 && !R) return NV_ERR_ARG;
     const dim3 grid((N + 15) / 16), block(GF_WAVES * 64);
     hipStream_t st = (hipStream_t)stream;
-    if (epilogue == 2)
-        NV_LAUNCH(gemv_fp8w_kernel<true>, grid, block, 0, st, (const bf16_t*)A, (const uint8_t*)Wq, scales, (bf16_t*)C, (const bf16_t*)R, M,
-                  N, K, lda, ldw, ldc, ldr);
-    else
-        NV_LAUNCH(gemv_fp8w_kernel<false>, grid, block, 0, st, (const bf16_t*)A, (const uint8_t*)Wq, scales, (bf16_t*)C,
-                  (const bf16_t*)nullptr, M, N, K, lda, ldw, ldc, ldr);
+    static const int unroll = [] { const char* e = getenv("NV_GEMV_FP8_UNROLL"); return e ? atoi(e) : 8; }();   // measurement knob
+#define NV_GF(RES, U) NV_LAUNCH((gemv_fp8w_kernel<RES, U>), grid, block, 0, st, (const bf16_t*)A, (const uint8_t*)Wq, scales, (bf16_t*)C, \
+                                (const bf16_t*)(RES ? R : nullptr), M, N, K, lda, ldw, ldc, ldr)
+    if (epilogue == 2) { if (unroll == 4) NV_GF(true, 4); else if (unroll == 2) NV_GF(true, 2); else NV_GF(true, 8); }
+    else { if (unroll == 4) NV_GF(false, 4); else if (unroll == 2) NV_GF(false, 2); else NV_GF(false, 8); }
+#undef NV_GF
     return nv_check_launch();
 }
 

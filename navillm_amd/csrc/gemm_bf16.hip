@@ -819,7 +819,10 @@ int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
         // hand-interleaved schedule (8) in all three layouts: since its addressing moved to SGPRs/immediates the
         // wgrad (TN) instance no longer spills and beats the compiler-scheduled loop (6) by ~15%
-        tile_cfg = (t256 >= 128) ? 8 : 1;
+        // round 2 (tools/gemm_smallm.py, the few-hundred-row GEMMs of a K/V-reuse inference step): below 128 tiles the 256x256
+        // tile still wins when K is long (down_proj: K = 11008 / 13824) -- the whole launch is then a "partial round" that the
+        // split-K tail cuts into K-slices (M=800, N=4096, K=11008: 124 vs 150 us) -- and loses when K is short (o_proj: 74 vs 48 us)
+        tile_cfg = (t256 >= 128 || p.K >= 8192) ? 8 : 1;
     }
     switch (tile_cfg) {
         case 1: return launch<128, 128, 2, 2, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);

@@ -370,3 +370,22 @@ def test_navigation_index_tables_vs_reference_loops():
         assert sel.tolist() == sel_w and np.array_equal(inv_sel, inv_sel_w) and np.array_equal(col, col_w), trial
     with pytest.raises(Exception):
         graph.perm_tables(np.array([[True, True, True]]), [np.array([0, 5])])        # not a permutation
+
+
+def test_bench_refuses_an_n_gpu_line_from_fewer_devices():
+    """`python bench.py --gpus 8` silently benchmarked ONE GPU.  Without a torchrun environment it now starts the N
+    ranks itself -- and refuses outright when fewer than N GPUs are visible (here: none)."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the relaunch path would really run")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and '"n_gpus"' not in r.stdout
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    if not torch.cuda.is_available():
+        return
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

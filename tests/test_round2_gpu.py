@@ -588,8 +588,8 @@ def test_philox_dropout_kernel_statistics_and_backward_mask():
         assert (k4 - (1 - p)).abs().max().item() < 5e-3
         assert (keep.view(256, -1).float().mean(1) - (1 - p)).abs().max().item() < 3.5e-2     # 4096 draws per block: sigma 0.008
     # autograd: d(out)/dx is the same mask, regenerated in the backward
-    torch.manual_seed(7)
     xg = torch.randn(3, 36, 768, device=DEV, requires_grad=True)
+    torch.manual_seed(7)
     out = Fn.dropout(xg, 0.4, True)
     out.backward(torch.ones_like(out))
     assert torch.equal(xg.grad != 0, out != 0) and torch.allclose(xg.grad[out != 0], torch.full_like(xg.grad[out != 0], 1 / 0.6))

@@ -23,21 +23,27 @@ def per_kernel(db):
 
 fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
 lines = ["# rocprofv3 --kernel-trace --pmc FETCH_SIZE  /  --pmc WRITE_SIZE (two separate passes) of",
-         "#   python bench.py --steps 3 --warmup 0 --prewarm 1 --no-cpu-baseline --no-profile --infer-steps 0   (MI355X, round 1, final kernels)",
+         "#   python bench.py --steps 3 --warmup 0 --prewarm 1 --no-cpu-baseline --no-profile --infer-steps 0   (MI355X)",
          "# per-dispatch averages for the bf16 GEMM kernels; counters are in KiB; gfx950 correction: FETCH_SIZE reports half",
          "# of a wide coalesced stream (MI355X_MICROARCH.md §HBM) -> HBM-side bytes = 2*FETCH_SIZE + WRITE_SIZE.",
          "# FETCH_SIZE counts fabric requests of the L2s (Infinity-Cache hits included), not only HBM reads.",
          f"# {'kernel':<62} {'counter':<12} {'launches':>8} {'avg_KiB':>12}"]
 fw = {"F": [0, 0.0], "W": [0, 0.0]}
+al = {"F": [0, 0.0], "W": [0, 0.0]}
 for tag, agg in (("F", fetch), ("W", write)):
     for (k, cn), (n, tot) in sorted(agg.items()):
         lines.append(f"{k:<64} {cn:<12} {n:>8d} {tot / n:>12.1f}")
-        if re.search(r"true, true, [02], 4>", k):          # forward NT launches (store and residual epilogues)
+        if re.search(r"<256, 256, .*, 4>", k):             # the production tile, every layout and epilogue
+            al[tag][0] += n; al[tag][1] += tot
+        if re.search(r"true, true, [025], 4>", k):         # forward NT launches (store, residual and RoPE epilogues)
             fw[tag][0] += n; fw[tag][1] += tot
 f_avg, w_avg = fw["F"][1] / max(fw["F"][0], 1), fw["W"][1] / max(fw["W"][0], 1)
-total = (2 * f_avg + w_avg) * 1024
+fa_avg, wa_avg = al["F"][1] / max(al["F"][0], 1), al["W"][1] / max(al["W"][0], 1)
+total, total_all = (2 * f_avg + w_avg) * 1024, (2 * fa_avg + wa_avg) * 1024
 lines.append(f"# forward (NT) GEMM launches: avg FETCH_SIZE {f_avg:.0f} KiB, WRITE_SIZE {w_avg:.0f} KiB -> corrected traffic {total/1e9:.3f} GB per launch")
+lines.append(f"# ALL 256x256 GEMM launches (NT + NN + TN): avg FETCH_SIZE {fa_avg:.0f} KiB, WRITE_SIZE {wa_avg:.0f} KiB -> corrected traffic {total_all/1e9:.3f} GB per launch")
 open(sys.argv[3], "w").write("\n".join(lines) + "\n")
-json.dump({"hbm_bytes_per_forward_gemm_launch": int(total), "fetch_kib_avg": f_avg, "write_kib_avg": w_avg,
-           "launches": fw["F"][0], "source": "profiles/r01_gemm_pmc_traffic.txt"}, open(sys.argv[4], "w"))
-print(lines[-1])
+json.dump({"hbm_bytes_per_forward_gemm_launch": int(total), "hbm_bytes_per_gemm_launch_all_layouts": int(total_all),
+           "fetch_kib_avg": f_avg, "write_kib_avg": w_avg, "launches_forward": fw["F"][0], "launches_all": al["F"][0],
+           "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 FETCH_SIZE half-count correction", "source": sys.argv[3]}, open(sys.argv[4], "w"))
+print(lines[-2]); print(lines[-1])
