@@ -121,9 +121,7 @@ __global__ void fp8_decode_table_kernel(bf16_t* __restrict__ out) {
 // of a 64-deep step and feeds TWO MFMAs (its first / second 8 codes); the x operand is loaded with the same k permutation.
 // Semantics = the de-quantised weight bf16(s[n] * q[n,k]) exactly as nv_fp8_dequant_rows writes it (lane (n, kg) always works on row
 // n, so s[n] is a per-lane constant multiplied in before the bf16 pack): decode and prefill see the same weights.
-constexpr int GF_WAVES = 8;
-
-template <bool RESID, int GF_UNROLL>
+template <bool RESID, int GF_UNROLL, int GF_WAVES>
 __global__ __launch_bounds__(GF_WAVES * 64) void gemv_fp8w_kernel(const bf16_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                                   const float* __restrict__ S, bf16_t* __restrict__ C,
                                                                   const bf16_t* __restrict__ R, int M, int N, int K, int lda, int ldw,
@@ -234,13 +232,17 @@ int nv_gemv_fp8w(const void* A, const void* Wq, const float* scales, void* C, co
     if (M > 16 || (K & 63) || (lda & 7) || (ldw & 15) || ((((uintptr_t)A) | ((uintptr_t)Wq)) & 15)) return NV_ERR_SHAPE;
     if (epilogue != 0 && epilogue != 2) return NV_ERR_ARG;
     if (epilogue == 2 && !R) return NV_ERR_ARG;
-    const dim3 grid((N + 15) / 16), block(GF_WAVES * 64);
     hipStream_t st = (hipStream_t)stream;
-    static const int unroll = [] { const char* e = getenv("NV_GEMV_FP8_UNROLL"); return e ? atoi(e) : 8; }();   // measurement knob
-#define NV_GF(RES, U) NV_LAUNCH((gemv_fp8w_kernel<RES, U>), grid, block, 0, st, (const bf16_t*)A, (const uint8_t*)Wq, scales, (bf16_t*)C, \
-                                (const bf16_t*)(RES ? R : nullptr), M, N, K, lda, ldw, ldc, ldr)
-    if (epilogue == 2) { if (unroll == 4) NV_GF(true, 4); else if (unroll == 2) NV_GF(true, 2); else NV_GF(true, 8); }
-    else { if (unroll == 4) NV_GF(false, 4); else if (unroll == 2) NV_GF(false, 2); else NV_GF(false, 8); }
+    // measurement knobs (tools/gemv_fp8_probe.py): loads in flight per lane and waves per block.  Defaults = the measured best.
+    static const int unroll = [] { const char* e = getenv("NV_GEMV_FP8_UNROLL"); return e ? atoi(e) : 4; }();
+    static const int waves = [] { const char* e = getenv("NV_GEMV_FP8_WAVES"); return e ? atoi(e) : 8; }();
+    const dim3 grid((N + 15) / 16);
+#define NV_GF(RES, U, W) NV_LAUNCH((gemv_fp8w_kernel<RES, U, W>), grid, dim3(W * 64), 0, st, (const bf16_t*)A, (const uint8_t*)Wq, scales, \
+                                   (bf16_t*)C, (const bf16_t*)(RES ? R : nullptr), M, N, K, lda, ldw, ldc, ldr)
+#define NV_GF_U(RES, W) do { if (unroll == 2) NV_GF(RES, 2, W); else if (unroll == 8) NV_GF(RES, 8, W); else NV_GF(RES, 4, W); } while (0)
+    if (epilogue == 2) { if (waves == 4) NV_GF_U(true, 4); else NV_GF_U(true, 8); }
+    else { if (waves == 4) NV_GF_U(false, 4); else NV_GF_U(false, 8); }
+#undef NV_GF_U
 #undef NV_GF
     return nv_check_launch();
 }
