@@ -121,72 +121,90 @@ __global__ void fp8_decode_table_kernel(bf16_t* __restrict__ out) {
 // of a 64-deep step and feeds TWO MFMAs (its first / second 8 codes); the x operand is loaded with the same k permutation.
 // Semantics = the de-quantised weight bf16(s[n] * q[n,k]) exactly as nv_fp8_dequant_rows writes it (lane (n, kg) always works on row
 // n, so s[n] is a per-lane constant multiplied in before the bf16 pack): decode and prefill see the same weights.
-template <bool RESID, int GF_UNROLL, int GF_WAVES>
+constexpr int GF_WAVES = 8;
+
+// NTILE column tiles per block share the x fragments (see gemv_bf16.hip): with one tile per block three 16-B loads (one of
+// codes, two of x) go through the vector-memory path per 16 B of codes and the streamer stalls at ~3 TB/s of codes; with NTILE
+// tiles it is (NTILE + 2) / NTILE.
+template <bool RESID, int NTILE>
 __global__ __launch_bounds__(GF_WAVES * 64) void gemv_fp8w_kernel(const bf16_t* __restrict__ A, const uint8_t* __restrict__ W,
                                                                   const float* __restrict__ S, bf16_t* __restrict__ C,
                                                                   const bf16_t* __restrict__ R, int M, int N, int K, int lda, int ldw,
                                                                   int ldc, int ldr) {
-    __shared__ float part[GF_WAVES][16][17];
+    constexpr int UNROLL = NTILE >= 2 ? 2 : 4;
+    __shared__ float part[GF_WAVES][NTILE * 16][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = lane & 15, kg = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * 16 * NTILE;
     const int steps = K / 64;                                     // K % 64 == 0 (checked on the host)
     const int per = (steps + GF_WAVES - 1) / GF_WAVES;
     const int s_beg = wave * per, s_end = min(steps, s_beg + per);
-    const int n = n0 + idx;
-    const bool n_ok = n < N, m_ok = idx < M;
-    const uint8_t* wp = W + (long)(n_ok ? n : N - 1) * ldw + kg * 16;
+    const bool m_ok = idx < M;
+    const uint8_t* wp[NTILE];
+    bool n_ok[NTILE];
+    float sc[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+        const int n = n0 + t * 16 + idx;
+        n_ok[t] = n < N;
+        wp[t] = W + (long)(n_ok[t] ? n : N - 1) * ldw + kg * 16;
+        sc[t] = n_ok[t] ? S[n] : 0.f;
+    }
     const bf16_t* ap = A + (long)(m_ok ? idx : 0) * lda + kg * 16;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16x8 zero = {};
-    const float sc = n_ok ? S[n] : 0.f;
-    auto step = [&](const u32x4& w, const bf16x8& a0, const bf16x8& a1) {
+    auto fma_tile = [&](int t, const u32x4& w, const bf16x8& a0, const bf16x8& a1) {
         float f[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) fp8x4_to_f32(w[j], f + 4 * j);
         u32x4 b0, b1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            b0[j] = pack2bf(f[2 * j] * sc, f[2 * j + 1] * sc);
-            b1[j] = pack2bf(f[8 + 2 * j] * sc, f[8 + 2 * j + 1] * sc);
+            b0[j] = pack2bf(f[2 * j] * sc[t], f[2 * j + 1] * sc[t]);
+            b1[j] = pack2bf(f[8 + 2 * j] * sc[t], f[8 + 2 * j + 1] * sc[t]);
         }
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b0), a0, acc, 0, 0, 0);   // D[n][m]
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b1), a1, acc, 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b0), a0, acc[t], 0, 0, 0);   // D[n][m]
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b1), a1, acc[t], 0, 0, 0);
     };
     int s = s_beg;
-    for (; s + GF_UNROLL <= s_end; s += GF_UNROLL) {
-        u32x4 wf[GF_UNROLL];
-        bf16x8 a0[GF_UNROLL], a1[GF_UNROLL];
+    for (; s + UNROLL <= s_end; s += UNROLL) {
+        u32x4 wf[UNROLL][NTILE];
+        bf16x8 a0[UNROLL], a1[UNROLL];
 #pragma unroll
-        for (int u = 0; u < GF_UNROLL; ++u) wf[u] = n_ok ? *(const u32x4*)(wp + (long)(s + u) * 64) : u32x4{0, 0, 0, 0};
+        for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-        for (int u = 0; u < GF_UNROLL; ++u) {
+            for (int t = 0; t < NTILE; ++t) wf[u][t] = n_ok[t] ? *(const u32x4*)(wp[t] + (long)(s + u) * 64) : u32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
             a0[u] = m_ok ? *(const bf16x8*)(ap + (long)(s + u) * 64) : zero;
             a1[u] = m_ok ? *(const bf16x8*)(ap + (long)(s + u) * 64 + 8) : zero;
         }
 #pragma unroll
-        for (int u = 0; u < GF_UNROLL; ++u) step(wf[u], a0[u], a1[u]);
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int t = 0; t < NTILE; ++t) fma_tile(t, wf[u][t], a0[u], a1[u]);
     }
     for (; s < s_end; ++s) {
-        const u32x4 wf = n_ok ? *(const u32x4*)(wp + (long)s * 64) : u32x4{0, 0, 0, 0};
         const bf16x8 a0 = m_ok ? *(const bf16x8*)(ap + (long)s * 64) : zero;
         const bf16x8 a1 = m_ok ? *(const bf16x8*)(ap + (long)s * 64 + 8) : zero;
-        step(wf, a0, a1);
+#pragma unroll
+        for (int t = 0; t < NTILE; ++t) fma_tile(t, n_ok[t] ? *(const u32x4*)(wp[t] + (long)s * 64) : u32x4{0, 0, 0, 0}, a0, a1);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part[wave][kg * 4 + r][idx] = acc[r];
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][t * 16 + kg * 4 + r][idx] = acc[t][r];
     __syncthreads();
-    if (wave == 0) {
+    for (int e = tid; e < NTILE * 256; e += GF_WAVES * 64) {
+        const int m = e / (NTILE * 16), nn = e % (NTILE * 16);
+        if (m < M && n0 + nn < N) {
+            float v = 0.f;
 #pragma unroll
-        for (int pss = 0; pss < 4; ++pss) {
-            const int t = pss * 64 + lane, m = t >> 4, nn = t & 15;
-            if (m < M && n0 + nn < N) {
-                float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < GF_WAVES; ++w) v += part[w][nn][m];
-                if (RESID) v = bf2f(R[(long)m * ldr + n0 + nn]) + rbf(v);     // torch: resid + bf16(x W^T)
-                C[(long)m * ldc + n0 + nn] = f2bf(v);
-            }
+            for (int w = 0; w < GF_WAVES; ++w) v += part[w][nn][m];
+            if (RESID) v = bf2f(R[(long)m * ldr + n0 + nn]) + rbf(v);     // torch: resid + bf16(x W^T)
+            C[(long)m * ldc + n0 + nn] = f2bf(v);
         }
     }
 }
@@ -233,16 +251,14 @@ int nv_gemv_fp8w(const void* A, const void* Wq, const float* scales, void* C, co
     if (epilogue != 0 && epilogue != 2) return NV_ERR_ARG;
     if (epilogue == 2 && !R) return NV_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    // measurement knobs (tools/gemv_fp8_probe.py): loads in flight per lane and waves per block.  Defaults = the measured best.
-    static const int unroll = [] { const char* e = getenv("NV_GEMV_FP8_UNROLL"); return e ? atoi(e) : 4; }();
-    static const int waves = [] { const char* e = getenv("NV_GEMV_FP8_WAVES"); return e ? atoi(e) : 8; }();
-    const dim3 grid((N + 15) / 16);
-#define NV_GF(RES, U, W) NV_LAUNCH((gemv_fp8w_kernel<RES, U, W>), grid, dim3(W * 64), 0, st, (const bf16_t*)A, (const uint8_t*)Wq, scales, \
-                                   (bf16_t*)C, (const bf16_t*)(RES ? R : nullptr), M, N, K, lda, ldw, ldc, ldr)
-#define NV_GF_U(RES, W) do { if (unroll == 2) NV_GF(RES, 2, W); else if (unroll == 8) NV_GF(RES, 8, W); else NV_GF(RES, 4, W); } while (0)
-    if (epilogue == 2) { if (waves == 4) NV_GF_U(true, 4); else NV_GF_U(true, 8); }
-    else { if (waves == 4) NV_GF_U(false, 4); else NV_GF_U(false, 8); }
-#undef NV_GF_U
+    static const int forced = [] { const char* e = getenv("NV_GEMV_NTILE"); return e ? atoi(e) : 0; }();   // measurement knob
+    // measured (profiles/r02_gemv_probe.txt): two tiles per block win by 6..27 % whenever the grid keeps >= 160 blocks
+    const int nt = (forced == 1 || forced == 2 || forced == 4) ? forced : (N >= 5120 ? 2 : 1);
+    const dim3 grid((N + 16 * nt - 1) / (16 * nt)), block(GF_WAVES * 64);
+#define NV_GF(RES, NT) NV_LAUNCH((gemv_fp8w_kernel<RES, NT>), grid, block, 0, st, (const bf16_t*)A, (const uint8_t*)Wq, scales, (bf16_t*)C, \
+                                 (const bf16_t*)(RES ? R : nullptr), M, N, K, lda, ldw, ldc, ldr)
+    if (epilogue == 2) { if (nt == 4) NV_GF(true, 4); else if (nt == 2) NV_GF(true, 2); else NV_GF(true, 1); }
+    else { if (nt == 4) NV_GF(false, 4); else if (nt == 2) NV_GF(false, 2); else NV_GF(false, 1); }
 #undef NV_GF
     return nv_check_launch();
 }

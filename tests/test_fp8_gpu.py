@@ -103,3 +103,52 @@ def test_fp8_weight_only_navigation_and_generation_vs_reference_on_dequantised_w
     # inference only
     with pytest.raises(RuntimeError, match="inference only"):
         _nav_forward(m, z3)
+
+
+def test_fp8_13b_shaped_layer_vs_fp8_oracle():
+    """BASELINE config 5's layer shape (Vicuna-13B: d=5120, 40 heads, ff=13824) with weight-only fp8, one decoder layer, B=4:
+    prefill GEMMs on the de-quantised scratch panel (20 / 54 / 108 column tiles) and the pruned-tail rows through
+    nv_gemv_fp8w -- against the oracle on de-quantised weights, in bf16 and fp32."""
+    from navillm_amd import config as nvcfg
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.params import synth_state_dict
+    from navillm_amd.synthetic import SyntheticEpisodes
+    O = load_oracle()
+    cfg = nvcfg.NavConfig(hidden_size=5120, num_layers=1, num_heads=40, intermediate_size=13824, base_vocab_size=1000,
+                          enc_hidden_size=256, enc_num_heads=4, enc_intermediate_size=512, image_feat_size=768)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=5)
+    m.eval()
+    P16 = synth_state_dict(cfg, 5)
+    with torch.no_grad():
+        assert m.load_reference_state_dict(P16) == len(P16)
+    m.to_fp8_weight_only()
+    Pq16 = O.fp8_weight_only_state_dict(P16)
+    Pq32 = {k: v.float() for k, v in Pq16.items()}
+    cfg32 = nvcfg.NavConfig(**{**cfg.__dict__, "precision": "fp32"})
+    ep = SyntheticEpisodes(cfg, 4, seed=77, instr_len=150, device=torch.device(DEV))
+    pin = ep.panorama_inputs()
+    with torch.no_grad():
+        pano = m("panorama", pin)
+    ep.update_maps(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+    nav = ep.nav_inputs(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+    ids, am = ep.tokenise(nav, "<cls_1>")
+    nav["input_ids"], nav["attention_mask"] = ids, am
+    torch.manual_seed(100)
+    with torch.no_grad():
+        out = m("navigation", nav)
+    cpu = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in nav.items()}
+    refs = {}
+    for tag, P, c in (("bf16", Pq16, cfg), ("fp32", Pq32, cfg32)):
+        torch.manual_seed(100)
+        with torch.no_grad():
+            refs[tag] = O.navigation(P, c, cpu, ids, am)["fuse_logits"]
+    torch.manual_seed(100)
+    with torch.no_grad():
+        unq = O.navigation({k: v.float() for k, v in P16.items()}, cfg32, cpu, ids, am)["fuse_logits"]
+    e_hip, e_ref = maxerr(out["fuse_logits"], refs["fp32"]), maxerr(refs["bf16"], refs["fp32"])
+    dq = maxerr(refs["fp32"], unq)
+    scale = float(refs["bf16"][torch.isfinite(refs["bf16"])].abs().max())
+    ulp = 2.0 ** (int(np.floor(np.log2(scale))) - 7)
+    print(f"[fp8 13b-layer] S={ids.shape[1]} |hip-orc32(dequant)|={e_hip:.5f} vs |orc16-orc32|={e_ref:.5f} (ratio {e_hip / e_ref:.2f}); "
+          f"quantisation itself moves the fp32 logits by {dq:.4f} (scale {scale:.2f})")
+    assert e_hip <= 1.25 * e_ref + ulp

@@ -21,7 +21,7 @@ def bench(fn, n=60):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-print("NV_GEMV_FP8_UNROLL =", os.environ.get("NV_GEMV_FP8_UNROLL", "(default)"), " NV_GEMV_FP8_WAVES =", os.environ.get("NV_GEMV_FP8_WAVES", "(default)"))
+print("NV_GEMV_NTILE =", os.environ.get("NV_GEMV_NTILE", "(auto)"))
 for d, ff in ((4096, 11008), (5120, 13824)):
     for (N, K) in ((3 * d, d), (d, d), (2 * ff, d), (d, ff)):
         nset = max(2, int(600e6 // (N * K)) + 1)
