@@ -91,6 +91,13 @@ int nv_rope_bf16(void* qkv, const void* cos_t, const void* sin_t, int M, int S, 
 /*   per-row positions pos[m] (forward only): the position_ids of HF's generation path (left-aligned per-sample frames) */
 int nv_rope_rows_bf16(void* qkv, const void* cos_t, const void* sin_t, const int* pos, int M, int H, int hd, int ld, void* stream);
 
+/*   transpose of nv_rope_rows_bf16 (backward of the per-row-position RoPE) */
+int nv_rope_rows_t_bf16(void* qkv, const void* cos_t, const void* sin_t, const int* pos, int M, int H, int hd, int ld, void* stream);
+/*   K/V gradients of a cached prompt prefix, summed over the steps of an episode in fp32 (navillm_amd/episode.py):
+ *   accum : acc[rows[i], 0..2d) += dqkv[rows[i], d..3d)        inject: dqkv[i, d..3d) += acc[rows[i], 0..2d)  (dqkv bf16 [*,3d]) */
+int nv_kv_grad_accum_f32(const void* dqkv, float* acc, const int* rows, int n, int d, void* stream);
+int nv_kv_grad_inject_bf16(void* dqkv, const float* acc, const int* rows, int n, int d, void* stream);
+
 /* ---- HF LlamaMLP activation on packed gate|up [M, 2*ff]: h = bf16(bf16(silu(g)) * u) */
 int nv_swiglu_fwd_bf16(const void* gu, void* h, int M, int ff, void* stream);
 int nv_swiglu_bwd_bf16(const void* gu, const void* dh, void* dgu, int M, int ff, void* stream);
@@ -126,6 +133,11 @@ int nv_attn_fwd_varlen_bf16(const void* qkv, void* out, float* lse2, const int* 
  *   difference in rounding points and nothing else. */
 int nv_attn_fwd_hfround_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, const int* cu, int B, int S, int H,
                              int head_dim, int q_row_min, void* stream);
+/*   backward over the K/V-cache layout of nv_attn_fwd_strided_bf16 (training with a cached prompt prefix, navillm_amd/episode.py):
+ *   queries >= q_row_min carry gradient (dO of all other rows zero), dK/dV for every key row < S, no RoPE^T;
+ *   workspace = nv_attn_bwd_workspace_bytes(B, S_stride, H) */
+int nv_attn_bwd_strided_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
+                             void* workspace, int B, int S, int S_stride, int H, int head_dim, int q_row_min, void* stream);
 int nv_attn_bwd_varlen_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* cu, const int* pos0,
                             void* dqkv, void* workspace, const void* rope_cos, const void* rope_sin, int B, int S_max, long rows,
                             int H, int head_dim, int q_row_min, void* stream);

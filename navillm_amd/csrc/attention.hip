@@ -751,7 +751,7 @@ size_t nv_attn_bwd_workspace_bytes(int B, int S, int H) { return (size_t)B * S *
 
 static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
                          void* workspace, int B, int S, int H, int head_dim, int q_row_min, const void* rope_cos,
-                         const void* rope_sin, void* stream, const int* cu = nullptr, long rows = -1) {
+                         const void* rope_sin, void* stream, const int* cu = nullptr, long rows = -1, int Sst = 0) {
     if (!qkv || !out || !dout || !lse2 || !kv_start || !dqkv || !workspace) return NV_ERR_ARG;
     if (head_dim != HD || (q_row_min >= 0 && (q_row_min & 127)) || q_row_min < (cu ? -1 : 0) || (S > 0 && q_row_min >= S)) return NV_ERR_SHAPE;
     if ((rope_cos == nullptr) != (rope_sin == nullptr)) return NV_ERR_ARG;
@@ -770,13 +770,15 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
     }
     hipStream_t st = (hipStream_t)stream;
     float* dsum = (float*)workspace;
-    if (rows < 0) rows = (long)B * S;
+    if (Sst <= 0) Sst = S;
+    if (rows < 0) rows = (long)B * Sst;
     const long items = rows * H;
+    // strided (K/V-cache) layout: dsum is indexed like lse2, [B, H, Sst]; the rows between a sample's length and Sst carry dO = 0
     NV_LAUNCH(attn_bwd_prep_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, (const bf16_t*)dout,
-                       (const bf16_t*)out, dsum, cu, rows, B, S, H);
+                       (const bf16_t*)out, dsum, cu, rows, B, cu ? S : Sst, H);
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.lse2 = (float*)lse2; p.dsum = dsum; p.dqkv = (bf16_t*)dqkv;
-    p.kv_start = kv_start; p.cu = cu; p.B = B; p.S = S; p.Sst = S; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
+    p.kv_start = kv_start; p.cu = cu; p.B = B; p.S = S; p.Sst = Sst; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
     p.rope_cos = (const bf16_t*)rope_cos; p.rope_sin = (const bf16_t*)rope_sin;
     // with q_row_min > 0 only those query rows carry gradient: dK/dV still cover every key, dQ rows below
@@ -803,6 +805,17 @@ int nv_attn_bwd_rope_bf16(const void* qkv, const void* out, const void* dout, co
                           int q_row_min, void* stream) {
     if (!rope_cos || !rope_sin) return NV_ERR_ARG;
     return attn_bwd_impl(qkv, out, dout, lse2, kv_start, dqkv, workspace, B, S, H, head_dim, q_row_min, rope_cos, rope_sin, stream);
+}
+
+// backward over the K/V-cache layout of nv_attn_fwd_strided_bf16 (sample b at rows b*S_stride .., valid length <= S; out, dout and
+// dqkv use the same sample stride; workspace = nv_attn_bwd_workspace_bytes(B, S_stride, H)).  Queries >= q_row_min carry gradient
+// (dO of every other row must be zero); dK/dV are written for every key row < S of every sample, dQ for rows >= q_row_min; no
+// RoPE^T (the gradients stay in the rotated frame of the cache).  Training with a cached prompt prefix (navillm_amd/episode.py).
+int nv_attn_bwd_strided_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
+                             void* workspace, int B, int S, int S_stride, int H, int head_dim, int q_row_min, void* stream) {
+    if (S_stride < S) return NV_ERR_SHAPE;
+    return attn_bwd_impl(qkv, out, dout, lse2, kv_start, dqkv, workspace, B, S, H, head_dim, q_row_min, nullptr, nullptr, stream, nullptr,
+                         -1, S_stride);
 }
 
 // backward over packed rows (see nv_attn_fwd_varlen_bf16); rope_cos/rope_sin optional (both or neither); `rows` = cu[B]

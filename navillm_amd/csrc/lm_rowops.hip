@@ -334,6 +334,37 @@ __global__ __launch_bounds__(256) void scale_dev_bf16_kernel(const bf16_t* __res
     }
 }
 
+__global__ __launch_bounds__(256) void kv_grad_accum_kernel(const bf16_t* __restrict__ dqkv, float* __restrict__ acc,
+                                                            const int* __restrict__ rows, int n, int d) {
+    const int per_row = 2 * d / 8;
+    const long total = (long)n * per_row;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const long r = rows[i / per_row];
+        const int c = (int)(i % per_row) * 8;
+        float f[8];
+        ld8(dqkv + r * 3 * d + d + c, f);
+        float* a = acc + r * 2 * d + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += f[j];
+    }
+}
+__global__ __launch_bounds__(256) void kv_grad_inject_kernel(bf16_t* __restrict__ dqkv, const float* __restrict__ acc,
+                                                             const int* __restrict__ rows, int n, int d) {
+    const int per_row = 2 * d / 8;
+    const long total = (long)n * per_row;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const long row = i / per_row, r = rows[row];
+        const int c = (int)(i % per_row) * 8;
+        float f[8];
+        bf16_t* q = dqkv + row * 3 * d + d + c;
+        ld8(q, f);
+        const float* a = acc + r * 2 * d + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += a[j];
+        st8(q, f);
+    }
+}
+
 inline int grid_for(long total, int cap = 256 * 8) {
     long b = (total + 255) / 256;
     if (b < 1) b = 1;
@@ -411,6 +442,33 @@ int nv_rope_rows_bf16(void* qkv, const void* cos_t, const void* sin_t, const int
     if (M == 0) return NV_OK;
     NV_LAUNCH(rope_kernel, dim3(grid_for((long)M * 2 * H * hd / 16)), dim3(256), 0, (hipStream_t)stream,
                        (bf16_t*)qkv, (const bf16_t*)cos_t, (const bf16_t*)sin_t, pos, M, 1, H, hd, ld, 1.f);
+    return nv_check_launch();
+}
+
+// transpose of nv_rope_rows_bf16 (the rotation by -theta): backward of the per-row-position RoPE
+int nv_rope_rows_t_bf16(void* qkv, const void* cos_t, const void* sin_t, const int* pos, int M, int H, int hd, int ld, void* stream) {
+    if (!qkv || !cos_t || !sin_t || !pos || (hd & 15)) return NV_ERR_ARG;
+    if (M == 0) return NV_OK;
+    NV_LAUNCH(rope_kernel, dim3(grid_for((long)M * 2 * H * hd / 16)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)qkv, (const bf16_t*)cos_t, (const bf16_t*)sin_t, pos, M, 1, H, hd, ld, -1.f);
+    return nv_check_launch();
+}
+
+// Training with a cached prompt prefix (navillm_amd/episode.py): the K/V gradients that the steps of an episode send into the
+// prefix rows are summed in fp32 and handed to the prefix's own (deferred) backward.
+//   accum : acc[rows[i], :] += f32(dqkv[rows[i], d .. 3d))          (acc [*, 2d] fp32, dqkv [*, 3d] bf16, same row index)
+//   inject: dqkv[i, d .. 3d) = bf16(f32(dqkv[i, d .. 3d)) + acc[rows[i], :])    (dqkv packed prefix rows, acc cache rows)
+int nv_kv_grad_accum_f32(const void* dqkv, float* acc, const int* rows, int n, int d, void* stream) {
+    if (!dqkv || !acc || !rows || (d & 7)) return NV_ERR_ARG;
+    if (n == 0) return NV_OK;
+    NV_LAUNCH(kv_grad_accum_kernel, dim3(grid_for((long)n * 2 * d / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dqkv, acc, rows,
+              n, d);
+    return nv_check_launch();
+}
+int nv_kv_grad_inject_bf16(void* dqkv, const float* acc, const int* rows, int n, int d, void* stream) {
+    if (!dqkv || !acc || !rows || (d & 7)) return NV_ERR_ARG;
+    if (n == 0) return NV_OK;
+    NV_LAUNCH(kv_grad_inject_kernel, dim3(grid_for((long)n * 2 * d / 8)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dqkv, acc, rows, n, d);
     return nv_check_launch();
 }
 

@@ -1,0 +1,305 @@
+"""Training with the prompt's static prefix computed ONCE per episode (an MI355X-first restructuring of the rollout's
+training loop; no counterpart in the reference).
+
+The reference re-runs the whole ~650-token prompt through the LM forward AND backward at every navigation step
+(tasks/agents/mp3d_agent.py:726,756), although
+  * ~530 of those tokens -- everything up to "### History:" (instruction + fixed template text) -- are identical at every
+    step of an episode, and
+  * the weights do not change inside an episode: `optimizer.step()` runs only between episodes (train.py:86-89), the per-step
+    `backward()`s just accumulate into `.grad`.
+So the prefix's hidden states, K and V are the same tensors at every step, and the episode's gradient
+  sum_t dL_t/dW  =  sum_t [suffix_t part]  +  backprop_prefix( sum_t dL_t/d(K,V of the prefix) )
+because backpropagation is linear in the upstream gradient.  This module does exactly that:
+  begin()   prefix forward once (activations kept; post-RoPE K/V written into a per-layer cache in HBM);
+  step      only the step's suffix rows (history entries, candidates, hints, <cls_1>: ~70-130 tokens) go through the layers,
+            attending to the cached prefix; their backward runs immediately (per-step `loss.backward()` as in the reference)
+            and ADDS the K/V gradients it sends into the prefix rows to an fp32 accumulator per layer;
+  finish()  ONE backward through the prefix with the accumulated K/V gradients injected at every layer.
+Per episode of 6 steps: 530 + 6*120 token-rows forward and backward instead of 6*650 -- about a third of the GEMM work --
+at the price of keeping the prefix activations and caches resident (288 GB of HBM make that a non-issue: 17 GB at 7B, B=8).
+
+Exactness: same function, same weights, same rounding points per op; what differs from the per-step recompute is (a) RoPE
+positions are counted from each sample's first token instead of over the batch's left padding (scores depend on position
+differences only: identical up to bf16 rounding of the rotated q/k, as in navillm_amd/kvcache.py), (b) summation order of
+the prefix's weight gradients (one GEMM over the summed upstream gradient instead of six accumulations).  Parity against the
+per-step recompute is asserted in tests/test_episode_gpu.py (logits per step, every gradient buffer after the episode).
+
+This is an OPTIONAL mode (`NavModel.begin_episode`): the default training path, `bench.py`'s `value` included, recomputes the
+full prompt at every step like the reference.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+
+
+class _SuffixLM(torch.autograd.Function):
+    """the step's suffix rows through the decoder over the cached prefix -> final-norm hidden state of each sample's last token"""
+
+    @staticmethod
+    def forward(ctx, vis_all, anchor, ep, step):
+        Hs, saved = ep._step_forward(step, vis_all)
+        ctx.ep, ctx.saved, ctx.has_vis = ep, saved, vis_all is not None
+        return Hs
+
+    @staticmethod
+    def backward(ctx, dH):
+        dvis = ctx.ep._step_backward(ctx.saved, dH.contiguous())
+        return (dvis if ctx.has_vis else None), None, None, None
+
+
+class PrefixEpisode:
+    def __init__(self, model, batch_size, capacity=1024):
+        cfg = model.cfg
+        self.m, self.B, self.cap = model, batch_size, capacity
+        d, L, H = cfg.hidden_size, cfg.num_layers, cfg.num_heads
+        dev = model.device
+        rows = batch_size * capacity
+        self.cache = [torch.zeros((rows + 1, 3 * d), dtype=BF16, device=dev) for _ in range(L)]   # + a junk row for padding rows
+        self.attn_buf = [torch.zeros((rows, d), dtype=BF16, device=dev) for _ in range(L)]
+        self.lse = [torch.zeros((batch_size, H, capacity), dtype=F32, device=dev) for _ in range(L)]
+        self.dkv_acc = [torch.zeros((rows, 2 * d), dtype=F32, device=dev) for _ in range(L)]
+        self.dout_full = torch.zeros((rows + 1, d), dtype=BF16, device=dev)
+        self.dqkv_full = torch.zeros((rows + 1, 3 * d), dtype=BF16, device=dev)
+        self.kv0 = torch.zeros((batch_size,), dtype=I32, device=dev)
+        self.prefix = None
+        self._slab = {}
+        self.stats = {"prefix_rows": 0, "suffix_rows": []}
+
+    # ------------------------------------------------------------------ helpers
+    def _buf(self, tag, shape, dtype=BF16):
+        """grow-only scratch tensors keyed by tag (no allocator traffic inside a step)"""
+        n = int(np.prod(shape))
+        t = self._slab.get(tag)
+        if t is None or t.numel() < n or t.dtype != dtype:
+            t = torch.empty((n,), dtype=dtype, device=self.m.device)
+            self._slab[tag] = t
+        return t[:n].view(*shape)
+
+    def _weights(self, i):
+        m, st = self.m, self.m.store
+        p = f"lang_model.model.layers.{i}."
+        return (st.qkv(i), st.p(p + "self_attn.o_proj.weight"), st.gate_up(i), st.p(p + "mlp.down_proj.weight"),
+                st.p(p + "input_layernorm.weight"), st.p(p + "post_attention_layernorm.weight"),
+                st.qkv(i, grad=True), st.g(p + "self_attn.o_proj.weight"), st.gate_up(i, grad=True), st.g(p + "mlp.down_proj.weight"),
+                st.g(p + "input_layernorm.weight"), st.g(p + "post_attention_layernorm.weight"))
+
+    # ------------------------------------------------------------------ prefix forward, once per episode
+    @torch.no_grad()
+    def begin(self, prefix_ids):
+        """prefix_ids: B python lists of token ids (no visual tokens) -- the part of every prompt of this episode that never changes"""
+        m, cfg, st = self.m, self.m.cfg, self.m.store
+        B, cap, H, hd, eps, L = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers
+        assert len(prefix_ids) == B
+        lens = np.array([len(p) for p in prefix_ids], dtype=np.int32)
+        assert lens.min() > 0 and lens.max() < cap
+        special = set(cfg.special_token_ids)
+        assert not any(t in special for p in prefix_ids for t in p), "the static prefix must not contain visual tokens"
+        Mp = int(lens.sum())
+        cu = np.zeros(B + 1, np.int32)
+        cu[1:] = np.cumsum(lens)
+        ids = np.concatenate([np.asarray(p, np.int32) for p in prefix_ids])
+        pos = np.concatenate([np.arange(n, dtype=np.int32) for n in lens])
+        crow = np.concatenate([b * cap + np.arange(n, dtype=np.int32) for b, n in enumerate(lens)])
+        dev = m.device
+        ids_d, pos_d, crow_d, cu_d = (ops.h2d(torch.from_numpy(a), dev) for a in (ids, pos, crow, cu))
+        vix = torch.full((Mp,), -1, dtype=I32, device=dev)
+        zero_pos0 = torch.zeros((B,), dtype=I32, device=dev)
+        Lmax = int(lens.max())
+        x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_d, vix, None)
+        layers = []
+        for i in range(L):
+            Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
+            n1, rstd1 = ops.rmsnorm_fwd(x, w1, eps)
+            qkv = ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, Lmax, 2 * H * hd, pos_i32=pos_d)
+            ops.scatter_rows_bf16_(qkv, crow_d, self.cache[i])
+            attn = torch.empty((Mp, H * hd), dtype=BF16, device=dev)
+            lse = torch.empty((B, H, Lmax), dtype=F32, device=dev)
+            ops.attn_fwd_varlen(qkv, cu_d, zero_pos0, B, Lmax, H, hd, out=attn, lse2=lse)
+            x1 = ops.gemm_bf16(ops.NT, attn, Wo, R=x, epilogue=ops.EPI_RESID)
+            n2, rstd2 = ops.rmsnorm_fwd(x1, w2, eps)
+            gu = ops.gemm_bf16(ops.NT, n2, Wgu)
+            h = ops.swiglu_fwd(gu)
+            x2 = ops.gemm_bf16(ops.NT, h, Wd, R=x1, epilogue=ops.EPI_RESID)
+            layers.append(dict(x=x, n1=n1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x1=x1, n2=n2, rstd2=rstd2, gu=gu, h=h))
+            self.dkv_acc[i].zero_()
+            x = x2
+        self.prefix = dict(ids=[list(p) for p in prefix_ids], ids_np=ids, lens=lens, cu=cu_d, pos=pos_d, crow=crow_d, pos0=zero_pos0,
+                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0)
+        self.stats = {"prefix_rows": Mp, "suffix_rows": []}
+
+    # ------------------------------------------------------------------ one step: suffix rows over the cached prefix
+    def lm(self, ids_list, vis_idx_list, vis_all):
+        """ids_list[b]: the whole prompt of sample b (must start with its registered prefix); vis_idx_list[b][j]: row of vis_all for
+        token j or -1.  -> [B, d] final-norm hidden state of every prompt's last token, differentiable w.r.t. vis_all."""
+        P = self.prefix
+        assert P is not None, "PrefixEpisode.begin() first"
+        B, cap = self.B, self.cap
+        n = []
+        for b in range(B):
+            lp = int(P["lens"][b])
+            assert ids_list[b][:lp] == P["ids"][b], "the prompt does not start with the prefix registered for this episode"
+            assert lp < len(ids_list[b]) <= cap, "prompt longer than the cache (left truncation is not supported in this mode)"
+            n.append(len(ids_list[b]) - lp)
+        N = max(n)
+        M = B * N
+        junk = B * cap
+        ids_new = np.full(M, self.m.cfg.pad_token_id, np.int32)
+        vix_new = np.full(M, -1, np.int32)
+        pos_new = np.zeros(M, np.int32)
+        crow = np.full(M, junk, np.int32)
+        grow = np.zeros(M, np.int32)
+        last = np.zeros(B, np.int32)
+        for b in range(B):
+            lp = int(P["lens"][b])
+            s, e = b * N, b * N + n[b]
+            ids_new[s:e] = ids_list[b][lp:]
+            vix_new[s:e] = vis_idx_list[b][lp:]
+            ar = np.arange(lp, lp + n[b], dtype=np.int32)
+            pos_new[s:e] = ar
+            crow[s:e] = b * cap + ar
+            grow[s:e] = b * cap + ar
+            grow[e:b * N + N] = b * cap
+            last[b] = e - 1
+        tok_rows = np.flatnonzero(vix_new >= 0)
+        R = 0 if vis_all is None else int(vis_all.shape[0])
+        assert tok_rows.size == R, f"{tok_rows.size} visual tokens in the step's suffix but {R} visual rows (the static prefix holds none)"
+        vis_rows = np.zeros(R, np.int32)
+        vis_rows[vix_new[tok_rows]] = tok_rows                 # vis row r is added at block row vis_rows[r]
+        packed = np.concatenate([ids_new, vix_new, pos_new, crow, grow, last, vis_rows])
+        idx = ops.h2d(torch.from_numpy(packed), self.m.device)
+        parts = [idx[k * M:(k + 1) * M] for k in range(5)] + [idx[5 * M:5 * M + B], idx[5 * M + B:]]
+        step = dict(M=M, N=N, n=n, Lmax=int(max(int(P["lens"][b]) + n[b] for b in range(B))), qmin=(int(P["lens"].min()) // 128) * 128,
+                    ids=parts[0], vix=parts[1], pos=parts[2], crow=parts[3], grow=parts[4], last=parts[5], vis_rows=parts[6],
+                    ids_np=ids_new)
+        self.stats["suffix_rows"].append(int(sum(n)))
+        anchor = self.m._anchor if torch.is_grad_enabled() else None
+        return _SuffixLM.apply(vis_all, anchor, self, step)
+
+    def _step_forward(self, step, vis_all):
+        m, cfg, st = self.m, self.m.cfg, self.m.store
+        B, cap, H, hd, eps, L, d, ff = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers, cfg.hidden_size, \
+            cfg.intermediate_size
+        M, Lmax, qmin = step["M"], step["Lmax"], step["qmin"]
+        k = self.prefix["steps"]
+        x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), step["ids"], step["vix"], vis_all, out=self._buf("E", (M, d)))
+        layers = []
+        for i in range(L):
+            Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
+            t = lambda name, width, dt=BF16: self._buf(f"s{i}.{name}", (M, width) if width else (M,), dt)
+            n1, rstd1 = ops.rmsnorm_fwd(x, w1, eps, out=t("n1", d), rstd=t("r1", 0, F32))
+            qkv = ops.gemm_bf16(ops.NT, n1, Wqkv, out=self._buf("qkv", (M, 3 * d)))
+            ops.rope_rows_(qkv, m.rope_cos, m.rope_sin, step["pos"], H, hd)
+            ops.scatter_rows_bf16_(qkv, step["crow"], self.cache[i])
+            ops.attn_fwd_strided(self.cache[i], self.kv0, B, Lmax, cap, H, hd, out=self.attn_buf[i], lse2=self.lse[i], q_row_min=qmin)
+            attn = t("attn", d)
+            ops._lib.check(ops._L().nv_gather_rows_bf16(self.attn_buf[i].data_ptr(), step["grow"].data_ptr(), attn.data_ptr(), M, d, ops._st()),
+                           "nv_gather_rows_bf16")
+            x1 = ops.gemm_bf16(ops.NT, attn, Wo, out=t("x1", d), R=x, epilogue=ops.EPI_RESID)
+            n2, rstd2 = ops.rmsnorm_fwd(x1, w2, eps, out=t("n2", d), rstd=t("r2", 0, F32))
+            gu = ops.gemm_bf16(ops.NT, n2, Wgu, out=t("gu", 2 * ff))
+            h = ops.swiglu_fwd(gu, out=t("h", ff))
+            x2 = ops.gemm_bf16(ops.NT, h, Wd, out=t("x2", d), R=x1, epilogue=ops.EPI_RESID)
+            layers.append(dict(x=x, n1=n1, rstd1=rstd1, attn=attn, x1=x1, n2=n2, rstd2=rstd2, gu=gu, h=h))
+            x = x2
+        x_last = ops.gather_rows_bf16(x, step["last"])
+        Hs, rstdf = ops.rmsnorm_fwd(x_last, st.p("lang_model.model.norm.weight"), eps)
+        self.prefix["steps"] = k + 1
+        return Hs, dict(step=step, layers=layers, x_last=x_last, rstdf=rstdf, serial=k + 1)
+
+    def _step_backward(self, saved, dH):
+        m, cfg, st = self.m, self.m.cfg, self.m.store
+        if saved["serial"] != self.prefix["steps"]:
+            raise RuntimeError("the step scratch of this episode was reused by a later step before this backward ran; call backward() "
+                               "right after each loss (as the rollout loop does)")
+        B, cap, H, hd, L, d = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.num_layers, cfg.hidden_size
+        step = saved["step"]
+        M, Lmax, qmin = step["M"], step["Lmax"], step["qmin"]
+        st.touch_layers()
+        m._dp_begin_backward()
+        dx_last = ops.rmsnorm_bwd(dH, saved["x_last"], st.p("lang_model.model.norm.weight"), saved["rstdf"], st.g("lang_model.model.norm.weight"))
+        dx = self._buf("dx_a", (M, d))
+        dx.zero_()
+        ops.scatter_rows_bf16_(dx_last, step["last"], dx)
+        other = self._buf("dx_b", (M, d))
+        for i in reversed(range(L)):
+            Wqkv, Wo, Wgu, Wd, w1, w2, gqkv, go, ggu, gd, gw1, gw2 = self._weights(i)
+            a = saved["layers"][i]
+            dh = ops.gemm_bf16(ops.NN, dx, Wd, out=self._buf("dh", (M, cfg.intermediate_size)))
+            ops.gemm_bf16(ops.TN, dx, a["h"], out=gd, epilogue=ops.EPI_ACCUM)
+            dgu = ops.swiglu_bwd(a["gu"], dh, out=self._buf("dgu", (M, 2 * cfg.intermediate_size)))
+            dn2 = ops.gemm_bf16(ops.NN, dgu, Wgu, out=self._buf("dn2", (M, d)))
+            ops.gemm_bf16(ops.TN, dgu, a["n2"], out=ggu, epilogue=ops.EPI_ACCUM)
+            dx1 = ops.rmsnorm_bwd(dn2, a["x1"], w2, a["rstd2"], gw2, resid_grad=dx, out=self._buf("dx1", (M, d)))
+            dattn = ops.gemm_bf16(ops.NN, dx1, Wo, out=self._buf("dattn", (M, d)))
+            ops.gemm_bf16(ops.TN, dx1, a["attn"], out=go, epilogue=ops.EPI_ACCUM)
+            # attention backward on the cache layout: dO is zero everywhere except this step's rows
+            self.dout_full.zero_()
+            ops.scatter_rows_bf16_(dattn, step["crow"], self.dout_full)
+            ops.attn_bwd_strided(self.cache[i], self.attn_buf[i], self.dout_full, self.lse[i], self.kv0, B, Lmax, cap, H, hd, self.dqkv_full,
+                                 q_row_min=qmin)
+            dqkv = ops.gather_rows_bf16(self.dqkv_full, step["crow"])
+            ops.rope_rows_t_(dqkv, m.rope_cos, m.rope_sin, step["pos"], H, hd)
+            ops.kv_grad_accum(self.dqkv_full, self.dkv_acc[i], self.prefix["crow"])     # what this step sends into the prefix's K/V
+            dn1 = ops.gemm_bf16(ops.NN, dqkv, Wqkv, out=self._buf("dn1", (M, d)))
+            ops.gemm_bf16(ops.TN, dqkv, a["n1"], out=gqkv, epilogue=ops.EPI_ACCUM)
+            ndx = ops.rmsnorm_bwd(dn1, a["x"], w1, a["rstd1"], gw1, resid_grad=dx1, out=other)
+            dx, other = ndx, dx
+        dvis = ops.vis_grad(dx, step["vis_rows"]) if step["vis_rows"].numel() else None
+        self._embed_grad(dx, step["ids_np"])
+        return dvis
+
+    def _embed_grad(self, dE, ids_np):
+        st = self.m.store
+        order = np.argsort(ids_np, kind="stable")
+        uniq, counts = np.unique(ids_np, return_counts=True)
+        seg = np.zeros(uniq.size + 1, dtype=np.int32)
+        np.cumsum(counts, out=seg[1:])
+        dev = dE.device
+        ops.embed_grad(dE, ops.h2d(torch.from_numpy(uniq.astype(np.int32)), dev), ops.h2d(torch.from_numpy(seg), dev),
+                       ops.h2d(torch.from_numpy(order.astype(np.int32)), dev), st.g("lang_model.model.embed_tokens.weight"))
+        st.touch("lang_model.model.embed_tokens.weight")
+
+    # ------------------------------------------------------------------ the prefix's one backward
+    @torch.no_grad()
+    def finish(self):
+        """backward through the prefix with the K/V gradients the episode's steps accumulated, injected layer by layer; call it
+        after the last step's backward() and before the optimizer step (inside `final_backward()` under data parallelism)"""
+        P = self.prefix
+        if P is None:
+            return
+        m, cfg, st = self.m, self.m.cfg, self.m.store
+        B, H, hd, L, d = self.B, cfg.num_heads, cfg.head_dim, cfg.num_layers, cfg.hidden_size
+        Mp, Lmax = P["Mp"], P["Lmax"]
+        st.touch_layers()
+        dx = None
+        for i in reversed(range(L)):
+            Wqkv, Wo, Wgu, Wd, w1, w2, gqkv, go, ggu, gd, gw1, gw2 = self._weights(i)
+            a = P["layers"][i]
+            dqkv = self._buf("p.dqkv", (Mp, 3 * d))
+            dx1 = None
+            if dx is not None:                    # (the top layer's prefix outputs feed nothing: only its K/V carry gradient)
+                dh = ops.gemm_bf16(ops.NN, dx, Wd, out=self._buf("p.dh", (Mp, cfg.intermediate_size)))
+                ops.gemm_bf16(ops.TN, dx, a["h"], out=gd, epilogue=ops.EPI_ACCUM)
+                dgu = ops.swiglu_bwd(a["gu"], dh, out=self._buf("p.dgu", (Mp, 2 * cfg.intermediate_size)))
+                dn2 = ops.gemm_bf16(ops.NN, dgu, Wgu, out=self._buf("p.dn2", (Mp, d)))
+                ops.gemm_bf16(ops.TN, dgu, a["n2"], out=ggu, epilogue=ops.EPI_ACCUM)
+                dx1 = ops.rmsnorm_bwd(dn2, a["x1"], w2, a["rstd2"], gw2, resid_grad=dx, out=self._buf("p.dx1", (Mp, d)))
+                dattn = ops.gemm_bf16(ops.NN, dx1, Wo, out=self._buf("p.dattn", (Mp, d)))
+                ops.gemm_bf16(ops.TN, dx1, a["attn"], out=go, epilogue=ops.EPI_ACCUM)
+                ops.attn_bwd_varlen(a["qkv"], a["attn"], dattn, a["lse"], P["cu"], P["pos0"], B, Lmax, H, hd, dqkv, q_row_min=0, rope=None)
+            else:
+                dqkv.zero_()
+            ops.kv_grad_inject(dqkv, self.dkv_acc[i], P["crow"])
+            ops.rope_rows_t_(dqkv, m.rope_cos, m.rope_sin, P["pos"], H, hd)
+            dn1 = ops.gemm_bf16(ops.NN, dqkv, Wqkv, out=self._buf("p.dn1", (Mp, d)))
+            ops.gemm_bf16(ops.TN, dqkv, a["n1"], out=gqkv, epilogue=ops.EPI_ACCUM)
+            dx = ops.rmsnorm_bwd(dn1, a["x"], w1, a["rstd1"], gw1, resid_grad=dx1, out=self._buf(f"p.dx{i & 1}", (Mp, d)))
+            m._dp_layer_done(i, [])
+        self._embed_grad(dx, P["ids_np"])
+        self.prefix = None
+        dp = getattr(m, "_dp", None)
+        if dp is not None and dp._exchanging():
+            dp._finalize()                         # outside autograd: no engine callback will run the end-of-backward exchange

@@ -32,6 +32,9 @@ SIGNATURES = {
     "nv_rmsnorm_bwd_bf16": (i, [vp, vp, vp, fp, vp, vp, vp, vp, i, i, vp]),
     "nv_rope_bf16": (i, [vp, vp, vp, i, i, i, i, i, i, vp]),
     "nv_rope_rows_bf16": (i, [vp, vp, vp, ip, i, i, i, i, vp]),
+    "nv_rope_rows_t_bf16": (i, [vp, vp, vp, ip, i, i, i, i, vp]),
+    "nv_kv_grad_accum_f32": (i, [vp, fp, ip, i, i, vp]),
+    "nv_kv_grad_inject_bf16": (i, [vp, fp, ip, i, i, vp]),
     "nv_swiglu_fwd_bf16": (i, [vp, vp, i, i, vp]),
     "nv_swiglu_bwd_bf16": (i, [vp, vp, vp, i, i, vp]),
     "nv_scale_bf16": (i, [vp, vp, l, f, vp]),
@@ -42,6 +45,7 @@ SIGNATURES = {
     "nv_attn_fwd_strided_bf16": (i, [vp, vp, fp, ip, i, i, i, i, i, i, vp]),
     "nv_attn_fwd_varlen_bf16": (i, [vp, vp, fp, ip, ip, i, i, i, i, i, vp]),
     "nv_attn_fwd_hfround_bf16": (i, [vp, vp, fp, ip, ip, i, i, i, i, i, vp]),
+    "nv_attn_bwd_strided_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, i, i, vp]),
     "nv_attn_bwd_varlen_bf16": (i, [vp, vp, vp, fp, ip, ip, vp, vp, vp, vp, i, i, l, i, i, i, vp]),
     "nv_attn_bwd_workspace_bytes": (sz, [i, i, i]),
     "nv_attn_bwd_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, i, vp]),

@@ -153,6 +153,7 @@ class NavModel(nn.Module):
         self.prune_last_layer = True     # navigation/grounding: last decoder layer computed for the <cls_1> rows only
         self.pack_rows = os.environ.get("NAVILLM_PACK_ROWS", "1") != "0"   # LM over the real tokens only (no left-padding rows)
         self._row_map = None
+        self.episode = None              # PrefixEpisode (begin_episode): static prompt prefix computed once per training episode
         self.fp8 = None                  # Fp8DecoderWeights after to_fp8_weight_only()
         self.flop_log = None             # bench: list of ("lm", tokens, sum of S_b^2, backward?) / ("lm_head", rows, backward?) per LM call
         self.attn_hf_rounding = False    # tests only: attention forward through the parity instrument nv_attn_fwd_hfround_bf16
@@ -243,6 +244,27 @@ class NavModel(nn.Module):
         from .kvcache import KVCacheLM
         self.kv = KVCacheLM(self, batch_size, capacity)
         return self.kv
+
+    # ---- optional training mode: the prompt's static prefix is computed once per episode (navillm_amd/episode.py)
+    def begin_episode(self, prefix_ids, capacity=1024):
+        """prefix_ids: B lists of token ids -- the part of every navigation prompt of the coming episode that never changes
+        (everything up to "### History:").  Until `finish_episode()`, training-mode `model('navigation' | 'object_grounding')`
+        calls push only the rest of each prompt through the LM, over the cached prefix; their `backward()`s accumulate the
+        prefix's K/V gradients, and `finish_episode()` runs the prefix's one backward.  Exact up to bf16 rounding order."""
+        from .episode import PrefixEpisode
+        B = len(prefix_ids)
+        if self.episode is None or self.episode.B != B or self.episode.cap != capacity:
+            self.episode = PrefixEpisode(self, B, capacity)
+        self.episode.begin(prefix_ids)
+        return self.episode
+
+    def finish_episode(self):
+        if self.episode is not None:
+            self.episode.finish()
+
+    def _lm_episode(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None):
+        ids_l, vix_l, vis_all, _ = self._vis_layout(ids_cpu, am_cpu, cand_vis, hist_vis, obj_vis)
+        return self.episode.lm(ids_l, vix_l, vis_all)
 
     def reset_kv_cache(self):
         if self.kv is not None:
@@ -626,6 +648,8 @@ class NavModel(nn.Module):
         if self.kv is not None and not torch.is_grad_enabled() and self.kv.B == B:
             hk = self._hist_keys(batch["hist_vis"])
             Hs_cls = self._lm_cached(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, hist_keys=hk)
+        elif self.episode is not None and self.episode.prefix is not None and torch.is_grad_enabled():
+            Hs_cls = self._lm_episode(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis)
         else:
             Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)
         pred = Fn.HeadBF16.apply(Hs_cls, self, "out_head.0")   # [B,100]

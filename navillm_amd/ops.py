@@ -282,6 +282,34 @@ def attn_bwd_varlen(qkv, out, dout, lse2, cu_i32, pos0_i32, B, S_max, H, hd, dqk
     return dqkv
 
 
+def attn_bwd_strided(qkv, out, dout, lse2, kv_start_i32, B, S, S_stride, H, hd, dqkv, q_row_min=0):
+    """backward over the K/V-cache layout (see nv_attn_bwd_strided_bf16); gradients stay in the rotated frame"""
+    ws = _workspace(_L().nv_attn_bwd_workspace_bytes(B, S_stride, H), qkv.device, "attn_strided")
+    rc = _L().nv_attn_bwd_strided_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(),
+                                       dqkv.data_ptr(), ws.data_ptr(), B, S, S_stride, H, hd, q_row_min, _st())
+    _lib.check(rc, "nv_attn_bwd_strided_bf16")
+    return dqkv
+
+
+def rope_rows_t_(qkv, cos_t, sin_t, pos_i32, H, hd):
+    """in-place RoPE^T with an explicit position per row (backward of rope_rows_)"""
+    _lib.check(_L().nv_rope_rows_t_bf16(qkv.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), pos_i32.data_ptr(), qkv.shape[0], H, hd,
+                                        qkv.stride(0), _st()), "nv_rope_rows_t_bf16")
+    return qkv
+
+
+def kv_grad_accum(dqkv_full, acc_f32, rows_i32):
+    d = dqkv_full.shape[1] // 3
+    _lib.check(_L().nv_kv_grad_accum_f32(dqkv_full.data_ptr(), acc_f32.data_ptr(), rows_i32.data_ptr(), rows_i32.numel(), d, _st()),
+               "nv_kv_grad_accum_f32")
+
+
+def kv_grad_inject(dqkv_packed, acc_f32, rows_i32):
+    d = dqkv_packed.shape[1] // 3
+    _lib.check(_L().nv_kv_grad_inject_bf16(dqkv_packed.data_ptr(), acc_f32.data_ptr(), rows_i32.data_ptr(), rows_i32.numel(), d, _st()),
+               "nv_kv_grad_inject_bf16")
+
+
 def attn_bwd(qkv, out, dout, lse2, kv_start_i32, B, S, H, hd, dqkv=None, q_row_min=0, rope=None):
     """rope=(cos_t, sin_t): dQ/dK leave the kernel already rotated back (RoPE^T fused into the final store)."""
     if dqkv is None:

@@ -81,3 +81,11 @@ def embodied_qa_prompt(agent, question, hist_num, cand_num):
 def qa3d_prompt(question):
     """llava.py:13-17"""
     return "### Image: <cand>\n" + "### Instruction: {}\n".format(question) + "### Output: "
+
+
+def static_prefix(prompt):
+    """the part of a navigation / grounding / summarization prompt that is the same at every step of an episode: everything up
+    to and including "### History:" (the task sentence + the instruction + the fixed history header)"""
+    key = "### History:"
+    i = prompt.index(key)
+    return prompt[: i + len(key)]

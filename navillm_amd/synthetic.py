@@ -18,7 +18,7 @@ import torch
 
 from . import ops
 from .graph import GraphMap, get_angle_fts
-from .prompts import navigation_prompt, object_grounding_prompt, summarization_prompt, embodied_qa_prompt, qa3d_prompt
+from .prompts import static_prefix, navigation_prompt, object_grounding_prompt, summarization_prompt, embodied_qa_prompt, qa3d_prompt
 
 
 # --------------------------------------------------------------------------- stub tokenizer
@@ -235,6 +235,15 @@ class SyntheticEpisodes:
         ids, am = self.tok.pad_left(seqs)
         self.S_hist.append(ids.shape[1])
         return ids, am
+
+    def prefix_ids(self):
+        """token ids of each episode's static prompt prefix (task sentence + instruction + history header), for
+        `NavModel.begin_episode`"""
+        out = []
+        for b in range(self.B):
+            p = static_prefix(navigation_prompt(self.task, "{INSTR}", 0, 1, "<cls_1>"))
+            out.append(self.tok.encode(p, self.instr[b]))
+        return out
 
     def teacher_targets(self, nav, last):
         """a random unvisited current candidate's map slot (0 = stop on the last step)."""

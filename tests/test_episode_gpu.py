@@ -1,0 +1,91 @@
+"""GPU: training with the prompt's static prefix computed once per episode (navillm_amd/episode.py) against the default path
+that recomputes the whole prompt at every step like the reference (tasks/agents/mp3d_agent.py:726,756): same logits at every
+step, same gradients after the episode."""
+import numpy as np
+import pytest
+import torch
+
+from util import bf16_ulps_at_scale
+from test_round2_gpu import _mid_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _episode(model, cfg, steps, use_prefix, seed=31, B=3, instr_len=180):
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step
+    from navillm_amd.losses import CrossEntropyLoss
+    ep = SyntheticEpisodes(cfg, B, seed=seed, instr_len=instr_len, device=torch.device(DEV))
+    for b in range(B):
+        ep.instr[b] = ep.instr[b][: instr_len - 23 * b]             # ragged prompts: prefixes of different lengths
+    crit = CrossEntropyLoss()
+    model.zero_grad()
+    model.store.touched.clear()
+    if use_prefix:
+        model.begin_episode(ep.prefix_ids())
+    logits = []
+    for t in range(steps):
+        torch.manual_seed(500 + t)
+        _, lg = nav_step(model, crit, ep, train=True, last=(t == steps - 1))
+        logits.append(lg.detach().float().cpu())
+    if use_prefix:
+        stats = dict(model.episode.stats)
+        model.finish_episode()
+    torch.cuda.synchronize()
+    grads = {g: t.detach().float().clone() for g, t in model.store.grad.items()}
+    return logits, grads, (stats if use_prefix else None)
+
+
+def test_prefix_episode_matches_per_step_recompute():
+    from navillm_amd.nav_model import NavModel
+    cfg = _mid_cfg()
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
+    m.eval()                                                        # dropout off: both runs see the same encoder outputs
+    steps = 4
+    l_ref, g_ref, _ = _episode(m, cfg, steps, use_prefix=False)
+    touched_ref = set(m.store.touched)
+    l_pre, g_pre, stats = _episode(m, cfg, steps, use_prefix=True)
+    assert set(m.store.touched) == touched_ref
+    assert m.episode.prefix is None                                  # finish() closed the episode
+    for t in range(steps):
+        fin = torch.isfinite(l_ref[t])
+        assert torch.equal(torch.isfinite(l_pre[t]), fin)
+        u = bf16_ulps_at_scale(l_pre[t], l_ref[t])
+        print(f"[episode step {t}] logits prefix-reuse vs recompute: {(l_pre[t][fin] - l_ref[t][fin]).abs().max().item():.5f} = {u:.2f} bf16 ulps")
+        assert u <= 3.0
+    st = m.store
+    worst = {}
+    for g in g_ref:
+        rel = ((g_pre[g] - g_ref[g]).norm() / (g_ref[g].norm() + 1e-20)).item()
+        worst[g] = rel
+        assert rel < 2.5e-2, (g, rel)
+    for n in ("lang_model.model.layers.0.self_attn.q_proj.weight", "lang_model.model.layers.0.self_attn.k_proj.weight",
+              "lang_model.model.layers.2.self_attn.v_proj.weight", "lang_model.model.layers.1.mlp.down_proj.weight",
+              "lang_model.model.layers.0.input_layernorm.weight", "lang_model.model.embed_tokens.weight", "out_head.0.weight",
+              "img_embeddings.mapper.weight"):
+        o, k = st.offsets[n], st.sizes[n]
+        a, b = g_pre[st.group_of[n]][o:o + k], g_ref[st.group_of[n]][o:o + k]
+        rel = ((a - b).norm() / (b.norm() + 1e-20)).item()
+        worst[n] = rel
+        assert rel < 4e-2, (n, rel)
+    print("[episode] gradient rel err prefix-reuse vs recompute:", {k: round(v, 4) for k, v in worst.items()})
+    rows_ref = steps * sum(180 - 23 * b + 90 for b in range(3))
+    print(f"[episode] token rows through the LM: prefix {stats['prefix_rows']} once + suffixes {stats['suffix_rows']} (recompute: ~{rows_ref})")
+    assert stats["prefix_rows"] + sum(stats["suffix_rows"]) < 0.6 * rows_ref
+
+
+def test_prefix_episode_rejects_foreign_prompts_and_wrong_use():
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step
+    from navillm_amd.losses import CrossEntropyLoss
+    cfg = _mid_cfg()
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
+    m.eval()
+    ep = SyntheticEpisodes(cfg, 2, seed=3, instr_len=60, device=torch.device(DEV))
+    pre = ep.prefix_ids()
+    pre[1][5] += 1                                                   # not a prefix of sample 1's prompts
+    m.begin_episode(pre)
+    with pytest.raises(AssertionError, match="does not start with the prefix"):
+        nav_step(m, CrossEntropyLoss(), ep, train=True, last=True)
+    with pytest.raises(AssertionError, match="visual tokens"):
+        m.begin_episode([[1, cfg.cand_token_id, 5], [1, 2, 3]])
