@@ -198,6 +198,41 @@ def mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed):
     return res
 
 
+def prefix_reuse_extra(a, cfg, model, wrapped, opt, crit, device, seed):
+    """NOT the headline: the same 6-step training episodes with the prompt's static prefix (instruction + fixed template,
+    ~530 of ~650 tokens) pushed through the LM forward and backward ONCE per episode instead of at every step
+    (navillm_amd/episode.py: exact by linearity of backpropagation while the weights are frozen inside an episode; parity vs
+    the per-step recompute in tests/test_episode_gpu.py).  `value` above recomputes the whole prompt at every step like the
+    reference does."""
+    from navillm_amd.synthetic import SyntheticEpisodes, prefix_reuse_episode
+    ep = SyntheticEpisodes(cfg, a.batch, seed=seed, instr_len=a.instr_len, device=device)
+    res = None
+    for rep in range(3):                      # first episode warms allocations and shapes
+        ep.reset()
+        model.flop_log = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        prefix_reuse_episode(wrapped, crit, ep, STEPS_PER_EPISODE)
+        opt.clip_grad_norm_(40.0); opt.step(); opt.zero_grad()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st = model.episode.stats
+        S = [int(s) for s in ep.S_hist[-STEPS_PER_EPISODE:]]
+        recompute_rows = a.batch * sum(S)
+        d, ff, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_layers
+        f_recompute = 3.0 * (2.0 * L * (4 * d * d + 3 * d * ff) * recompute_rows + 2.0 * L * d * a.batch * sum(s * s for s in S))
+        res = {"nav_steps_per_s_per_gpu": round(a.batch * STEPS_PER_EPISODE / dt, 2), "ms_per_step": round(dt / STEPS_PER_EPISODE * 1e3, 1),
+               "token_rows_per_episode": {"prefix_once": int(st["prefix_rows"]), "suffix_per_step": [int(x) for x in st["suffix_rows"]],
+                                          "per_step_recompute": int(recompute_rows)},
+               "recompute_equivalent_tflops": round(f_recompute / dt / 1e12, 1),
+               "what": "6-step episodes, B=%d: prefix forward once, per-step suffix forward+backward, one deferred prefix backward, clip+AdamW; "
+                       "'recompute_equivalent_tflops' = algorithmic FLOPs of the per-step-recompute formulation divided by this wall time "
+                       "(it exceeds what the GEMMs execute: the point of the restructuring)" % a.batch}
+    model.episode = None
+    torch.cuda.empty_cache()
+    return res
+
+
 def long_horizon_extra(a, cfg, model, wrapped, crit, device, seed, T=64):
     """BASELINE config 4: a 64-step episode.  (i) the validation rollout with history K/V reuse (what "history-KV caching" buys:
     only the new suffix of each prompt is computed), (ii) training steps at the far end of the horizon (history of 58..63
@@ -500,6 +535,7 @@ def main():
     if not a.no_extras and a.model != "tiny":
         for name, fn in (("mixed_task_training_config3", lambda: mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed + 100)),
                          ("long_horizon_config4", lambda: long_horizon_extra(a, cfg, model, wrapped, crit, device, seed + 200)),
+                         ("training_prefix_reuse", lambda: prefix_reuse_extra(a, cfg, model, wrapped, opt, crit, device, seed + 400)),
                          ("fp8_weight_only_13b_config5", lambda: fp8_13b_extra(a, device, seed + 300) if world == 1 else None)):
             phase(name)
             try:        # never take the headline line (or a rank) down

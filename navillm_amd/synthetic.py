@@ -423,3 +423,19 @@ def mixed_task_episode(model, criterion, ep, steps, enable_og=None, enable_summa
         if last and enable_summarize and train:
             losses["sum"] = lm_aux_step(model, ep, "summarization", sync="final", accum=accum)[0]
     return losses
+
+
+def prefix_reuse_episode(model, criterion, ep, steps, accum=1):
+    """One training episode with the prompt's static prefix computed once (navillm_amd/episode.py): `begin_episode`, `steps`
+    navigation steps whose per-step backward()s cover the suffix rows only (all inside the accumulation phase of a data-parallel
+    wrapper), then the prefix's single backward -- the LAST backward before the optimizer step, from inside which a
+    `NavDataParallel` wrapper exchanges the gradients, layer by layer."""
+    inner = model.module if hasattr(model, "module") else model
+    inner.begin_episode(ep.prefix_ids())
+    losses = []
+    for t in range(steps):
+        losses.append(nav_step(model, criterion, ep, train=True, last=(t == steps - 1), accum=accum, final=False)[0])
+    ctx = model.final_backward if hasattr(model, "final_backward") else contextlib.nullcontext
+    with ctx():
+        inner.finish_episode()
+    return losses

@@ -89,3 +89,35 @@ def test_prefix_episode_rejects_foreign_prompts_and_wrong_use():
         nav_step(m, CrossEntropyLoss(), ep, train=True, last=True)
     with pytest.raises(AssertionError, match="visual tokens"):
         m.begin_episode([[1, cfg.cand_token_id, 5], [1, 2, 3]])
+
+
+def test_prefix_episode_under_the_data_parallel_wrapper_world1():
+    """the episode mode behind NavDataParallel (world of one, exchange forced): the per-layer exchanges are launched from the
+    prefix's deferred backward inside final_backward(); gradients must equal the unwrapped episode bit for bit and nothing may
+    stay pending."""
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.parallel import NavDataParallel, RcclComm
+    from navillm_amd.synthetic import SyntheticEpisodes, prefix_reuse_episode
+    from navillm_amd.losses import CrossEntropyLoss
+    cfg = _mid_cfg()
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
+    m.eval()
+    crit = CrossEntropyLoss()
+
+    def run(wrapped):
+        ep = SyntheticEpisodes(cfg, 3, seed=8, instr_len=120, device=torch.device(DEV))
+        m.zero_grad()
+        torch.manual_seed(5)
+        prefix_reuse_episode(wrapped, crit, ep, 3)
+        torch.cuda.synchronize()
+        return {g: t.detach().clone() for g, t in m.store.grad.items()}
+
+    base = run(m)
+    comm = RcclComm(0, 1)
+    ddp = NavDataParallel(m, comm=comm, force_sync=True)
+    got = run(ddp)
+    assert not ddp._pending and not ddp._queued
+    object.__setattr__(m, "_dp", None)
+    for g in base:
+        assert torch.equal(base[g], got[g]), g
+    comm.close()
