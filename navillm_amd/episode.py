@@ -35,6 +35,21 @@ from . import ops
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 
 
+def prefix_ids_from_prompts(tokenizer, prompts):
+    """For callers that hold prompt STRINGS (the reference's agents): token ids of each prompt's static prefix = the longest common
+    prefix of tokenise(prompt) and tokenise(text up to "### History:") -- the LCP guards against a sub-word merge across the cut."""
+    from .prompts import static_prefix
+    out = []
+    for p in prompts:
+        full = tokenizer(p, add_special_tokens=True)["input_ids"]
+        head = tokenizer(static_prefix(p), add_special_tokens=True)["input_ids"]
+        n = 0
+        while n < min(len(full), len(head)) and full[n] == head[n]:
+            n += 1
+        out.append(list(full[:n]))
+    return out
+
+
 class _SuffixLM(torch.autograd.Function):
     """the step's suffix rows through the decoder over the cached prefix -> final-norm hidden state of each sample's last token"""
 

@@ -389,3 +389,23 @@ def test_bench_refuses_an_n_gpu_line_from_fewer_devices():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
                        env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_episode_prefix_ids_from_prompt_strings():
+    """navillm_amd/episode.py::prefix_ids_from_prompts with the real (fixture) Llama tokenizer: the ids of the text up to
+    "### History:" are a true prefix of every later prompt of the episode, whatever the history / candidate counts."""
+    from navillm_amd.nav_model import load_tokenizer
+    from navillm_amd.episode import prefix_ids_from_prompts
+    from navillm_amd.prompts import navigation_prompt, object_grounding_prompt
+    cfg = tiny_cfg("bf16")
+    tok = load_tokenizer(os.path.join(GOLD, "tiny_llama"), cfg)
+    instr = "walk past the table and turn left at the door then wait near the sofa"
+    pre = prefix_ids_from_prompts(tok, [navigation_prompt("r2r", instr, 0, 3), navigation_prompt("reverie", instr, 0, 2)])
+    assert all(len(p) > 10 for p in pre)
+    for agent, p in zip(("r2r", "reverie"), pre):
+        for h, c in ((0, 1), (1, 4), (5, 9)):
+            ids = tok(navigation_prompt(agent, instr, h, c), add_special_tokens=True)["input_ids"]
+            assert ids[:len(p)] == p and len(ids) > len(p)
+            assert not any(t in cfg.special_token_ids for t in p)
+    og = tok(object_grounding_prompt("reverie", instr, 2, 5), add_special_tokens=True)["input_ids"]
+    assert og[:len(pre[1])] != pre[1]           # the grounding prompt starts with another sentence: its own episode prefix would differ
