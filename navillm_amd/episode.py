@@ -81,6 +81,7 @@ class PrefixEpisode:
         self.kv0 = torch.zeros((batch_size,), dtype=I32, device=dev)
         self.prefix = None
         self._slab = {}
+        self._wcache = {}
         self.stats = {"prefix_rows": 0, "suffix_rows": []}
 
     # ------------------------------------------------------------------ helpers
@@ -94,6 +95,13 @@ class PrefixEpisode:
         return t[:n].view(*shape)
 
     def _weights(self, i):
+        """(Wqkv, Wo, Wgu, Wd, w1, w2, their six gradient views) of layer i: views of the flat store, built once"""
+        w = self._wcache.get(i)
+        if w is None:
+            w = self._wcache[i] = self._weights_uncached(i)
+        return w
+
+    def _weights_uncached(self, i):
         m, st = self.m, self.m.store
         p = f"lang_model.model.layers.{i}."
         return (st.qkv(i), st.p(p + "self_attn.o_proj.weight"), st.gate_up(i), st.p(p + "mlp.down_proj.weight"),
@@ -239,6 +247,8 @@ class PrefixEpisode:
         dx.zero_()
         ops.scatter_rows_bf16_(dx_last, step["last"], dx)
         other = self._buf("dx_b", (M, d))
+        zeros_md = self._buf("zeros_md", (M, d))
+        zeros_md.zero_()
         for i in reversed(range(L)):
             Wqkv, Wo, Wgu, Wd, w1, w2, gqkv, go, ggu, gd, gw1, gw2 = self._weights(i)
             a = saved["layers"][i]
@@ -250,11 +260,12 @@ class PrefixEpisode:
             dx1 = ops.rmsnorm_bwd(dn2, a["x1"], w2, a["rstd2"], gw2, resid_grad=dx, out=self._buf("dx1", (M, d)))
             dattn = ops.gemm_bf16(ops.NN, dx1, Wo, out=self._buf("dattn", (M, d)))
             ops.gemm_bf16(ops.TN, dx1, a["attn"], out=go, epilogue=ops.EPI_ACCUM)
-            # attention backward on the cache layout: dO is zero everywhere except this step's rows
-            self.dout_full.zero_()
+            # attention backward on the cache layout: dO is zero everywhere except this step's rows (written, used, zeroed again:
+            # a full-buffer fill per layer was 3 % of the episode)
             ops.scatter_rows_bf16_(dattn, step["crow"], self.dout_full)
             ops.attn_bwd_strided(self.cache[i], self.attn_buf[i], self.dout_full, self.lse[i], self.kv0, B, Lmax, cap, H, hd, self.dqkv_full,
                                  q_row_min=qmin)
+            ops.scatter_rows_bf16_(zeros_md, step["crow"], self.dout_full)
             dqkv = ops.gather_rows_bf16(self.dqkv_full, step["crow"])
             ops.rope_rows_t_(dqkv, m.rope_cos, m.rope_sin, step["pos"], H, hd)
             ops.kv_grad_accum(self.dqkv_full, self.dkv_acc[i], self.prefix["crow"])     # what this step sends into the prefix's K/V
