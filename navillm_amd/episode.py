@@ -131,21 +131,24 @@ class PrefixEpisode:
         vix = torch.full((Mp,), -1, dtype=I32, device=dev)
         zero_pos0 = torch.zeros((B,), dtype=I32, device=dev)
         Lmax = int(lens.max())
-        x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_d, vix, None)
+        d, ff = cfg.hidden_size, cfg.intermediate_size
+        x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_d, vix, None, out=self._buf("pE", (Mp, d)))
         layers = []
         for i in range(L):
             Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
-            n1, rstd1 = ops.rmsnorm_fwd(x, w1, eps)
-            qkv = ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, Lmax, 2 * H * hd, pos_i32=pos_d)
+            # kept until finish(): grow-only slabs, so prefixes of varying length do not churn the allocator
+            t = lambda name, width, dt=BF16: self._buf(f"p{i}.{name}", (Mp, width) if width else (Mp,), dt)
+            n1, rstd1 = ops.rmsnorm_fwd(x, w1, eps, out=t("n1", d), rstd=t("r1", 0, F32))
+            qkv = ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, Lmax, 2 * H * hd, out=t("qkv", 3 * d), pos_i32=pos_d)
             ops.scatter_rows_bf16_(qkv, crow_d, self.cache[i])
-            attn = torch.empty((Mp, H * hd), dtype=BF16, device=dev)
-            lse = torch.empty((B, H, Lmax), dtype=F32, device=dev)
+            attn = t("attn", d)
+            lse = self._buf(f"p{i}.lse", (B, H, Lmax), F32)
             ops.attn_fwd_varlen(qkv, cu_d, zero_pos0, B, Lmax, H, hd, out=attn, lse2=lse)
-            x1 = ops.gemm_bf16(ops.NT, attn, Wo, R=x, epilogue=ops.EPI_RESID)
-            n2, rstd2 = ops.rmsnorm_fwd(x1, w2, eps)
-            gu = ops.gemm_bf16(ops.NT, n2, Wgu)
-            h = ops.swiglu_fwd(gu)
-            x2 = ops.gemm_bf16(ops.NT, h, Wd, R=x1, epilogue=ops.EPI_RESID)
+            x1 = ops.gemm_bf16(ops.NT, attn, Wo, out=t("x1", d), R=x, epilogue=ops.EPI_RESID)
+            n2, rstd2 = ops.rmsnorm_fwd(x1, w2, eps, out=t("n2", d), rstd=t("r2", 0, F32))
+            gu = ops.gemm_bf16(ops.NT, n2, Wgu, out=t("gu", 2 * ff))
+            h = ops.swiglu_fwd(gu, out=t("h", ff))
+            x2 = ops.gemm_bf16(ops.NT, h, Wd, out=t("x2", d), R=x1, epilogue=ops.EPI_RESID)
             layers.append(dict(x=x, n1=n1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x1=x1, n2=n2, rstd2=rstd2, gu=gu, h=h))
             self.dkv_acc[i].zero_()
             x = x2

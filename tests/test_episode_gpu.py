@@ -36,9 +36,13 @@ def _episode(model, cfg, steps, use_prefix, seed=31, B=3, instr_len=180):
     return logits, grads, (stats if use_prefix else None)
 
 
-def test_prefix_episode_matches_per_step_recompute():
+@pytest.mark.parametrize("size", ["mid", "7b-width"])
+def test_prefix_episode_matches_per_step_recompute(size):
+    """mid: d=512, 3 layers; 7b-width: Vicuna-7B's d=4096 / 32 heads / ff=11008 with two layers (multi-tile GEMMs, split-K tails,
+    32 heads in the strided attention backward)"""
     from navillm_amd.nav_model import NavModel
-    cfg = _mid_cfg()
+    from navillm_amd import config as nvcfg
+    cfg = _mid_cfg() if size == "mid" else nvcfg.vicuna_7b(image_feat_size=768, num_layers=2, base_vocab_size=2000)
     m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
     m.eval()                                                        # dropout off: both runs see the same encoder outputs
     steps = 4
@@ -51,7 +55,7 @@ def test_prefix_episode_matches_per_step_recompute():
         fin = torch.isfinite(l_ref[t])
         assert torch.equal(torch.isfinite(l_pre[t]), fin)
         u = bf16_ulps_at_scale(l_pre[t], l_ref[t])
-        print(f"[episode step {t}] logits prefix-reuse vs recompute: {(l_pre[t][fin] - l_ref[t][fin]).abs().max().item():.5f} = {u:.2f} bf16 ulps")
+        print(f"[episode {size} step {t}] logits prefix-reuse vs recompute: {(l_pre[t][fin] - l_ref[t][fin]).abs().max().item():.5f} = {u:.2f} bf16 ulps")
         assert u <= 3.0
     st = m.store
     worst = {}
@@ -60,7 +64,7 @@ def test_prefix_episode_matches_per_step_recompute():
         worst[g] = rel
         assert rel < 2.5e-2, (g, rel)
     for n in ("lang_model.model.layers.0.self_attn.q_proj.weight", "lang_model.model.layers.0.self_attn.k_proj.weight",
-              "lang_model.model.layers.2.self_attn.v_proj.weight", "lang_model.model.layers.1.mlp.down_proj.weight",
+              f"lang_model.model.layers.{cfg.num_layers - 1}.self_attn.v_proj.weight", "lang_model.model.layers.1.mlp.down_proj.weight",
               "lang_model.model.layers.0.input_layernorm.weight", "lang_model.model.embed_tokens.weight", "out_head.0.weight",
               "img_embeddings.mapper.weight"):
         o, k = st.offsets[n], st.sizes[n]
@@ -68,7 +72,7 @@ def test_prefix_episode_matches_per_step_recompute():
         rel = ((a - b).norm() / (b.norm() + 1e-20)).item()
         worst[n] = rel
         assert rel < 4e-2, (n, rel)
-    print("[episode] gradient rel err prefix-reuse vs recompute:", {k: round(v, 4) for k, v in worst.items()})
+    print(f"[episode {size}] gradient rel err prefix-reuse vs recompute:", {k: round(v, 4) for k, v in worst.items()})
     rows_ref = steps * sum(180 - 23 * b + 90 for b in range(3))
     print(f"[episode] token rows through the LM: prefix {stats['prefix_rows']} once + suffixes {stats['suffix_rows']} (recompute: ~{rows_ref})")
     assert stats["prefix_rows"] + sum(stats["suffix_rows"]) < 0.6 * rows_ref
