@@ -46,6 +46,9 @@ def test_prefix_episode_matches_per_step_recompute(size):
     m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
     m.eval()                                                        # dropout off: both runs see the same encoder outputs
     steps = 4
+    # measured on MI355X: mid 1.0-1.5 spacings / 0.9-1.1 % ; 7B width 2.3-2.9 spacings / 1.5-2.4 % (the RoPE position frame differs
+    # between the two formulations, on top of the summation order) -> asserted x1.4
+    max_ulps, max_rel, max_rel_tensor = (3.0, 2.5e-2, 4e-2) if size == "mid" else (4.0, 3.3e-2, 3.5e-2)
     l_ref, g_ref, _ = _episode(m, cfg, steps, use_prefix=False)
     touched_ref = set(m.store.touched)
     l_pre, g_pre, stats = _episode(m, cfg, steps, use_prefix=True)
@@ -56,13 +59,13 @@ def test_prefix_episode_matches_per_step_recompute(size):
         assert torch.equal(torch.isfinite(l_pre[t]), fin)
         u = bf16_ulps_at_scale(l_pre[t], l_ref[t])
         print(f"[episode {size} step {t}] logits prefix-reuse vs recompute: {(l_pre[t][fin] - l_ref[t][fin]).abs().max().item():.5f} = {u:.2f} bf16 ulps")
-        assert u <= 3.0
+        assert u <= max_ulps
     st = m.store
     worst = {}
     for g in g_ref:
         rel = ((g_pre[g] - g_ref[g]).norm() / (g_ref[g].norm() + 1e-20)).item()
         worst[g] = rel
-        assert rel < 2.5e-2, (g, rel)
+        assert rel < max_rel, (g, rel)
     for n in ("lang_model.model.layers.0.self_attn.q_proj.weight", "lang_model.model.layers.0.self_attn.k_proj.weight",
               f"lang_model.model.layers.{cfg.num_layers - 1}.self_attn.v_proj.weight", "lang_model.model.layers.1.mlp.down_proj.weight",
               "lang_model.model.layers.0.input_layernorm.weight", "lang_model.model.embed_tokens.weight", "out_head.0.weight",
@@ -71,7 +74,7 @@ def test_prefix_episode_matches_per_step_recompute(size):
         a, b = g_pre[st.group_of[n]][o:o + k], g_ref[st.group_of[n]][o:o + k]
         rel = ((a - b).norm() / (b.norm() + 1e-20)).item()
         worst[n] = rel
-        assert rel < 4e-2, (n, rel)
+        assert rel < max_rel_tensor, (n, rel)
     print(f"[episode {size}] gradient rel err prefix-reuse vs recompute:", {k: round(v, 4) for k, v in worst.items()})
     rows_ref = steps * sum(180 - 23 * b + 90 for b in range(3))
     print(f"[episode] token rows through the LM: prefix {stats['prefix_rows']} once + suffixes {stats['suffix_rows']} (recompute: ~{rows_ref})")
