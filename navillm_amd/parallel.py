@@ -235,24 +235,32 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
         keep = t.clone()
         res = {}
         for algo in ("allreduce", "rs_ag"):
-            self._reduce(t, algo)                      # warm the channels of this collective
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(iters):
-                self._reduce(t, algo)
-            torch.cuda.synchronize()
-            dt = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float32, device=t.device)
-            # max over ranks through the communicator itself: mean of (x_r * world) would need a max -- use sum of one-hot
-            # slots instead: rank r writes slot r, all-reduce(mean) * world, then max on the host
+            try:
+                self._reduce(t, algo)                      # warm the channels of this collective
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    self._reduce(t, algo)
+                torch.cuda.synchronize()
+                mine = (time.perf_counter() - t0) / iters
+            except Exception as e:                         # a collective this RCCL build rejects (symmetric on all ranks): never chosen
+                if algo == "allreduce":
+                    raise
+                res[algo] = float("inf")
+                res[algo + "_error"] = f"{type(e).__name__}: {e}"
+                continue
+            # max over ranks through the communicator itself: rank r writes slot r (x world), mean-all-reduce, max on the host
             slots = torch.zeros(self.comm.world, dtype=torch.float32, device=t.device)
-            slots[self.comm.rank] = dt[0] * self.comm.world
+            slots[self.comm.rank] = mine * self.comm.world
             self.comm.allreduce_mean_(slots)
             res[algo] = float(slots.max().item())
         t.copy_(keep)
         self.algo = "rs_ag" if res["rs_ag"] <= res["allreduce"] else "allreduce"
         nbytes = t.numel() * t.element_size()
-        self.calibration = {"slice_bytes": nbytes, "seconds": res, "chosen": self.algo,
-                            "algbw_GBps": {k: round(nbytes / v / 1e9, 1) for k, v in res.items()}}
+        self.calibration = {"slice_bytes": nbytes, "seconds": {k: (None if v == float("inf") else v) for k, v in res.items() if not k.endswith("_error")},
+                            "chosen": self.algo,
+                            "algbw_GBps": {k: round(nbytes / v / 1e9, 1) for k, v in res.items() if isinstance(v, float) and v not in (0.0, float("inf"))},
+                            "errors": {k: v for k, v in res.items() if k.endswith("_error")}}
         return self.calibration
 
     # ---- the DDP protocol
