@@ -40,6 +40,7 @@ def parse():
                     "first-use kernel/attribute/allocator/RCCL initialisation)")
     ap.add_argument("--infer-steps", type=int, default=6, help="extra, untimed-for-`value` forward-only steps reported aside")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--extras-on-tiny", action="store_true", help="run the extras with --model tiny too (rehearsals)")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-3 (mixed tasks) and config-4 (64-step) extra measurements")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch GEMM event timing")
     return ap.parse_args()
@@ -411,7 +412,7 @@ def relaunch_one_rank_per_gpu(a):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < a.gpus:
+    if have < a.gpus and not REHEARSAL:
         raise SystemExit(f"bench.py: --gpus {a.gpus} requested but only {have} GPU(s) are visible; refusing to report a "
                          f"{a.gpus}-GPU line from fewer devices")
     s = socket.socket()
@@ -426,6 +427,10 @@ def relaunch_one_rank_per_gpu(a):
 
 
 _T0 = time.perf_counter()
+# NAVILLM_BENCH_REHEARSAL=1: run the N-rank control flow (spawn, barriers, max-over-ranks clock, the data-parallel wrapper's
+# hooks inside the real backward, every extra) on a box with FEWER than N GPUs: all ranks share GPU 0, torch.distributed
+# runs on gloo and the gradient exchange is staged through the host.  The line is marked "rehearsal": its numbers mean nothing.
+REHEARSAL = os.environ.get("NAVILLM_BENCH_REHEARSAL") == "1"
 
 
 def phase(msg):
@@ -439,7 +444,9 @@ def main():
         sys.exit(relaunch_one_rank_per_gpu(a))
     from navillm_amd.parallel import init_distributed_device, NavDataParallel
     import torch.distributed as dist
-    device, rank, world = init_distributed_device()
+    if REHEARSAL:
+        os.environ["NAVILLM_COMM"] = "torch"
+    device, rank, world = init_distributed_device(backend="gloo" if REHEARSAL else None, device_index=0 if REHEARSAL else None)
     # Host threads for torch's CPU-side glue ops (masks, index lists): a handful.  With the default (all 256 hardware
     # threads) a barrier of the intra-op pool now and then takes 80-100 ms on a tiny tensor (tools/pack_probe.py), longer
     # than a whole forward; and with one process per GPU the ranks must share the host anyway.  (cpu_baseline sets its own.)
@@ -506,7 +513,7 @@ def main():
     dt = time.perf_counter() - t0
     if not a.no_profile:
         timer.uninstall()
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if REHEARSAL else device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -532,7 +539,7 @@ def main():
                         "sample": f"failed: {type(e).__name__}: {e}"}
         torch.set_num_threads(max(1, min(16, usable_cpus() // max(world, 1))))
     extras = {}
-    if not a.no_extras and a.model != "tiny":
+    if not a.no_extras and (a.model != "tiny" or a.extras_on_tiny):
         for name, fn in (("mixed_task_training_config3", lambda: mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed + 100)),
                          ("long_horizon_config4", lambda: long_horizon_extra(a, cfg, model, wrapped, crit, device, seed + 200)),
                          ("training_prefix_reuse", lambda: prefix_reuse_extra(a, cfg, model, wrapped, opt, crit, device, seed + 400)),
@@ -563,6 +570,8 @@ def main():
                        "global_batch": a.batch * world, "seq_len": int(max(ep.S_hist)) if ep.S_hist else None,
                        "parallelism": f"dp{world}", "loss": float(loss.detach()) if loss is not None else None},
         }
+        if REHEARSAL:
+            line["rehearsal"] = "all ranks shared GPU 0 over gloo: control-flow check only, the numbers are meaningless"
         if world > 1:
             line["dp"] = {"transport": "nv_comm (RCCL, C ABI)" if wrapped.comm is not None else "torch.distributed",
                           "reduce": wrapped.reduce, "algo": wrapped.algo, "calibration": wrapped.calibration,

@@ -32,11 +32,13 @@ def world_info_from_env():
     return int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_distributed_device(backend=None):
+def init_distributed_device(backend=None, device_index=None):
     """-> (device, rank, world_size). env:// rendezvous, one GPU per process.  The torch.distributed group is the CONTROL
-    plane (rendezvous, barriers, the bench's max-over-ranks clock); gradients travel through `RcclComm`."""
+    plane (rendezvous, barriers, the bench's max-over-ranks clock); gradients travel through `RcclComm`.
+    `device_index` overrides LOCAL_RANK (rehearsing the N-rank control flow on a box with fewer GPUs: every rank on GPU 0, gloo)."""
     local_rank, rank, world = world_info_from_env()
     if torch.cuda.is_available():
+        local_rank = local_rank if device_index is None else device_index
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
         backend = backend or "nccl"
@@ -132,6 +134,12 @@ def _allreduce_mean_(t, group=None):
     """torch.distributed transport: in-place mean over ranks on the CURRENT stream (SUM collective, then a 1/world scale;
     for bf16 on the GPU the scale is our own HIP kernel)."""
     world = dist.get_world_size(group)
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (NAVILLM_BENCH_REHEARSAL: N ranks sharing one GPU cannot form an RCCL communicator): stage through the host
+        h = t.detach().to("cpu", torch.float32)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_((h / world).to(t.dtype))
+        return
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     if t.is_cuda and t.dtype == torch.bfloat16 and t.numel() % 8 == 0:
         from . import ops
@@ -220,10 +228,17 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
                 self._reduce(probe)          # channel setup for the collectives of the first exchange
             return
         if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            staged = self.module.store.device.type == "cuda" and dist.get_backend(self.group) == "gloo"      # rehearsal only
             for t in self.module.store.param.values():
-                dist.broadcast(t, src=0, group=self.group)
-            probe = torch.zeros(1024, dtype=torch.float32, device=self.module.store.device)
-            dist.all_reduce(probe, group=self.group)
+                if staged:
+                    h = t.detach().cpu()
+                    dist.broadcast(h, src=0, group=self.group)
+                    t.copy_(h)
+                else:
+                    dist.broadcast(t, src=0, group=self.group)
+            if not staged:
+                probe = torch.zeros(1024, dtype=torch.float32, device=self.module.store.device)
+                dist.all_reduce(probe, group=self.group)
 
     @torch.no_grad()
     def calibrate(self, iters=2):
