@@ -427,6 +427,7 @@ def relaunch_one_rank_per_gpu(a):
 
 
 _T0 = time.perf_counter()
+_JSON_OUT = sys.stdout
 # NAVILLM_BENCH_REHEARSAL=1: run the N-rank control flow (spawn, barriers, max-over-ranks clock, the data-parallel wrapper's
 # hooks inside the real backward, every extra) on a box with FEWER than N GPUs: all ranks share GPU 0, torch.distributed
 # runs on gloo and the gradient exchange is staged through the host.  The line is marked "rehearsal": its numbers mean nothing.
@@ -444,6 +445,13 @@ def main():
         sys.exit(relaunch_one_rank_per_gpu(a))
     from navillm_amd.parallel import init_distributed_device, NavDataParallel
     import torch.distributed as dist
+    # stdout carries exactly ONE line, the JSON: libraries that print banners on fd 1 (RCCL: "ROCm version / Hostname / Librccl
+    # path" per rank, flushed at exit, i.e. AFTER the line; gloo: "[Gloo] Rank ...") are sent to stderr for the whole run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    global _JSON_OUT
+    _JSON_OUT = os.fdopen(json_fd, "w")
     if REHEARSAL:
         os.environ["NAVILLM_COMM"] = "torch"
     device, rank, world = init_distributed_device(backend="gloo" if REHEARSAL else None, device_index=0 if REHEARSAL else None)
@@ -609,7 +617,8 @@ def main():
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         phase("done")
-        print(json.dumps(line), flush=True)
+        _JSON_OUT.write(json.dumps(line) + "\n")
+        _JSON_OUT.flush()
     if world > 1:
         dist.barrier()
     if dist.is_initialized():
