@@ -14,9 +14,7 @@ Not mirrored (raise NotImplementedError): sampling generation, fp32 LM, OPT LMs.
 import collections
 import functools
 import itertools
-import math
 import os
-import types
 
 import numpy as np
 import torch
