@@ -118,6 +118,13 @@ int nv_attn_fwd_bf16(const void* qkv, void* out, float* lse2, const int* kv_star
                      int q_row_min, void* stream);
 /*   KV-cache layout (inference; SURVEY.md §8f items 1-2, HF generation path reached from models/modified_lm.py:184-199):
  *   sample b's rows start at b*S_stride in qkv, out and lse2; S = longest valid length. */
+/*   ... with the cache length and the first computed query row in DEVICE memory: dyn = {S, q_row_min} (a decode step replayed
+ *   from a hipGraph has frozen launch arguments); the grid covers S_stride, query blocks at or beyond S exit at once */
+/*   decode attention (one new token per sample): query r = q slice of cache row crow[r] of sample r, keys/values = cache rows
+ *   r*cap + [0, pos[r]]; out [M, H*128] compact; HBM-bound streaming form, K and V read once */
+int nv_attn_decode_bf16(const void* kv, const int* crow, const int* pos, void* out, int M, int H, int head_dim, int cap, void* stream);
+int nv_attn_fwd_strided_dyn_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, int B, int S_stride, int H, int head_dim,
+                                 const int* dyn, void* stream);
 int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, int B, int S, int S_stride, int H,
                              int head_dim, int q_row_min, void* stream);
 /*   Packed ("varlen") rows: sample b = rows [cu[b], cu[b+1]) (cu: int32 [B+1], device), S_max = longest sample, lse2
@@ -241,9 +248,36 @@ int nv_decoder_set_shared(nv_decoder* p, const void* rope_cos, const void* rope_
 size_t nv_decoder_workspace_bytes(const nv_decoder* p, int max_rows);
 /*   x_in [M,d] new-row embeddings; pos/crow/grow [M] (position, cache row written, cache row read back); kv0 [B] zeros; attn_buf
  *   [B*cap,d]; lse [B,H,cap]; last [B] -> hs_out [B,d] final-norm hidden states of those block rows; hs_all optional [M,d] */
+/*   dyn: optional DEVICE {Lmax, q_row_min} overriding the two host values */
 int nv_decoder_extend(const nv_decoder* p, const void* x_in, const int* pos, const int* crow, const int* grow, const int* kv0,
                       void* attn_buf, float* lse, const int* last, void* hs_out, void* hs_all, int M, int B, int Lmax, int cap,
-                      int q_row_min, void* workspace, size_t workspace_bytes, void* stream);
+                      int q_row_min, const int* dyn, void* workspace, size_t workspace_bytes, void* stream);
+/* ---- the decode-step Linear with its row kernels folded in (navillm_amd/csrc/gemv_stream.hip; HF LlamaDecoderLayer's
+ *      RMSNorm -> Linear and gate|up -> SwiGLU as one launch each when M <= 16):  C = pre(A)[M,K] @ W[N,K]^T
+ *      W bf16 (scales NULL) or e4m3fn codes + per-row scales; a_rows: optional row gather of A;
+ *      rmsnorm: the operand is RMSNorm(A; norm_w [K], eps), bit-identical to nv_rmsnorm_fwd_bf16;
+ *      swiglu == 0: C [M,N] (+ optional residual R);  swiglu != 0 (with rmsnorm, no R): W = gate|up [N = 2 ff, K] and
+ *      C [M, N/2] = bf16(bf16(silu(g)) * u) of the bf16-rounded projections, bit-identical to nv_swiglu_fwd_bf16 on the stored gate|up.
+ *      NV_ERR_SHAPE outside the streamer's fast path (K % 64, fp8: % 128; N % 8; 16-B aligned rows; M <= 16). */
+int nv_gemv_pre(const void* A, const int* a_rows, const void* W, const float* scales, void* C, const void* R, int M, int N, int K, int lda,
+                int ldw, int ldc, int ldr, int rmsnorm, const void* norm_w, float eps, int swiglu, void* stream);
+/*   nv_rope_rows_bf16 + nv_scatter_rows_bf16 in one launch: dst[rows[m]] = [rope(q) | rope(k) | v] of qkv row m at position pos[m] */
+int nv_rope_scatter_rows_bf16(const void* qkv, const void* cos_t, const void* sin_t, const int* pos, const int* rows, void* dst, int M, int H,
+                              int hd, int ld, void* stream);
+/* ---- greedy decoding with the decisions on the device (HF generate(do_sample=False), models/nav_model.py:324-341,388-402;
+ *      special-id mask models/modified_lm.py:122-124).  state = nv_decode_state_ints(B) int32:
+ *      tok[B] | fin[B] | len[B] | pos[B] | crow[B] | grow[B] | last[B] | dyn[2] | cnt[1].
+ *      nv_decode_pick_bf16: masked argmax of logits [B, ldl] (ids >= V and [special0, special0+nspecial) excluded, ties -> smallest
+ *      id), finished rows emit `pad`, a row finishes on `eos`; out[cnt, b] = token.  nv_decode_advance: cache indices of the new
+ *      token from len, dyn = {max len + 1, 128-aligned min len}, len += 1, cnt += 1.  nv_decoder_greedy_step: lm_head -> pick ->
+ *      advance -> embedding gather -> nv_decoder_extend(dyn); identical launch arguments every step (hipGraph replay). */
+int nv_decode_state_ints(int B);
+int nv_decode_pick_bf16(const void* logits, int ldl, int V, int special0, int nspecial, int* state, int* out, int max_steps, int B, int eos,
+                        int pad, void* stream);
+int nv_decode_advance(int* state, int B, int cap, void* stream);
+int nv_decoder_greedy_step(const nv_decoder* p, void* hs, const void* embed, const void* lm_head, int Vp, int V, int special0, int nspecial,
+                           void* logits, void* x, int* state, int* out, int max_steps, const int* kv0, void* attn_buf, float* lse, int B,
+                           int cap, int eos, int pad, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- data-parallel exchange over RCCL (C0-C3): replaces the DDP gradient all-reduce behind tools/optims.py:52-54
  *      (+ its initial parameter broadcast) and the task-id broadcast of tasks/loaders.py:176-179.

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libnavillm_hip.so")
-SOURCES = ["gemm_bf16.hip", "lm_rowops.hip", "attention.hip", "enc_f32.hip", "head_loss_optim.hip", "comm_rccl.hip", "gemv_bf16.hip",
+SOURCES = ["gemm_bf16.hip", "lm_rowops.hip", "attention.hip", "enc_f32.hip", "head_loss_optim.hip", "comm_rccl.hip", "gemv_bf16.hip", "gemv_stream.hip", "decode_step.hip",
            "graph_host.cpp", "fp8w.hip", "decoder_runtime.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 

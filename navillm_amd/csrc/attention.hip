@@ -129,6 +129,8 @@ struct AttnArgs {
     float scale2;          // head_dim^-0.5 * log2(e)
     float scale;           // head_dim^-0.5
     const bf16_t* rope_cos; const bf16_t* rope_sin;   // backward only, optional: apply RoPE^T to dQ/dK as they are written
+    const int* dyn;        // forward over a K/V cache, optional: {S, q_row_min} read from DEVICE memory (a decode step replayed from a
+                           // hipGraph: the launch arguments are frozen, the lengths are not); the grid then covers the capacity
 };
 
 // where sample b lives, how long it is, which keys are padding, its first position, and the first query row computed
@@ -139,13 +141,95 @@ __device__ __forceinline__ Seq seq_of(const AttnArgs& p, int b) {
         const int r0 = p.cu[b];
         s.row0 = r0; s.S = p.cu[b + 1] - r0; s.kvs = 0; s.pos0 = p.kv_start[b];
     } else {
-        s.row0 = (long)b * p.Sst; s.S = p.S; s.kvs = p.kv_start[b]; s.pos0 = 0;
+        s.row0 = (long)b * p.Sst; s.S = p.dyn ? p.dyn[0] : p.S; s.kvs = p.kv_start[b]; s.pos0 = 0;
     }
-    s.qmin = p.q_row_min >= 0 ? p.q_row_min : ((s.S - 1) / 128) * 128;
+    s.qmin = p.dyn ? p.dyn[1] : p.q_row_min >= 0 ? p.q_row_min : ((s.S - 1) / 128) * 128;
     return s;
 }
 __device__ __forceinline__ int lse_stride(const AttnArgs& p) { return p.cu ? p.S : p.Sst; }
 
+
+// =========================================================================== decode (one query row per sample)
+// A decode step attends ONE new query per sample to its cached keys: the tile kernel below would push a whole 128-query block
+// through the MFMAs to use one row of it (32.8 us per layer at B=8, ~650 cached tokens).  This is the HBM-bound form: block =
+// (head, sample), 16 waves; a wave instruction fetches the K (then V) head slices of 4 cache rows -- 4 x 256 B, whole lines --
+// lane (ks = lane>>4, dp = lane&15) holding 8 of the 128 dims of key ks.  q.k is 8 FMAs + a 16-lane butterfly, the softmax is
+// online per lane group (fp32 scores and probabilities), p.V 8 FMAs; the 64 groups' (m, l, acc) meet in LDS.  K and V of the
+// cache are read exactly once: 2 * L * 256 B per (sample, head).
+constexpr int DEC_WAVES = 16, DEC_U = 4;
+__global__ __launch_bounds__(DEC_WAVES * 64) void attn_decode_kernel(const bf16_t* __restrict__ kv, const int* __restrict__ crow,
+                                                                    const int* __restrict__ pos, bf16_t* __restrict__ out, int H, int cap,
+                                                                    float scale2) {
+    __shared__ float pm[DEC_WAVES * 4], pl[DEC_WAVES * 4];
+    __shared__ float pacc[DEC_WAVES * 4][HD + 1];
+    const int h = blockIdx.x, r = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ks = lane >> 4, dp = lane & 15;
+    const int ld = 3 * H * HD;
+    const int L = min(pos[r] + 1, cap);                            // keys 0 .. pos (causal, left-aligned cache)
+    const bf16_t* base = kv + (long)r * cap * ld;
+    float q[8];
+    {
+        const u32x4 v = *(const u32x4*)(kv + (long)crow[r] * ld + h * HD + dp * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { q[2 * j] = __uint_as_float(v[j] << 16) * scale2; q[2 * j + 1] = __uint_as_float(v[j] & 0xffff0000u) * scale2; }
+    }
+    const int kcol = H * HD + h * HD + dp * 8, vcol = 2 * H * HD + h * HD + dp * 8;
+    float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k0 = wave * 4 + ks; k0 < L; k0 += 64 * DEC_U) {           // a 16-lane group shares k0: its lanes leave the loop together
+        u32x4 kf[DEC_U], vf[DEC_U];
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u) {
+            const int key = k0 + u * 64;
+            const long row = key < L ? key : L - 1;
+            kf[u] = __builtin_nontemporal_load((const u32x4*)(base + row * ld + kcol));
+            vf[u] = __builtin_nontemporal_load((const u32x4*)(base + row * ld + vcol));
+        }
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u) {
+            const int key = k0 + u * 64;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s += q[2 * j] * __uint_as_float(kf[u][j] << 16);
+                s += q[2 * j + 1] * __uint_as_float(kf[u][j] & 0xffff0000u);
+            }
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s += __shfl_xor(s, 8, 64);
+            if (key < L) {                                          // uniform within the 16-lane group
+                const float mn = fmaxf(m, s);
+                const float sc = fast_exp2(m - mn), p = fast_exp2(s - mn);   // m = -inf the first time: exp2(-inf) = 0
+                l = l * sc + p;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[2 * j] = acc[2 * j] * sc + p * __uint_as_float(vf[u][j] << 16);
+                    acc[2 * j + 1] = acc[2 * j + 1] * sc + p * __uint_as_float(vf[u][j] & 0xffff0000u);
+                }
+                m = mn;
+            }
+        }
+    }
+    const int g = wave * 4 + ks;
+    if (dp == 0) { pm[g] = m; pl[g] = l; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pacc[g][dp * 8 + j] = acc[j];
+    __syncthreads();
+    if (tid < HD) {
+        float mm = -INFINITY;
+        for (int i = 0; i < DEC_WAVES * 4; ++i) mm = fmaxf(mm, pm[i]);
+        float num = 0.f, den = 0.f;
+        for (int i = 0; i < DEC_WAVES * 4; ++i) {
+            if (pm[i] != -INFINITY) {
+                const float w = fast_exp2(pm[i] - mm);
+                num += pacc[i][tid] * w;
+                den += pl[i] * w;
+            }
+        }
+        out[((long)r * H + h) * HD + tid] = f2bf(den > 0.f ? num / den : 0.f);
+    }
+}
 
 // =========================================================================== forward
 // grid (ceil(S/128), B*H), 256 threads: wave w owns queries q0 + w*32 .. +31 (two 16-query tiles)
@@ -704,6 +788,35 @@ int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int*
     p.B = B; p.S = S; p.Sst = S_stride; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
     NV_LAUNCH(attn_fwd_kernel<false>, dim3(B * H, (S - q_row_min + 127) / 128), dim3(256), 65536, (hipStream_t)stream, p);
+    return nv_check_launch();
+}
+
+// Decode attention: query r = the q slice of cache row crow[r] of SAMPLE r (one new token per sample), keys/values = cache rows
+// r*cap + [0, pos[r]], out [M, H*128] compact.  pos / crow are device arrays: nothing in the launch depends on the lengths.
+int nv_attn_decode_bf16(const void* kv, const int* crow, const int* pos, void* out, int M, int H, int head_dim, int cap, void* stream) {
+    if (!kv || !crow || !pos || !out || cap <= 0) return NV_ERR_ARG;
+    if (head_dim != HD) return NV_ERR_SHAPE;
+    if (M == 0) return NV_OK;
+    const float scale2 = (1.f / sqrtf((float)HD)) * 1.4426950408889634f;
+    NV_LAUNCH(attn_decode_kernel, dim3(H, M), dim3(DEC_WAVES * 64), 0, (hipStream_t)stream, (const bf16_t*)kv, crow, pos, (bf16_t*)out, H, cap,
+              scale2);
+    return nv_check_launch();
+}
+
+// The same over a K/V cache whose current length and first computed query row live in DEVICE memory: dyn = {S, q_row_min}
+// (q_row_min a multiple of 128, < S <= S_stride).  The grid covers the whole capacity; query blocks at or beyond S exit at once.
+int nv_attn_fwd_strided_dyn_bf16(const void* qkv, void* out, float* lse2, const int* kv_start, int B, int S_stride, int H, int head_dim,
+                                 const int* dyn, void* stream) {
+    if (!qkv || !out || !lse2 || !kv_start || !dyn) return NV_ERR_ARG;
+    if (head_dim != HD || S_stride <= 0) return NV_ERR_SHAPE;
+    if (B == 0) return NV_OK;
+    static bool once = false;
+    if (!once) { if (set_lds((const void*)attn_fwd_kernel<false>, 65536)) return NV_ERR_LAUNCH; once = true; }
+    AttnArgs p{};
+    p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse2 = lse2; p.kv_start = kv_start;
+    p.B = B; p.S = S_stride; p.Sst = S_stride; p.H = H; p.ld = 3 * H * HD; p.q_row_min = 0; p.dyn = dyn;
+    p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
+    NV_LAUNCH(attn_fwd_kernel<false>, dim3(B * H, (S_stride + 127) / 128), dim3(256), 65536, (hipStream_t)stream, p);
     return nv_check_launch();
 }
 

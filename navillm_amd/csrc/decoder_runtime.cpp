@@ -104,9 +104,10 @@ static int linear(const nv_decoder* p, const Layer& ly, int kind, const void* x,
 //   kv0      [B] int32     zeros (samples are left-aligned in the cache);  attn_buf [B*cap, d] bf16, lse [B, H, cap] fp32
 //   last     [B] int32     block row of each sample's last token -> hs_out [B, d] = final-norm hidden state of those rows
 //   hs_all   optional [M, d]: final-norm hidden states of ALL block rows (generation reads none; tests may)
+//   dyn      optional DEVICE {Lmax, q_row_min}: overrides the two host values (a step replayed from a hipGraph)
 int nv_decoder_extend(const nv_decoder* p, const void* x_in, const int* pos, const int* crow, const int* grow, const int* kv0,
                       void* attn_buf, float* lse, const int* last, void* hs_out, void* hs_all, int M, int B, int Lmax, int cap,
-                      int q_row_min, void* workspace, size_t workspace_bytes, void* stream) {
+                      int q_row_min, const int* dyn, void* workspace, size_t workspace_bytes, void* stream) {
     if (!p || !x_in || !pos || !crow || !grow || !kv0 || !attn_buf || !lse || !workspace || M <= 0 || B <= 0) return NV_ERR_ARG;
     if ((last == nullptr) != (hs_out == nullptr)) return NV_ERR_ARG;
     if (workspace_bytes < nv_decoder_workspace_bytes(p, M)) return NV_ERR_ARG;
@@ -124,16 +125,45 @@ int nv_decoder_extend(const nv_decoder* p, const void* x_in, const int* pos, con
     const void* x = x_in;
     int rc = NV_OK;
 #define NV_TRY(call) do { rc = (call); if (rc != NV_OK) return rc; } while (0)
+    // Few rows (decode steps, pruned tails): every Linear is a weight streamer and the row kernels fold into it (nv_gemv_pre:
+    // RMSNorm and the gather of the attention rows in the operand producer, SwiGLU in the gate|up epilogue; RoPE + cache scatter in one launch) --
+    // 6 launches per layer instead of 11.  NV_DECODER_FUSED=0 keeps the unfused sequence (A/B, and the parity test's reference).
+    const char* knob = getenv("NV_DECODER_FUSED");                   // read per call: the parity test flips it
+    const char* knob2 = getenv("NV_DECODE_ATTN");
+    // one new row per sample (M == B: row r is sample r): the streaming decode attention, output rows compact in `attn`
+    const bool dec_attn = !(knob2 && atoi(knob2) == 0) && M == B;
+    const bool fused = !(knob && atoi(knob) == 0) && M <= 16 && (d % 128) == 0 && (ff % 128) == 0;
     for (int i = 0; i < p->L; ++i) {
         const Layer& ly = p->layers[i];
         if (!ly.norm1 || !ly.norm2 || !ly.kv) return NV_ERR_ARG;
         void* x2 = outb[i & 1];                                       // != x (the previous layer wrote the other one) and != x1
+        if (fused) {
+            const int D = (int)d, F = (int)ff;
+            auto wq = [&](int k) { return ly.q[k] ? ly.q[k] : ly.w[k]; };
+            auto sq = [&](int k) { return ly.q[k] ? ly.s[k] : (const float*)nullptr; };
+            NV_TRY(nv_gemv_pre(x, nullptr, wq(0), sq(0), qkv, nullptr, M, 3 * D, D, D, D, 3 * D, 0, 1, ly.norm1, p->eps, 0, stream));
+            NV_TRY(nv_rope_scatter_rows_bf16(qkv, p->rope_cos, p->rope_sin, pos, crow, ly.kv, M, p->H, p->hd, 3 * D, stream));
+            if (dec_attn) NV_TRY(nv_attn_decode_bf16(ly.kv, crow, pos, attn, M, p->H, p->hd, cap, stream));
+            else if (dyn) NV_TRY(nv_attn_fwd_strided_dyn_bf16(ly.kv, attn_buf, lse, kv0, B, cap, p->H, p->hd, dyn, stream));
+            else NV_TRY(nv_attn_fwd_strided_bf16(ly.kv, attn_buf, lse, kv0, B, Lmax, cap, p->H, p->hd, q_row_min, stream));
+            NV_TRY(nv_gemv_pre(dec_attn ? attn : attn_buf, dec_attn ? nullptr : grow, wq(1), sq(1), x1, x, M, D, D, D, D, D, D, 0, nullptr, 0.f, 0,
+                               stream));                                                   // x1 = x + o_proj(attn rows)
+            NV_TRY(nv_gemv_pre(x1, nullptr, wq(2), sq(2), h, nullptr, M, 2 * F, D, D, D, F, 0, 1, ly.norm2, p->eps, 1, stream));   // h = SwiGLU
+            NV_TRY(nv_gemv_pre(h, nullptr, wq(3), sq(3), x2, x1, M, D, F, F, F, D, D, 0, nullptr, 0.f, 0, stream));        // x2 = x1 + down(h)
+            x = x2;
+            continue;
+        }
         NV_TRY(nv_rmsnorm_fwd_bf16(x, ly.norm1, n, rstd, M, (int)d, p->eps, stream));
         NV_TRY(linear(p, ly, 0, n, qkv, nullptr, M, 3 * (int)d, (int)d, stream));
         NV_TRY(nv_rope_rows_bf16(qkv, p->rope_cos, p->rope_sin, pos, M, p->H, p->hd, 3 * (int)d, stream));
         NV_TRY(nv_scatter_rows_bf16(qkv, crow, ly.kv, M, 3 * (int)d, stream));
-        NV_TRY(nv_attn_fwd_strided_bf16(ly.kv, attn_buf, lse, kv0, B, Lmax, cap, p->H, p->hd, q_row_min, stream));
-        NV_TRY(nv_gather_rows_bf16(attn_buf, grow, attn, M, (int)d, stream));
+        if (dec_attn) {
+            NV_TRY(nv_attn_decode_bf16(ly.kv, crow, pos, attn, M, p->H, p->hd, cap, stream));
+        } else {
+            if (dyn) NV_TRY(nv_attn_fwd_strided_dyn_bf16(ly.kv, attn_buf, lse, kv0, B, cap, p->H, p->hd, dyn, stream));
+            else NV_TRY(nv_attn_fwd_strided_bf16(ly.kv, attn_buf, lse, kv0, B, Lmax, cap, p->H, p->hd, q_row_min, stream));
+            NV_TRY(nv_gather_rows_bf16(attn_buf, grow, attn, M, (int)d, stream));
+        }
         NV_TRY(linear(p, ly, 1, attn, x1, x, M, (int)d, (int)d, stream));                    // x1 = x + o_proj(attn)
         NV_TRY(nv_rmsnorm_fwd_bf16(x1, ly.norm2, n, rstd, M, (int)d, p->eps, stream));
         NV_TRY(linear(p, ly, 2, n, gu, nullptr, M, 2 * (int)ff, (int)d, stream));
@@ -148,6 +178,30 @@ int nv_decoder_extend(const nv_decoder* p, const void* x_in, const int* pos, con
     }
 #undef NV_TRY
     return NV_OK;
+}
+
+// One greedy-decoding step with every decision on the device (decode_step.hip): lm_head on the B last hidden states -> masked
+// argmax + HF's finished/pad bookkeeping -> cache indices of the new token -> its embedding -> the L decoder layers over the
+// K/V cache -> the new last hidden states (written back to `hs`).  Launch arguments do not change from step to step: the call
+// is captured once into a hipGraph and replayed per token.
+//   hs [B,d] in/out;  embed [V.., d];  lm_head [Vp, d] (rows >= V unused);  logits [B, Vp] bf16 scratch;  x [B, d] scratch;
+//   state: nv_decode_state_ints(B) ints (tok|fin|len|pos|crow|grow|last|dyn|cnt);  out [max_steps, B] picked tokens
+int nv_decoder_greedy_step(const nv_decoder* p, void* hs, const void* embed, const void* lm_head, int Vp, int V, int special0, int nspecial,
+                           void* logits, void* x, int* state, int* out, int max_steps, const int* kv0, void* attn_buf, float* lse, int B,
+                           int cap, int eos, int pad, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!p || !hs || !embed || !lm_head || !logits || !x || !state || !out || !kv0 || !attn_buf || !lse || !workspace) return NV_ERR_ARG;
+    if (B <= 0 || Vp < V || V <= 0) return NV_ERR_ARG;
+    const int d = p->d;
+    int rc;
+    if (B <= 16 && (d & 31) == 0) rc = nv_gemv_bf16(hs, lm_head, logits, nullptr, B, Vp, d, d, d, Vp, Vp, 0, stream);
+    else rc = nv_gemm_bf16_ws(0, hs, lm_head, logits, nullptr, B, Vp, d, d, d, Vp, Vp, 0, 0, p->gemm_ws, stream);
+    if (rc != NV_OK) return rc;
+    if ((rc = nv_decode_pick_bf16(logits, Vp, V, special0, nspecial, state, out, max_steps, B, eos, pad, stream)) != NV_OK) return rc;
+    if ((rc = nv_decode_advance(state, B, cap, stream)) != NV_OK) return rc;
+    int* tok = state;
+    if ((rc = nv_gather_rows_bf16(embed, tok, x, B, d, stream)) != NV_OK) return rc;
+    return nv_decoder_extend(p, x, state + 3 * B, state + 4 * B, state + 5 * B, kv0, attn_buf, lse, state + 6 * B, hs, nullptr, B, B, cap, cap,
+                             0, state + 7 * B, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

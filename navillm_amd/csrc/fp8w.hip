@@ -250,6 +250,10 @@ int nv_gemv_fp8w(const void* A, const void* Wq, const float* scales, void* C, co
     if (M > 16 || (K & 63) || (lda & 7) || (ldw & 15) || ((((uintptr_t)A) | ((uintptr_t)Wq)) & 15)) return NV_ERR_SHAPE;
     if (epilogue != 0 && epilogue != 2) return NV_ERR_ARG;
     if (epilogue == 2 && !R) return NV_ERR_ARG;
+    {   // the full-line streamer (gemv_stream.hip) takes every shape of its fast path
+        const int rc = nvi_gemv_stream(A, Wq, scales, C, R, M, N, K, lda, ldw, ldc, ldr, epilogue == 2, 1, stream);
+        if (rc != NV_ERR_SHAPE) return rc;
+    }
     hipStream_t st = (hipStream_t)stream;
     static const int forced = [] { const char* e = getenv("NV_GEMV_NTILE"); return e ? atoi(e) : 0; }();   // measurement knob
     // measured (profiles/r02_gemv_probe.txt): two tiles per block win by 6..27 % whenever the grid keeps >= 160 blocks

@@ -108,6 +108,10 @@ int nv_gemv_bf16(const void* A, const void* W, void* C, const void* R, int M, in
     if (M > 16 || (K & 31) || (lda & 7) || (ldw & 7) || ((((uintptr_t)A) | ((uintptr_t)W)) & 15)) return NV_ERR_SHAPE;
     if (epilogue != 0 && epilogue != 2) return NV_ERR_ARG;
     if (epilogue == 2 && !R) return NV_ERR_ARG;
+    {   // the full-line streamer (gemv_stream.hip) takes every shape of its fast path
+        const int rc = nvi_gemv_stream(A, W, nullptr, C, R, M, N, K, lda, ldw, ldc, ldr, epilogue == 2, 0, stream);
+        if (rc != NV_ERR_SHAPE) return rc;
+    }
     const int nt = gemv_ntile(N, K);
     const dim3 grid((N + 16 * nt - 1) / (16 * nt)), block(GV_WAVES * 64);
     hipStream_t st = (hipStream_t)stream;

@@ -241,6 +241,50 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, con
     }
 }
 
+// RoPE of the new rows fused with their scatter into the K/V cache (decode / K/V-reuse steps: nv_rope_rows_bf16 followed by
+// nv_scatter_rows_bf16 in one launch): dst[rows[m], :] = [rope(q) | rope(k) | v] of src row m at position pos[m].  Same
+// arithmetic as rope_kernel (sign = +1); src is left untouched.
+__global__ __launch_bounds__(256) void rope_scatter_kernel(const bf16_t* __restrict__ src, const bf16_t* __restrict__ cos_t,
+                                                           const bf16_t* __restrict__ sin_t, const int* __restrict__ pos,
+                                                           const int* __restrict__ rows, bf16_t* __restrict__ dst, int M, int H, int hd,
+                                                           int ld) {
+    const int half = hd / 2;
+    const int per_head = half / 8;
+    const long n_rope = (long)M * 2 * H * per_head;                // q and k heads: pairs of 8-wide vectors
+    const int v_per_row = H * hd / 8;
+    const long total = n_rope + (long)M * v_per_row;               // + the v part: plain 16-B copies
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        if (i < n_rope) {
+            const int v = (int)(i % per_head);
+            long r = i / per_head;
+            const int head = (int)(r % (2 * H));
+            const int m = (int)(r / (2 * H));
+            const int s = pos[m];
+            const long off = (long)head * hd + v * 8;
+            const bf16_t* base = src + (long)m * ld + off;
+            bf16_t* out = dst + (long)rows[m] * ld + off;
+            float a[8], b[8], c[8], sn[8];
+            ld8(base, a);
+            ld8(base + half, b);
+            ld8(cos_t + (long)s * hd + v * 8, c);
+            ld8(sin_t + (long)s * hd + v * 8, sn);
+            float o1[8], o2[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o1[j] = rbf(a[j] * c[j]) + rbf(-1.f * b[j] * sn[j]);
+                o2[j] = rbf(b[j] * c[j]) + rbf(1.f * a[j] * sn[j]);
+            }
+            st8(out, o1);
+            st8(out + half, o2);
+        } else {
+            const long k = i - n_rope;
+            const int m = (int)(k / v_per_row), c = (int)(k % v_per_row) * 8;
+            const long off = 2L * H * hd + c;
+            *(u32x4*)(dst + (long)rows[m] * ld + off) = *(const u32x4*)(src + (long)m * ld + off);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- SwiGLU on packed gate|up
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + expf(-x)); }
 
@@ -442,6 +486,15 @@ int nv_rope_rows_bf16(void* qkv, const void* cos_t, const void* sin_t, const int
     if (M == 0) return NV_OK;
     NV_LAUNCH(rope_kernel, dim3(grid_for((long)M * 2 * H * hd / 16)), dim3(256), 0, (hipStream_t)stream,
                        (bf16_t*)qkv, (const bf16_t*)cos_t, (const bf16_t*)sin_t, pos, M, 1, H, hd, ld, 1.f);
+    return nv_check_launch();
+}
+
+int nv_rope_scatter_rows_bf16(const void* qkv, const void* cos_t, const void* sin_t, const int* pos, const int* rows, void* dst, int M, int H,
+                              int hd, int ld, void* stream) {
+    if (!qkv || !cos_t || !sin_t || !pos || !rows || !dst || (hd & 15) || ld != 3 * H * hd) return NV_ERR_ARG;
+    if (M == 0) return NV_OK;
+    NV_LAUNCH(rope_scatter_kernel, dim3(grid_for((long)M * (2 * H * hd / 16 + H * hd / 8))), dim3(256), 0, (hipStream_t)stream,
+              (const bf16_t*)qkv, (const bf16_t*)cos_t, (const bf16_t*)sin_t, pos, rows, (bf16_t*)dst, M, H, hd, ld);
     return nv_check_launch();
 }
 

@@ -164,3 +164,11 @@ static inline int nv_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? NV_OK : NV_ERR_LAUNCH;
 }
+
+// gemv_stream.hip: the decode-step weight streamer behind nv_gemv_bf16 / nv_gemv_fp8w (library-internal, not part of the C ABI).
+// Returns NV_ERR_SHAPE when the shape is outside its fast path (the callers then run their generic kernel).
+extern "C" __attribute__((visibility("hidden"))) int nvi_gemv_stream(const void* A, const void* W, const float* scales, void* C,
+                                                                    const void* R, int M, int N, int K, int lda, int ldw, int ldc,
+                                                                    int ldr, int resid, int fp8, void* stream);
+extern "C" int nv_gemv_pre(const void* A, const int* a_rows, const void* W, const float* scales, void* C, const void* R, int M, int N, int K,
+                           int lda, int ldw, int ldc, int ldr, int rmsnorm, const void* norm_w, float eps, int swiglu, void* stream);

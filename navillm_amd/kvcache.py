@@ -20,6 +20,7 @@ Everything arithmetic is a launch of the same HIP kernels as the training path (
 `nv_attn_fwd_strided_bf16`); there is no autograd here.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -28,6 +29,8 @@ from . import lib as _lib
 from . import ops
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+DEVICE_GREEDY = os.environ.get("NAVILLM_DEVICE_GREEDY", "1") != "0"      # greedy decoding with the loop on the device (no trie)
+USE_HIP_GRAPH = os.environ.get("NAVILLM_DECODE_GRAPH", "1") != "0"       # ... replayed from a captured hipGraph
 
 
 class KVCacheLM:
@@ -42,6 +45,7 @@ class KVCacheLM:
         self.lse = torch.empty((batch_size, cfg.num_heads, capacity), dtype=F32, device=dev)
         self.kv0 = torch.zeros((batch_size,), dtype=I32, device=dev)
         self._dec, self._dec_key, self._ws = None, None, None
+        self._greedy = None                                    # device-side decode loop: buffers + captured hipGraph
         self._key_ids = {}                                     # reuse key (hashable) -> small int
         self.reset()
 
@@ -170,7 +174,7 @@ class KVCacheLM:
         hs_all = torch.empty((M, d), dtype=BF16, device=dev) if want_all else None
         rc = L.nv_decoder_extend(dec, x.data_ptr(), pos_d.data_ptr(), crow_d.data_ptr(), grow_d.data_ptr(), self.kv0.data_ptr(),
                                  self.attn.data_ptr(), self.lse.data_ptr(), last_d.data_ptr(), hs.data_ptr(), ops._p(hs_all), M, B, Lmax, cap,
-                                 qmin, self._ws.data_ptr(), self._ws.numel(), ops._st())
+                                 qmin, None, self._ws.data_ptr(), self._ws.numel(), ops._st())
         _lib.check(rc, "nv_decoder_extend")
         self.state = new_state
         self.last_stats = {"prefix": P, "new": n, "block_rows": M}
@@ -198,10 +202,12 @@ class KVCacheLM:
         self.reset()
         seqs = [list(x) for x in ids_list]
         vix = None if vis_idx_list is None else [list(v) for v in vis_idx_list]
+        keys = None if vis_all is None else [("gen", r) for r in range(vis_all.shape[0])]   # constant within one call
+        if trie is None and DEVICE_GREEDY and max_new_tokens > 0 and max(len(x) for x in seqs) + max_new_tokens <= self.cap:
+            return self._generate_on_device(seqs, vix, vis_all, keys, max_new_tokens, eos_token_id, pad_token_id)
         out = [[] for _ in range(B)]
         unfinished = [True] * B
         nodes = [trie.root for _ in range(B)] if trie is not None else None
-        keys = None if vis_all is None else [("gen", r) for r in range(vis_all.shape[0])]   # constant within one call
         for step in range(max_new_tokens):
             Hs = self.extend(seqs, vix, vis_all, keys)
             lg = self.logits_last(Hs)
@@ -224,3 +230,96 @@ class KVCacheLM:
             if not any(unfinished):
                 break
         return out
+
+    # ------------------------------------------------------------------ greedy decoding with the loop on the device
+    def _greedy_state(self, max_steps):
+        """persistent buffers of the device loop (fixed addresses: the step is replayed from a hipGraph)"""
+        g = self._greedy
+        if g is not None and g["max_steps"] >= max_steps:
+            return g
+        m, cfg, dev, B = self.model, self.model.cfg, self.model.device, self.B
+        L = ops._L()
+        n = L.nv_decode_state_ints(B)
+        vp = m.store.vocab_pad
+        g = {"max_steps": max(max_steps, 64), "graph": None, "graph_key": None,
+             "state": torch.zeros((n,), dtype=I32, device=dev), "hs": torch.zeros((B, cfg.hidden_size), dtype=BF16, device=dev),
+             "x": torch.zeros((B, cfg.hidden_size), dtype=BF16, device=dev), "logits": torch.zeros((B, vp), dtype=BF16, device=dev),
+             "fin_host": torch.zeros((B,), dtype=I32).pin_memory()}
+        g["out"] = torch.zeros((g["max_steps"], B), dtype=I32, device=dev)
+        self._greedy = g
+        return g
+
+    def _greedy_step(self, g, eos, pad, stream):
+        m, cfg, st = self.model, self.model.cfg, self.model.store
+        sp = cfg.special_token_ids
+        rc = ops._L().nv_decoder_greedy_step(self._decoder(), g["hs"].data_ptr(), st.p("lang_model.model.embed_tokens.weight").data_ptr(),
+                                             st.lm_head_padded().data_ptr(), st.vocab_pad, cfg.vocab_size, sp[0], len(sp), g["logits"].data_ptr(),
+                                             g["x"].data_ptr(), g["state"].data_ptr(), g["out"].data_ptr(), g["max_steps"], self.kv0.data_ptr(),
+                                             self.attn.data_ptr(), self.lse.data_ptr(), self.B, self.cap, eos, pad, self._ws.data_ptr(),
+                                             self._ws.numel(), stream)
+        _lib.check(rc, "nv_decoder_greedy_step")
+
+    @torch.no_grad()
+    def _generate_on_device(self, seqs, vix, vis_all, keys, max_new_tokens, eos, pad):
+        """prefill through `extend` (host-built indices, once), then max_new_tokens replays of ONE captured step
+        (nv_decoder_greedy_step: lm_head -> masked argmax + finished/pad bookkeeping -> cache indices -> embedding -> decoder layers).
+        The host never waits for a token: it polls the `fin` flags two steps behind and trims the output where HF would have stopped."""
+        B, dev = self.B, self.model.device
+        g = self._greedy_state(max_new_tokens)
+        L = ops._L()
+        need = L.nv_decoder_workspace_bytes(self._decoder(), B)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        if USE_HIP_GRAPH and g["graph"] is None:
+            # one eager step on a scratch state BEFORE the prefill: the kernels' first-use initialisation (hipFuncSetAttribute, device
+            # queries) must not happen inside a stream capture.  It writes cache row 0 of every sample, which the prefill rewrites.
+            g["state"].zero_()
+            self._greedy_step(g, eos, pad, ops._st())
+        Hs = self.extend(seqs, vix, vis_all, keys)
+        n = g["state"].numel()
+        init = np.zeros(n, np.int32)
+        init[2 * B:3 * B] = [len(x) for x in seqs]
+        g["state"].copy_(ops.h2d(torch.from_numpy(init), dev))
+        g["hs"].copy_(Hs)
+        key = (self._dec_key, self._ws.data_ptr(), eos, pad, g["out"].data_ptr())
+        if USE_HIP_GRAPH and g["graph_key"] != key:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                self._greedy_step(g, eos, pad, torch.cuda.current_stream().cuda_stream)
+            g["graph"], g["graph_key"] = graph, key            # capture enqueues nothing: the first replay is step 0
+        events = []
+        steps = 0
+        for t in range(max_new_tokens):
+            if USE_HIP_GRAPH:
+                g["graph"].replay()
+            else:
+                self._greedy_step(g, eos, pad, ops._st())
+            steps += 1
+            if len(events) >= 2:                               # flags as of two steps ago: the host stays ahead of the GPU
+                ev, snap = events.pop(0)
+                ev.synchronize()
+                if bool(snap.all()):
+                    break
+            snap = torch.empty((B,), dtype=I32).pin_memory()
+            snap.copy_(g["state"][B:2 * B], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            events.append((ev, snap))
+        toks = g["out"][:steps].cpu().numpy()                  # [steps, B]; syncs
+        # HF stops after the step in which the last unfinished row emitted eos: trim the steps the lagging poll let through
+        fin = np.zeros(B, bool)
+        keep = steps
+        for t in range(steps):
+            fin |= toks[t] == eos
+            if fin.all():
+                keep = t + 1
+                break
+        toks = toks[:keep]
+        lens = g["state"][2 * B:3 * B].cpu().numpy()
+        # the cache now also holds the generated tokens (all `steps` of them): record it so a later extend() reuses / overwrites correctly
+        full = g["out"][:steps].cpu().numpy()
+        self.state = [(np.concatenate([np.asarray(seqs[b], np.int64), full[:, b].astype(np.int64)])[:int(lens[b])],
+                       np.concatenate([self.state[b][1], np.zeros(steps, np.int64)])[:int(lens[b])]) for b in range(B)]
+        return [toks[:, b].tolist() for b in range(B)]

@@ -43,6 +43,8 @@ SIGNATURES = {
     "nv_scatter_rows_bf16": (i, [vp, ip, vp, i, i, vp]),
     "nv_attn_fwd_bf16": (i, [vp, vp, fp, ip, i, i, i, i, i, vp]),
     "nv_attn_fwd_strided_bf16": (i, [vp, vp, fp, ip, i, i, i, i, i, i, vp]),
+    "nv_attn_decode_bf16": (i, [vp, ip, ip, vp, i, i, i, i, vp]),
+    "nv_attn_fwd_strided_dyn_bf16": (i, [vp, vp, fp, ip, i, i, i, i, ip, vp]),
     "nv_attn_fwd_varlen_bf16": (i, [vp, vp, fp, ip, ip, i, i, i, i, i, vp]),
     "nv_attn_fwd_hfround_bf16": (i, [vp, vp, fp, ip, ip, i, i, i, i, i, vp]),
     "nv_attn_bwd_strided_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, i, i, vp]),
@@ -96,7 +98,13 @@ SIGNATURES = {
     "nv_decoder_set_layer": (i, [vp, i, vp, vp, vp]),
     "nv_decoder_set_shared": (i, [vp, vp, vp, vp, vp, vp]),
     "nv_decoder_workspace_bytes": (sz, [vp, i]),
-    "nv_decoder_extend": (i, [vp, vp, ip, ip, ip, ip, vp, fp, ip, vp, vp, i, i, i, i, i, vp, sz, vp]),
+    "nv_decoder_extend": (i, [vp, vp, ip, ip, ip, ip, vp, fp, ip, vp, vp, i, i, i, i, i, ip, vp, sz, vp]),
+    "nv_gemv_pre": (i, [vp, ip, vp, fp, vp, vp, i, i, i, i, i, i, i, i, vp, f, i, vp]),
+    "nv_rope_scatter_rows_bf16": (i, [vp, vp, vp, ip, ip, vp, i, i, i, i, vp]),
+    "nv_decode_state_ints": (i, [i]),
+    "nv_decode_pick_bf16": (i, [vp, i, i, i, i, ip, ip, i, i, i, i, vp]),
+    "nv_decode_advance": (i, [ip, i, i, vp]),
+    "nv_decoder_greedy_step": (i, [vp, vp, vp, vp, i, i, i, i, vp, vp, ip, ip, i, ip, vp, fp, i, i, i, i, vp, sz, vp]),
     # data-parallel exchange over RCCL (nv_ctx* travels as void*)
     "nv_comm_unique_id_bytes": (i, []),
     "nv_comm_unique_id": (i, [vp]),

@@ -36,7 +36,9 @@ def test_fp8_decode_and_quantiser_are_bit_exact_vs_torch_float8():
     assert torch.equal(q.cpu(), qo.view(torch.uint8)) and torch.equal(s.cpu(), so)
 
 
-@pytest.mark.parametrize("M,N,K,resid", [(8, 512, 256, False), (3, 1000, 1408, True), (16, 13824, 5120, True), (1, 64, 64, False)])
+@pytest.mark.parametrize("M,N,K,resid", [(8, 512, 256, False), (3, 1000, 1408, True), (16, 13824, 5120, True), (1, 64, 64, False),
+                                         (8, 27648, 5120, False), (5, 5120, 13824, True), (12, 22016, 4096, False), (8, 4096, 4096, True),
+                                         (2, 8, 128, False)])
 def test_gemv_fp8w_matches_dequantised_gemm(M, N, K, resid):
     """decode-step weight streamer on the codes == bf16 GEMM on the de-quantised operand == fp32 reference within one rounding"""
     from navillm_amd import fp8, ops

@@ -498,7 +498,8 @@ def test_gemm_swiglu_bwd_epilogue_equals_two_pass(M, ff, d, tile):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K,resid", [(8, 4096, 4096, False), (8, 1000, 256, True), (1, 22016, 4096, False), (16, 4112, 11008, True),
-                                         (3, 100, 64, False)])
+                                         (3, 100, 64, False), (12, 22016, 4096, True), (5, 27648, 5120, False), (8, 12288, 4096, True),
+                                         (9, 8, 64, False), (7, 15360, 5120, False)])
 def test_gemv_bf16_matches_reference(M, N, K, resid):
     """the decode-step weight streamer against a torch fp32 reference (and it is what ops.gemm_bf16 picks for M <= 16)"""
     from navillm_amd import ops

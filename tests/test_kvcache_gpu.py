@@ -201,3 +201,245 @@ def test_generation_modes_return_sentences():
     assert len(out["generated_sentences"]) == B and all(1 <= len(x) <= 6 for x in out["generated_ids"])
     with pytest.raises(NotImplementedError):
         m("3dqa", {"features": feats, "question": ["q"] * B, "input_ids": ids_t, "attention_mask": am}, training=False, do_sample=True)
+
+
+def test_decode_pick_and_advance_kernels_vs_torch():
+    """nv_decode_pick_bf16 (masked argmax, first index on ties, HF's finished/pad bookkeeping) and nv_decode_advance (cache
+    indices, dyn = {max len + 1, 128-aligned min len}) against the same arithmetic in torch"""
+    from navillm_amd import ops, lib
+    L = ops._L()
+    B, V, Vp, cap, eos, pad = 5, 1006, 1024, 512, 2, 1005
+    sp0, nsp = 1000, 5
+    g = torch.Generator().manual_seed(3)
+    lg = (torch.randn(B, Vp, generator=g) * 2).to(torch.bfloat16)
+    lg[0, 1001] = 50.0                       # a special id holds the maximum: must be skipped
+    lg[1, 1010] = 60.0                       # beyond the vocabulary
+    lg[2, 7] = lg[2, 300] = lg[2, 650] = 40.0   # ties -> smallest id
+    lg[3, eos] = 70.0                        # finishes now
+    lgd = lg.to(DEV)
+    n = L.nv_decode_state_ints(B)
+    st = torch.zeros(n, dtype=torch.int32)
+    st[B + 4] = 1                            # sample 4 finished earlier -> pad
+    lens = torch.tensor([130, 257, 300, 128, 140], dtype=torch.int32)
+    st[2 * B:3 * B] = lens
+    st[7 * B + 2] = 1                        # second step
+    std = st.to(DEV)
+    out = torch.full((4, B), -1, dtype=torch.int32, device=DEV)
+    lib.check(L.nv_decode_pick_bf16(lgd.data_ptr(), Vp, V, sp0, nsp, std.data_ptr(), out.data_ptr(), 4, B, eos, pad, ops._st()), "pick")
+    lib.check(L.nv_decode_advance(std.data_ptr(), B, cap, ops._st()), "advance")
+    torch.cuda.synchronize()
+    ref = lg.float()[:, :V].clone()
+    ref[:, sp0:sp0 + nsp] = float("-inf")
+    want = ref.argmax(-1).tolist()
+    assert want[2] == 7
+    want[4] = pad
+    s = std.cpu()
+    assert s[:B].tolist() == want and out[1].tolist() == want and out[0].tolist() == [-1] * B
+    assert s[B:2 * B].tolist() == [0, 0, 0, 1, 1]
+    assert s[2 * B:3 * B].tolist() == (lens + 1).tolist() and s[3 * B:4 * B].tolist() == lens.tolist()
+    assert s[4 * B:5 * B].tolist() == [b * cap + int(lens[b]) for b in range(B)] == s[5 * B:6 * B].tolist()
+    assert s[6 * B:7 * B].tolist() == list(range(B))
+    assert s[7 * B:7 * B + 3].tolist() == [301, 128, 2]
+
+
+def test_attention_with_device_side_lengths_equals_static_launch():
+    from navillm_amd import ops, lib
+    L = ops._L()
+    B, H, hd, cap, S, qmin = 3, 4, 128, 512, 300, 256
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B * cap + 1, 3 * H * hd, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    kv0 = torch.zeros(B, dtype=torch.int32, device=DEV)
+    outs = []
+    for dyn in (False, True):
+        out = torch.zeros(B * cap, H * hd, dtype=torch.bfloat16, device=DEV)
+        lse = torch.zeros(B, H, cap, dtype=torch.float32, device=DEV)
+        if dyn:
+            d = torch.tensor([S, qmin], dtype=torch.int32, device=DEV)
+            lib.check(L.nv_attn_fwd_strided_dyn_bf16(qkv.data_ptr(), out.data_ptr(), lse.data_ptr(), kv0.data_ptr(), B, cap, H, hd, d.data_ptr(),
+                                                     ops._st()), "attn dyn")
+        else:
+            ops.attn_fwd_strided(qkv, kv0, B, S, cap, H, hd, out, lse, q_row_min=qmin)
+        torch.cuda.synchronize()
+        outs.append((out.cpu(), lse.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0].view(B, cap, -1)[:, qmin:S].abs().sum() > 0 and outs[0][0].view(B, cap, -1)[:, :qmin].abs().sum() == 0
+
+
+def test_device_side_greedy_loop_equals_host_loop(monkeypatch):
+    """greedy decoding with the choice + bookkeeping on the device and the step replayed from a hipGraph == the host loop
+    (token for token, early eos / pad rows included); the captured graph is reused by a second call"""
+    import navillm_amd.kvcache as kvm
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.kvcache import KVCacheLM
+    cfg = _mid_cfg(layers=3)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=11)
+    m.eval()
+    B = 4
+    ids_t, am, cand, hist = _gen_case(cfg, B, 321)
+    ids_l, vix_l, vis_all, _ = m._vis_layout(ids_t, am, cand.to(DEV), hist.to(DEV), None)
+    pad = 0
+    runs = {}
+    monkeypatch.setattr(kvm, "DEVICE_GREEDY", False)
+    kv = KVCacheLM(m, B, capacity=256)
+    free = kv.generate(ids_l, vix_l, vis_all, max_new_tokens=12, eos_token_id=-7, pad_token_id=pad)
+    assert all(len(x) == 12 for x in free)
+    eos = free[1][2]                          # sample 1 (at least) finishes at its third token
+    for tag, dev_loop, graph in (("host", False, False), ("device", True, False), ("graph", True, True)):
+        monkeypatch.setattr(kvm, "DEVICE_GREEDY", dev_loop)
+        monkeypatch.setattr(kvm, "USE_HIP_GRAPH", graph)
+        kv = KVCacheLM(m, B, capacity=256)
+        a = kv.generate(ids_l, vix_l, vis_all, max_new_tokens=12, eos_token_id=eos, pad_token_id=pad)
+        b = kv.generate(ids_l, vix_l, vis_all, max_new_tokens=12, eos_token_id=eos, pad_token_id=pad)      # graph reuse
+        c = kv.generate(ids_l, vix_l, vis_all, max_new_tokens=5, eos_token_id=-7, pad_token_id=pad)
+        runs[tag] = (a, b, c)
+        assert a == b
+        # the cache bookkeeping stays consistent: a following extend() of prompt + generated tokens reuses everything but the last token
+        seqs = [list(ids_l[i]) + c[i] for i in range(B)]
+        vix = [list(vix_l[i]) + [-1] * len(c[i]) for i in range(B)]
+        keys = [("gen", r) for r in range(vis_all.shape[0])]
+        kv.extend(seqs, vix, vis_all, keys)
+        if dev_loop:
+            assert kv.last_stats["new"] == [1] * B, kv.last_stats
+    print("host  :", runs["host"][0])
+    print("graph :", runs["graph"][0])
+    assert runs["host"] == runs["device"] == runs["graph"]
+    assert pad in runs["host"][0][1] or len(runs["host"][0][1]) == 3
+
+
+@pytest.mark.parametrize("fp8w", [False, True])
+@pytest.mark.parametrize("M", [1, 8, 13])
+def test_gemv_pre_modes_equal_the_unfused_kernels_bit_for_bit(M, fp8w):
+    """nv_gemv_pre (RMSNorm / SwiGLU / row gather folded into the weight streamer) == the row kernel followed by the plain GEMV"""
+    from navillm_amd import ops, lib, fp8
+    L = ops._L()
+    d, ff = 512, 1408
+    g = torch.Generator().manual_seed(17 + M)
+    x = (torch.randn(M, d, generator=g) * 1.3).to(torch.bfloat16).to(DEV)
+    nw = (1 + 0.1 * torch.randn(d, generator=g)).to(torch.bfloat16).to(DEV)
+    W1 = (torch.randn(2 * ff, d, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    W2 = (torch.randn(d, ff, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    R = torch.randn(M, d, generator=g).to(torch.bfloat16).to(DEV)
+    q1 = fp8.quantize_rows(W1) if fp8w else None
+    q2 = fp8.quantize_rows(W2) if fp8w else None
+
+    def pre(A, rows, W, q, N, K, lda, R=None, norm=None, swiglu=False):
+        out = torch.empty(M, N // 2 if swiglu else N, dtype=torch.bfloat16, device=DEV)
+        Wp, sp = (q[0].data_ptr(), q[1].data_ptr()) if q is not None else (W.data_ptr(), None)
+        lib.check(L.nv_gemv_pre(A.data_ptr(), ops._p(rows), Wp, sp, out.data_ptr(), ops._p(R), M, N, K, lda, K, out.shape[1],
+                                N if R is not None else 0, int(norm is not None), ops._p(norm), 1e-6, int(swiglu), ops._st()), "nv_gemv_pre")
+        return out
+
+    def plain(A, W, q, R=None):
+        if q is not None:
+            return fp8.gemv_fp8w(A, q[0], q[1], R=R, epilogue=ops.EPI_RESID if R is not None else ops.EPI_STORE)
+        return ops.gemm_bf16(ops.NT, A, W, R=R, epilogue=ops.EPI_RESID if R is not None else ops.EPI_STORE)
+
+    def norm_of(t):
+        n = ops.rmsnorm_fwd(t, nw, 1e-6)
+        return n[0] if isinstance(n, tuple) else n
+
+    # RMSNorm -> gate|up
+    gu = plain(norm_of(x), W1, q1)
+    got = pre(x, None, W1, q1, 2 * ff, d, d, norm=nw)
+    assert torch.equal(got.view(torch.int16), gu.view(torch.int16)), (got.float() - gu.float()).abs().max()
+    # RMSNorm -> gate|up -> SwiGLU in the epilogue (gate|up never stored)
+    h = ops.swiglu_fwd(gu)
+    got_h = pre(x, None, W1, q1, 2 * ff, d, d, norm=nw, swiglu=True)
+    assert torch.equal(got_h.view(torch.int16), h.view(torch.int16)), (got_h.float() - h.float()).abs().max()
+    # down (+ residual) on it
+    assert torch.equal(pre(h, None, W2, q2, d, ff, ff, R=R).view(torch.int16), plain(h, W2, q2, R=R).view(torch.int16))
+    # gathered rows (+ RMSNorm over gathered rows)
+    big = (torch.randn(40, d, generator=g)).to(torch.bfloat16).to(DEV)
+    rows = torch.randperm(40, generator=g)[:M].to(torch.int32).to(DEV)
+    sel = ops.gather_rows_bf16(big, rows)
+    W3 = W1[:d].contiguous()
+    q3 = fp8.quantize_rows(W3) if fp8w else None
+    assert torch.equal(pre(big, rows, W3, q3, d, d, d, R=R).view(torch.int16), plain(sel, W3, q3, R=R).view(torch.int16))
+    assert torch.equal(pre(big, rows, W3, q3, d, d, d, norm=nw).view(torch.int16), plain(norm_of(sel), W3, q3).view(torch.int16))
+
+
+def test_rope_scatter_equals_rope_then_scatter():
+    from navillm_amd import ops, lib
+    L = ops._L()
+    M, H, hd, rows_dst = 11, 4, 128, 64
+    g = torch.Generator().manual_seed(23)
+    qkv = torch.randn(M, 3 * H * hd, generator=g).to(torch.bfloat16).to(DEV)
+    pos = torch.randint(0, 500, (M,), generator=g).to(torch.int32).to(DEV)
+    rows = torch.randperm(rows_dst, generator=g)[:M].to(torch.int32).to(DEV)
+    inv = 1.0 / (10000 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    emb = torch.cat([torch.outer(torch.arange(512).float(), inv)] * 2, -1)
+    cos_t, sin_t = emb.cos().to(torch.bfloat16).to(DEV).contiguous(), emb.sin().to(torch.bfloat16).to(DEV).contiguous()
+    want = torch.zeros(rows_dst, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+    a = qkv.clone()
+    ops.rope_rows_(a, cos_t, sin_t, pos, H, hd)
+    ops.scatter_rows_bf16_(a, rows, want)
+    got = torch.zeros_like(want)
+    lib.check(L.nv_rope_scatter_rows_bf16(qkv.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), pos.data_ptr(), rows.data_ptr(), got.data_ptr(),
+                                          M, H, hd, 3 * H * hd, ops._st()), "rope_scatter")
+    torch.cuda.synchronize()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("fp8w", [False, True])
+def test_fused_decode_layers_equal_the_unfused_sequence(monkeypatch, fp8w):
+    """nv_decoder_extend with <= 16 new rows: 6 fused launches per layer == the 11-launch sequence, bit for bit (hidden states of
+    all rows and the cache contents), bf16 and weight-only fp8"""
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.kvcache import KVCacheLM
+    cfg = _mid_cfg(layers=3)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=13)
+    m.eval()
+    if fp8w:
+        m.to_fp8_weight_only()
+    B = 4
+    g = torch.Generator().manual_seed(2)
+    prompt = [torch.randint(3, cfg.base_vocab_size, (50 + 7 * b,), generator=g).tolist() for b in range(B)]
+    more = [p + torch.randint(3, cfg.base_vocab_size, (1 + (b % 3),), generator=g).tolist() for b, p in enumerate(prompt)]
+    res = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("NV_DECODER_FUSED", fused)
+        kv = KVCacheLM(m, B, capacity=128)
+        kv.extend(prompt)
+        hs_all, _ = kv.extend(more, return_rows="all")
+        assert kv.last_stats["block_rows"] <= 16
+        torch.cuda.synchronize()
+        res[fused] = (hs_all.clone(), [q.clone() for q in kv.qkv])
+    assert torch.equal(res["0"][0].view(torch.int16), res["1"][0].view(torch.int16))
+    for a, b in zip(res["0"][1], res["1"][1]):
+        assert torch.equal(a[:-1].view(torch.int16), b[:-1].view(torch.int16))      # (the last row is the junk row)
+
+
+@pytest.mark.parametrize("lens", [[1, 5, 64, 65], [300, 129, 511, 512, 17, 256, 640, 1000]])
+def test_decode_attention_vs_fp32_reference_and_tile_kernel(lens):
+    """nv_attn_decode_bf16 (one query per sample, streaming) against softmax(q k^T / sqrt(d)) v in fp32 on the same bf16 cache, and
+    against the tile kernel's row (which rounds P to bf16): both within bf16 output noise"""
+    from navillm_amd import ops, lib
+    L = ops._L()
+    B, H, hd, cap = len(lens), 4, 128, 1024
+    g = torch.Generator().manual_seed(41)
+    qkv = (torch.randn(B * cap + 1, 3 * H * hd, generator=g)).to(torch.bfloat16)
+    qkv[:, H * hd:2 * H * hd] *= 0.6
+    qd = qkv.to(DEV)
+    pos = torch.tensor([n - 1 for n in lens], dtype=torch.int32).to(DEV)
+    crow = torch.tensor([b * cap + lens[b] - 1 for b in range(B)], dtype=torch.int32).to(DEV)
+    out = torch.zeros(B, H * hd, dtype=torch.bfloat16, device=DEV)
+    lib.check(L.nv_attn_decode_bf16(qd.data_ptr(), crow.data_ptr(), pos.data_ptr(), out.data_ptr(), B, H, hd, cap, ops._st()), "decode attn")
+    torch.cuda.synchronize()
+    got = out.float().cpu().view(B, H, hd)
+    ref = torch.zeros(B, H, hd)
+    for b in range(B):
+        rows = qkv[b * cap:b * cap + lens[b]].float().view(lens[b], 3, H, hd)
+        q = rows[-1, 0]                                           # [H, hd]
+        k, v = rows[:, 1], rows[:, 2]                              # [L, H, hd]
+        s = torch.einsum("hd,lhd->hl", q, k) / hd ** 0.5
+        ref[b] = torch.einsum("hl,lhd->hd", torch.softmax(s, -1), v)
+    err = (got - ref).abs().max().item()
+    assert err <= 2 ** -8 * max(1.0, ref.abs().max().item()) * 1.01, err
+    # the tile kernel on the same cache
+    Lmax = max(lens)
+    tile = torch.zeros(B * cap, H * hd, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(B, H, cap, dtype=torch.float32, device=DEV)
+    ops.attn_fwd_strided(qd, torch.zeros(B, dtype=torch.int32, device=DEV), B, Lmax, cap, H, hd, tile, lse, q_row_min=0)
+    torch.cuda.synchronize()
+    trow = torch.stack([tile[b * cap + lens[b] - 1] for b in range(B)]).float().cpu().view(B, H, hd)
+    assert (got - trow).abs().max().item() <= 2 ** -6 * max(1.0, ref.abs().max().item())

@@ -15,7 +15,7 @@ def main():
     for name, s, e in rows:
         n = name.replace("(anonymous namespace)::", "")
         m = re.match(r"(void )?([\w:]+)(<[^(]*>)?", n)
-        key = (m.group(2) + (m.group(3) or "")) if "gemm_bf16" in n else m.group(2)
+        key = (m.group(2) + (m.group(3) or "")) if ("gemm_bf16" in n or "gemv_stream" in n) else m.group(2)
         a = agg[key[:110]]
         d = (e - s) / 1e3
         a[0] += 1
