@@ -193,17 +193,20 @@ class KVCacheLM:
 
     @torch.no_grad()
     def generate(self, ids_list, vis_idx_list=None, vis_all=None, max_new_tokens=50, eos_token_id=2, pad_token_id=0,
-                 trie=None):
+                 trie=None, do_sample=False, temperature=1.0, top_k=50):
         """Greedy decoding with HF's bookkeeping (`generate(do_sample=False)`): finished rows emit `pad_token_id`, the
         loop ends when every row has produced `eos_token_id` or after `max_new_tokens`.  `trie` (tools/trie.py protocol:
         `.root`, `.get_child_index(node)`, `.get_next_node(node, w)`) constrains each step like TrieLogitsProcessor.
+        do_sample=True (tasks/agents/llava.py:58-62 forwards `--do_sample --temperature`): HF's `sample()` -- after the mask and
+        the trie, logits / temperature, the default top-k (50) warper, softmax, one multinomial draw per row from torch's CUDA
+        generator (same distribution as the reference; the streams of two RNG implementations cannot be compared draw by draw).
         Returns B lists with the new tokens only."""
         B = self.B
         self.reset()
         seqs = [list(x) for x in ids_list]
         vix = None if vis_idx_list is None else [list(v) for v in vis_idx_list]
         keys = None if vis_all is None else [("gen", r) for r in range(vis_all.shape[0])]   # constant within one call
-        if trie is None and DEVICE_GREEDY and max_new_tokens > 0 and max(len(x) for x in seqs) + max_new_tokens <= self.cap:
+        if trie is None and not do_sample and DEVICE_GREEDY and max_new_tokens > 0 and max(len(x) for x in seqs) + max_new_tokens <= self.cap:
             return self._generate_on_device(seqs, vix, vis_all, keys, max_new_tokens, eos_token_id, pad_token_id)
         out = [[] for _ in range(B)]
         unfinished = [True] * B
@@ -218,7 +221,15 @@ class KVCacheLM:
                 for b in range(B):
                     allow[b, trie.get_child_index(nodes[b])] = True
                 lg = lg.masked_fill(ops.h2d(allow.logical_not(), lg.device), float("-inf"))
-            nxt = torch.argmax(lg, dim=-1).tolist()
+            if do_sample:
+                if temperature != 1.0:
+                    lg = lg / temperature
+                if top_k and top_k < lg.shape[-1]:
+                    kth = torch.topk(lg, top_k, dim=-1).values[:, -1:]
+                    lg = lg.masked_fill(lg < kth, float("-inf"))
+                nxt = torch.multinomial(torch.softmax(lg, dim=-1), 1).view(-1).tolist()
+            else:
+                nxt = torch.argmax(lg, dim=-1).tolist()
             for b in range(B):
                 t = nxt[b] if unfinished[b] else pad_token_id
                 out[b].append(t)

@@ -532,11 +532,11 @@ class NavModel(nn.Module):
         return self.kv.extend(ids_l, vix_l, vis_all, keys)
 
     @torch.no_grad()
-    def _generate(self, ids_cpu, am_cpu, cand_vis, hist_vis, max_new_tokens=20, trie=None, do_sample=False, **unused):
-        """`self.lang_model.generate(...)` of nav_model.py:324-341,388-402: greedy, eos-terminated, pad = unk, special
-        ids masked, optional trie; served by the K/V-cache decoder (navillm_amd/kvcache.py)."""
-        if do_sample:
-            raise NotImplementedError("sampling (do_sample=True) is not built; the reference's eval configs decode greedily")
+    def _generate(self, ids_cpu, am_cpu, cand_vis, hist_vis, max_new_tokens=20, trie=None, do_sample=False, temperature=1.0,
+                  top_k=50, **unused):
+        """`self.lang_model.generate(...)` of nav_model.py:324-341,388-402: eos-terminated, pad = unk, special ids masked,
+        optional trie; greedy, or HF's sampling when the caller forwards `do_sample` / `temperature` (llava.py:58-62); served by
+        the K/V-cache decoder (navillm_amd/kvcache.py)."""
         from .kvcache import KVCacheLM
         B, S = ids_cpu.shape
         need = S + max_new_tokens
@@ -547,7 +547,7 @@ class NavModel(nn.Module):
         eos = getattr(tok, "eos_token_id", None)
         pad = getattr(tok, "unk_token_id", None)
         gen = kv.generate(ids_l, vix_l, vis_all, max_new_tokens=max_new_tokens, eos_token_id=2 if eos is None else eos,
-                          pad_token_id=0 if pad is None else pad, trie=trie)
+                          pad_token_id=0 if pad is None else pad, trie=trie, do_sample=do_sample, temperature=temperature, top_k=top_k)
         kv.reset()
         out = {"generated_ids": gen}
         if hasattr(tok, "batch_decode"):

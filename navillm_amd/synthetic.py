@@ -274,8 +274,11 @@ class SyntheticEpisodes:
             self.gmaps[b].update_graph(self.obs[b])
 
 
-def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accum=1, final=None):
+def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accum=1, final=None, feedback=None, temperature=1.0):
     """One iteration of the rollout loop for all B episodes. Returns (loss tensor or None, logits).
+    feedback: how the next viewpoint is chosen (mp3d_agent.py:759-772): 'teacher' (default when training), 'argmax' (default
+    otherwise) or 'sample' = one draw from Categorical(softmax(logits / temperature)), as the REVERIE / SOON evaluation scripts
+    run it (`--do_sample --temperature 0.01`).
     last: the episode's last step (mp3d_agent.py:661-676: every earlier step runs inside `no_sync`).
     final: this step's backward is the LAST one before the optimizer step (default: `last`); a `NavDataParallel` wrapper then
     exchanges the accumulated gradients from inside it, overlapped (navillm_amd/parallel.py)."""
@@ -302,9 +305,16 @@ def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accu
         if train:
             loss = criterion(logits, ops.h2d(targets, logits.device)) * loss_weight / ep.B / accum
             loss.backward()
+        feedback = feedback or ("teacher" if train else "argmax")
+        if feedback == "teacher":
             actions = targets
+        elif feedback == "sample":
+            probs = torch.softmax(logits.detach() / temperature, 1).float()
+            actions = torch.distributions.Categorical(probs).sample().cpu()
+        elif feedback == "argmax":
+            actions = logits.detach().float().argmax(1).cpu()
         else:
-            actions = logits.float().argmax(1).cpu()
+            raise NotImplementedError(feedback)
         ep.advance(nav, actions, out["fuse_embeds"])
     return loss, logits
 

@@ -199,8 +199,43 @@ def test_generation_modes_return_sentences():
     out = m("3dqa", {"features": feats, "question": ["q"] * B, "input_ids": ids_t, "attention_mask": am}, training=False,
             max_new_tokens=6, do_sample=False, temperature=1.0)
     assert len(out["generated_sentences"]) == B and all(1 <= len(x) <= 6 for x in out["generated_ids"])
+    batch = {"features": feats, "question": ["q"] * B, "input_ids": ids_t, "attention_mask": am}
+    # sampling (llava.py:58-62 forwards --do_sample / --temperature): temperature -> 0 reproduces greedy decoding; at T = 1 the draws
+    # differ between seeds, stay inside the vocabulary minus the special ids, and are reproducible from torch's generator
+    cold = m("3dqa", batch, training=False, max_new_tokens=6, do_sample=True, temperature=1e-4)
+    assert cold["generated_ids"] == out["generated_ids"]
+    draws = []
+    for seed in (1, 1, 2, 3):
+        torch.manual_seed(seed)
+        draws.append(m("3dqa", batch, training=False, max_new_tokens=6, do_sample=True, temperature=1.0)["generated_ids"])
+    assert draws[0] == draws[1] and (draws[0] != draws[2] or draws[0] != draws[3])
+    special = set(cfg.special_token_ids)
+    assert all(0 <= t < cfg.vocab_size and t not in special for d in draws for row in d for t in row)
+
+
+def test_nav_step_feedback_modes():
+    """mp3d_agent.py:759-772: argmax / sample (Categorical(softmax(logits / T))) / teacher action selection in the rollout driver"""
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.losses import CrossEntropyLoss
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step
+    cfg = _mid_cfg(layers=1)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=3)
+    m.eval()
+    crit = CrossEntropyLoss()
+    hist = {}
+    for tag, kw in (("argmax", {}), ("cold", dict(feedback="sample", temperature=1e-4)), ("hot", dict(feedback="sample", temperature=50.0))):
+        ep = SyntheticEpisodes(cfg, 4, seed=5, instr_len=40, device=torch.device(DEV))
+        torch.manual_seed(0)
+        pos = []
+        with torch.no_grad():
+            for t in range(4):
+                nav_step(m, crit, ep, train=False, **kw)
+                pos.append(list(ep.cur))
+        hist[tag] = pos
+    assert hist["argmax"] == hist["cold"]                 # T -> 0: the sample is the argmax
+    assert hist["hot"] != hist["argmax"]                  # T large: (nearly) uniform over the candidates
     with pytest.raises(NotImplementedError):
-        m("3dqa", {"features": feats, "question": ["q"] * B, "input_ids": ids_t, "attention_mask": am}, training=False, do_sample=True)
+        nav_step(m, crit, SyntheticEpisodes(cfg, 4, seed=5, instr_len=40, device=torch.device(DEV)), train=False, feedback="beam")
 
 
 def test_decode_pick_and_advance_kernels_vs_torch():
