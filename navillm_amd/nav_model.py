@@ -9,7 +9,7 @@ tokenisation, vpid matching (nav_model.py:174-190), candidate permutation (:216-
 
 Inference extras (SURVEY.md §8f): `enable_kv_cache()` = prompt-prefix K/V reuse across no-grad navigation steps;
 `training=False` in the LM-loss modes = greedy generation (navillm_amd/kvcache.py).
-Not mirrored (raise NotImplementedError): sampling generation, fp32 LM, OPT LMs.
+Not mirrored (raise NotImplementedError): fp32 LM, OPT LMs.
 """
 import collections
 import functools
