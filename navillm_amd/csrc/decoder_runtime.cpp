@@ -88,6 +88,8 @@ static int linear(const nv_decoder* p, const Layer& ly, int kind, const void* x,
     const int epi = R ? 2 : 0;                                       // residual add or plain store
     if (ly.q[kind]) {
         if (M <= 16 && (K & 63) == 0) return nv_gemv_fp8w(x, ly.q[kind], ly.s[kind], out, R, M, N, K, K, K, N, N, epi, stream);
+        if (ly.w[kind])                                                // the de-quantised operand is resident: no pre-pass
+            return nv_gemm_bf16_ws(0, x, ly.w[kind], out, R, M, N, K, K, K, N, N, epi, 0, p->gemm_ws, stream);
         if (!p->fp8_scratch) return NV_ERR_ARG;
         int rc = nv_fp8_dequant_rows(ly.q[kind], ly.s[kind], p->fp8_scratch, N, K, K, K, stream);
         if (rc) return rc;

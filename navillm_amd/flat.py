@@ -164,6 +164,14 @@ class FlatStore:
             p.requires_grad_(False)
             p.data = torch.empty(0, dtype=p.dtype, device=self.device) if n in self.released else self.p(n)
 
+    def release_grads(self, named_params):
+        """inference deployment that keeps the parameters: drop the gradient buffers and the optimizer state only"""
+        self.grad = None
+        self.exp_avg = self.exp_avg_sq = None
+        for p in named_params.values():
+            p.grad = None
+            p.requires_grad_(False)
+
     def init_optimizer_state(self):
         if self.exp_avg is None:
             self.exp_avg = {g: torch.zeros_like(t) for g, t in self.param.items()}

@@ -59,9 +59,10 @@ def gemv_fp8w(x, q, s, out=None, R=None, epilogue=ops.EPI_STORE):
 
 
 class Fp8DecoderWeights:
-    def __init__(self, model):
+    def __init__(self, model, resident_bf16=False):
         cfg, st = model.cfg, model.store
         self.codes, self.scales = [], []
+        self.resident = [] if resident_bf16 else None          # per layer: the bf16 operands holding bf16(s*q) (views of the flat store)
         with torch.no_grad():
             for i in range(cfg.num_layers):
                 p = f"lang_model.model.layers.{i}."
@@ -70,12 +71,18 @@ class Fp8DecoderWeights:
                 qs = {k: quantize_rows(v) for k, v in mats.items()}
                 self.codes.append({k: v[0] for k, v in qs.items()})
                 self.scales.append({k: v[1] for k, v in qs.items()})
+                if resident_bf16:
+                    for k, W in mats.items():
+                        dequantize_rows(qs[k][0], qs[k][1], out=W)
+                    self.resident.append(mats)
         n_max = max(q.shape[0] * q.shape[1] for q in self.codes[0].values())
-        self._scratch = torch.empty((n_max,), dtype=BF16, device=model.device)
+        self._scratch = None if resident_bf16 else torch.empty((n_max,), dtype=BF16, device=model.device)
         self.bytes = sum(q.numel() + s.numel() * 4 for c, sc in zip(self.codes, self.scales) for q, s in zip(c.values(), sc.values()))
 
     def weight(self, i, kind):
         """the de-quantised operand bf16(s*q) in the shared scratch panel (valid until the next call, stream-ordered)"""
+        if self.resident is not None:
+            return self.resident[i][kind]
         q, s = self.codes[i][kind], self.scales[i][kind]
         return dequantize_rows(q, s, out=self._scratch[:q.numel()].view(q.shape))
 

@@ -74,7 +74,7 @@ class KVCacheLM:
     # ------------------------------------------------------------------ the native layer loop (navillm_amd/csrc/decoder_runtime.cpp)
     def _decoder(self):
         m, cfg, st = self.model, self.model.cfg, self.model.store
-        key = (id(m.fp8), ops._st())
+        key = (id(m.fp8), m.fp8 is not None and m.fp8.resident is not None, m.store.param["lm"].data_ptr(), ops._st())
         if self._dec is not None and self._dec_key == key:
             return self._dec
         L = ops._L()
@@ -91,11 +91,12 @@ class KVCacheLM:
                                               st.p(p + "post_attention_layernorm.weight").data_ptr(), self.qkv[i].data_ptr()), "nv_decoder_set_layer")
             for k, kind in enumerate(kinds):
                 if m.fp8 is not None:
-                    rc = L.nv_decoder_set_weight(dec, i, k, None, m.fp8.codes[i][kind].data_ptr(), m.fp8.scales[i][kind].data_ptr())
+                    wb = m.fp8.resident[i][kind].data_ptr() if m.fp8.resident is not None else None      # bf16(s*q) kept resident
+                    rc = L.nv_decoder_set_weight(dec, i, k, wb, m.fp8.codes[i][kind].data_ptr(), m.fp8.scales[i][kind].data_ptr())
                 else:
                     rc = L.nv_decoder_set_weight(dec, i, k, m.lm_w(i, kind).data_ptr(), None, None)
                 _lib.check(rc, "nv_decoder_set_weight")
-        scratch = m.fp8._scratch.data_ptr() if m.fp8 is not None else None
+        scratch = m.fp8._scratch.data_ptr() if (m.fp8 is not None and m.fp8._scratch is not None) else None
         _lib.check(L.nv_decoder_set_shared(dec, m.rope_cos.data_ptr(), m.rope_sin.data_ptr(), st.p("lang_model.model.norm.weight").data_ptr(),
                                            ops._gemm_ws(m.device) if ops.SPLITK_TAIL else None, scratch), "nv_decoder_set_shared")
         self._dec, self._dec_key = dec, key

@@ -216,19 +216,44 @@ class NavModel(nn.Module):
         return ops.gemm_bf16(ops.NT, x, self.lm_w(i, kind), out=out, R=R, epilogue=epilogue)
 
     @torch.no_grad()
-    def to_fp8_weight_only(self):
+    def to_fp8_weight_only(self, resident_bf16=False):
         """Deployment form for inference: decoder Linear weights -> e4m3fn codes + per-output-channel
         scales (navillm_amd/fp8.py); the bf16 copies of those weights and ALL gradient buffers are released.  Irreversible;
-        training / backward / state_dict() of the decoder layers are not available afterwards."""
+        training / backward / state_dict() of the decoder layers are not available afterwards.
+        resident_bf16=True trades the memory back for time: the bf16 buffers are kept, overwritten with the de-quantised operand
+        bf16(s*q) -- the SAME values the per-call de-quantisation produces -- so prefill / K/V-reuse GEMMs skip the pre-pass while the
+        decode steps still stream the codes (13B: 12.7 GB codes + 25.4 GB bf16 of 288 GB)."""
         from .fp8 import Fp8DecoderWeights
         if self.fp8 is not None:
             return self.fp8
         torch.cuda.synchronize(self.device)
-        self.fp8 = Fp8DecoderWeights(self)
+        self.fp8 = Fp8DecoderWeights(self, resident_bf16=resident_bf16)
+        if resident_bf16:
+            self.store.release_grads(self._named)
+            self.eval()
+            torch.cuda.empty_cache()
+            return self.fp8
         self.store.release_decoder_layers_and_grads(self._named)
         self.eval()
         torch.cuda.empty_cache()
         return self.fp8
+
+    @torch.no_grad()
+    def fp8_release_resident(self):
+        """`to_fp8_weight_only(resident_bf16=True)` -> the memory-lean form: drop the resident bf16(s*q) operands (and the compacted
+        store that goes with it); prefill GEMMs de-quantise into the shared scratch panel from then on."""
+        f8 = self.fp8
+        if f8 is None or f8.resident is None:
+            return f8
+        torch.cuda.synchronize(self.device)
+        f8.resident = None
+        n_max = max(q.shape[0] * q.shape[1] for q in f8.codes[0].values())
+        f8._scratch = torch.empty((n_max,), dtype=BF16, device=self.device)
+        self.store.release_decoder_layers_and_grads(self._named)
+        if self.kv is not None:
+            self.kv._dec_key = None                                # the native decoder's weight table points at the released buffers
+        torch.cuda.empty_cache()
+        return f8
 
     def reserve_activations(self, batch, seq_len):
         """size the LM activation arena once, up front (B*S rows)"""

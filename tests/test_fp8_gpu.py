@@ -154,3 +154,28 @@ def test_fp8_13b_shaped_layer_vs_fp8_oracle():
     print(f"[fp8 13b-layer] S={ids.shape[1]} |hip-orc32(dequant)|={e_hip:.5f} vs |orc16-orc32|={e_ref:.5f} (ratio {e_hip / e_ref:.2f}); "
           f"quantisation itself moves the fp32 logits by {dq:.4f} (scale {scale:.2f})")
     assert e_hip <= 1.25 * e_ref + ulp
+
+
+def test_fp8_resident_bf16_operands_equal_the_per_call_dequantisation():
+    """to_fp8_weight_only(resident_bf16=True): prefill / K/V-reuse GEMMs read the kept bf16(s*q) operands, decode steps the codes --
+    bit-identical to the memory-lean form (same de-quantised values), before and after fp8_release_resident()"""
+    z3 = gold("g3_nav_bf16.npz")
+    cfg = tiny_cfg("bf16")
+    lean, res = build(cfg), build(cfg)
+    lean.to_fp8_weight_only()
+    f8 = res.to_fp8_weight_only(resident_bf16=True)
+    assert f8.resident is not None and res.store.grad is None and res.P("lang_model.model.layers.0.self_attn.q_proj.weight").numel() > 0
+    outs = {}
+    for tag, m in (("lean", lean), ("resident", res)):
+        with torch.no_grad():
+            _, o, _ = _nav_forward(m, z3)
+            m.enable_kv_cache(3)
+            _, oc, _ = _nav_forward(m, z3)
+            m.kv = None
+        outs[tag] = (o["fuse_logits"].clone(), oc["fuse_logits"].clone())
+    assert torch.equal(outs["lean"][0], outs["resident"][0]) and torch.equal(outs["lean"][1], outs["resident"][1])
+    res.fp8_release_resident()
+    assert f8.resident is None and res.P("lang_model.model.layers.0.self_attn.q_proj.weight").numel() == 0
+    with torch.no_grad():
+        _, o2, _ = _nav_forward(res, z3)
+    assert torch.equal(o2["fuse_logits"], outs["lean"][0])
