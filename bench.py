@@ -343,8 +343,10 @@ def fp8_13b_extra(a, device, seed):
     out["lm_buffer_bytes_bf16_before"] = int(lm_bf16)
     measure("fp8_weight_only_nav_steps_per_s")
     out["what"] = ("inference nav steps/s per GPU over one 6-step episode (panorama + navigation forward, argmax actions) at B=4 and 8, and "
-                   "greedy decoding of 24 tokens at B=8; prefill GEMMs run on the de-quantised bf16 scratch panel (3 B/weight pre-pass), "
-                   "decode steps stream the fp8 codes (nv_gemv_fp8w)")
+                   "greedy decoding of 24 tokens at B=8 (prefill included; device-side loop replayed from a hipGraph); decode steps stream "
+                   "the fp8 codes (gemv_stream.hip); prefill / K/V-reuse GEMMs read either the de-quantised operands kept resident "
+                   "(fp8_codes_plus_resident_bf16: 38 GB of weights) or one shared bf16 scratch panel filled per GEMM (fp8_weight_only: "
+                   "12.7 GB, a 3 B/weight pre-pass)")
     del m
     torch.cuda.empty_cache()
     return out
