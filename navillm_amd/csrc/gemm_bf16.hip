@@ -26,6 +26,8 @@ namespace {
 
 enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_RESID = 2, EPI_BIAS = 3, EPI_SWIGLU_BWD = 4, EPI_ROPE = 5 };
 
+constexpr int MAX_SLABS = 512;   // fp32 partial tiles the split-K tail may have in flight (workspace = MAX_SLABS * 256 KiB + 4 KiB)
+
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; bf16_t* C;
     const bf16_t* R;        // EPI_RESID: residual [M,N] (ldr) ; EPI_BIAS: bias[N] ; EPI_SWIGLU_BWD: gate|up [M,2N] (ldr)
@@ -36,6 +38,9 @@ struct GemmArgs {
     int col_strips;         // 1: walk column strips of 8 tiles (XCDs partition B), 0: row groups (XCDs partition A)
     // split-K tail (see launch()): blocks >= full_blocks are K-slices of the last, partial round of tiles
     int full_blocks, rem, split;
+    int kcut;               // split == 2 only: K-tiles of slice 0 (the rest is slice 1); 0 = equal slices
+    int tail_first;         // > 0: the first `tail_first` items are the tail K-slices (padded to a multiple of 8 with no-op items),
+                            // the full tiles follow: the slab hand-off + reduction of the split tiles then overlaps the full tiles
     float* slabs;           // [rem*split][BM*BN] fp32 partials
     unsigned* counters;     // [rem] arrival tickets, zero between launches
     int debug;              // NV_GEMM_DEBUG (measurement only): bit0 skip the C stores, bit1 skip the K loop, bit2 record clocks
@@ -238,7 +243,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     int tile_b = item, ks = 0, nsplit = 1, tail_u = 0;
-    if (tile_b >= p.full_blocks) {           // uniform per block
+    if (p.tail_first) {                      // uniform per block
+        if (item < p.tail_first) {
+            if (item >= p.rem * p.split) return;          // padding item (keeps blockIdx % 8 == XCD aligned with the tile order)
+            ks = item / p.rem;
+            tail_u = item % p.rem;
+            tile_b = p.full_blocks + tail_u;
+            nsplit = p.split;
+        } else {
+            tile_b = item - p.tail_first;
+        }
+    } else if (tile_b >= p.full_blocks) {
         const int q = tile_b - p.full_blocks;
         ks = q / p.rem;
         tail_u = q % p.rem;
@@ -276,8 +291,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT_all = (p.K + BKT - 1) / BKT;
-    const int kt0 = (int)(((long)KT_all * ks) / nsplit);
-    const int KT = (p.debug & 2) ? 0 : (int)(((long)KT_all * (ks + 1)) / nsplit) - kt0;   // this block's K-tiles: kt0 .. kt0+KT-1
+    const bool uneven = nsplit == 2 && p.kcut > 0;
+    const int kt0 = uneven ? (ks ? p.kcut : 0) : (int)(((long)KT_all * ks) / nsplit);
+    const int KT = (p.debug & 2) ? 0 : (uneven ? (ks ? KT_all - p.kcut : p.kcut) : (int)(((long)KT_all * (ks + 1)) / nsplit) - kt0);   // this block's K-tiles: kt0 .. kt0+KT-1
     auto stage = [&](int kt_local, int buf) {
         const int kt = kt0 + kt_local;
         // LDS layout: [A|B] per stage, except for the interleaved loop (PIPE 4): [A0][A1][B0][B1], so that the
@@ -787,7 +803,7 @@ int launch(const GemmArgs& p, hipStream_t st) {
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     GemmArgs q = p;
-    q.full_blocks = tiles; q.rem = 1; q.split = 1;
+    q.full_blocks = tiles; q.rem = 1; q.split = 1; q.kcut = 0; q.tail_first = 0;
     // Split-K tail: with one 256x256 block per CU, T tiles run in ceil(T/256) rounds and the last round is
     // often nearly empty (M=5152,N=4096: 336 tiles = 2 rounds for 1.31 rounds of work).  The tiles of that
     // partial round are cut into `split` K-slices so the round is ~full and 1/split as long.
@@ -799,9 +815,22 @@ int launch(const GemmArgs& p, hipStream_t st) {
             if (split > 4) split = 4;
             if (split > KT / 8) split = KT / 8;
             if (split >= 2) { q.full_blocks = tiles - rem; q.rem = rem; q.split = split; }
+        } else if (rem > CUS / 2) {
+            // 50-80 % full last round: two UNEVEN slices per tail tile.  The rem long slices occupy rem CUs; the CUS - rem others
+            // work off the rem short slices, r = ceil(rem / (CUS - rem)) each; balanced when long = r * short.
+            // OFF by default (NV_GEMM_UNEVEN=1 enables): correct, but measured 3.5-8 % SLOWER where it applies (M=4744: q|k|v forward
+            // rem 144: 1189 -> 1147 TF; down-proj wgrad rem 176: 1168 -> 1069 TF) -- two 256-KiB fp32 slabs per tail tile through the
+            // fabric plus the reducer's serial read cost more than the third of a round the split saves.
+            static const int uneven = [] { const char* e = getenv("NV_GEMM_UNEVEN"); return e ? atoi(e) : 0; }();
+            const int r = (rem + (CUS - rem) - 1) / (CUS - rem);
+            const int kcut = (int)(((long)KT * r + r / 2) / (r + 1));
+            if (uneven && r <= 4 && KT - kcut >= 8 && 2 * rem <= MAX_SLABS) { q.full_blocks = tiles - rem; q.rem = rem; q.split = 2; q.kcut = kcut; }
         }
     }
-    q.items = q.full_blocks + (q.split > 1 ? q.rem * q.split : 0);
+    const int ntail = q.split > 1 ? q.rem * q.split : 0;
+    static const int tail_first = [] { const char* e = getenv("NV_GEMM_TAIL_FIRST"); return e ? atoi(e) : 0; }();
+    if (ntail > 0 && tail_first && q.full_blocks > 0) q.tail_first = (ntail + 7) & ~7;
+    q.items = q.full_blocks + (q.tail_first ? q.tail_first : ntail);
     // persistent blocks for the interleaved kernel (its prologue/epilogue are the per-tile fixed cost worth hiding)
     const int grid = (PIPE == 4 && p.persist && q.items > CUS) ? CUS : q.items;
     NV_LAUNCH(kern, dim3(grid), dim3(WGM * WGN * 64), LDS, st, q);
@@ -868,7 +897,7 @@ inline uint32_t span_bytes(long rows, long cols, long ld) {
 }  // namespace
 
 // ---------------------------------------------------------------- C ABI (see include/navillm_hip.h)
-extern "C" size_t nv_gemm_bf16_workspace_bytes() { return (size_t)256 * 256 * 256 * sizeof(float) + 4096; }
+extern "C" size_t nv_gemm_bf16_workspace_bytes() { return (size_t)MAX_SLABS * 256 * 256 * sizeof(float) + 4096; }
 
 // workspace: nv_gemm_bf16_workspace_bytes() bytes, ZERO-FILLED once by the caller (the kernel leaves its
 // ticket words zero again); NULL disables the split-K tail.
@@ -885,7 +914,7 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.counters = (unsigned*)workspace;
     p.slabs = workspace ? (float*)((char*)workspace + 4096) : nullptr;
-    p.full_blocks = 0; p.rem = 1; p.split = 1;
+    p.full_blocks = 0; p.rem = 1; p.split = 1; p.kcut = 0; p.tail_first = 0;
     p.rope_sin = (const bf16_t*)rope_sin; p.rope_S = rope_S; p.rope_cols = rope_cols; p.rope_pos = rope_pos;
     {
         // tuning / measurement knobs, read once per process
