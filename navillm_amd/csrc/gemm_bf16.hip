@@ -39,6 +39,7 @@ struct GemmArgs {
     // split-K tail (see launch()): blocks >= full_blocks are K-slices of the last, partial round of tiles
     int full_blocks, rem, split;
     int kcut;               // split == 2 only: K-tiles of slice 0 (the rest is slice 1); 0 = equal slices
+    int slab_sc1;           // split-K hand-off through write-through (sc1) slab stores / loads instead of release + acquire fences
     int tail_first;         // > 0: the first `tail_first` items are the tail K-slices (padded to a multiple of 8 with no-op items),
                             // the full tiles follow: the slab hand-off + reduction of the split tiles then overlaps the full tiles
     float* slabs;           // [rem*split][BM*BN] fp32 partials
@@ -598,6 +599,37 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     // plain loads.  The slab image is the accumulator register image (lane-linear 16-B stores).
     if (nsplit > 1) {
         constexpr int SLAB = BM * BN;
+        LDS_PTR(unsigned) flag = (LDS_PTR(unsigned))smem;
+        if (p.slab_sc1) {
+            // Write-through form of the same hand-off (cdna_hip_programming.md §6 G16 R1): sc1 slab stores go to memory past the
+            // XCD's L2, so no release fence (= no buffer_wbl2 of an L2 full of dirty C tiles) and no acquire invalidate; every
+            // wave drains its stores, one lane takes the ticket, the reducer reads all slabs with sc1 loads.
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.slabs, 0, 0x7fffffff, 0x00020000);
+            const int mine = (tail_u * p.split + ks) * SLAB * 4;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
+                                                           mine + ((((wave * TN + i) * TM + j) * 64 + lane) * 16), 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) *flag = __hip_atomic_fetch_add(p.counters + tail_u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const unsigned ticket = *flag;
+            if (ticket != (unsigned)(nsplit - 1)) return;
+            if (tid == 0) __hip_atomic_store(p.counters + tail_u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            for (int o = 0; o < nsplit; ++o) {                 // slice order, whichever block reduces (deterministic sum)
+                const int part = (tail_u * p.split + o) * SLAB * 4;
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, part + ((((wave * TN + i) * TM + j) * 64 + lane) * 16), 0, 16));
+                        acc[i][j] = (o == 0) ? v : acc[i][j] + v;
+                    }
+            }
+        } else {
         float* mine = p.slabs + (size_t)(tail_u * p.split + ks) * SLAB;
 #pragma unroll
         for (int i = 0; i < TN; ++i)
@@ -606,7 +638,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
                 *(f32x4*)(mine + (size_t)(((wave * TN + i) * TM + j) * 64 + lane) * 4) = acc[i][j];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        LDS_PTR(unsigned) flag = (LDS_PTR(unsigned))smem;
         if (tid == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -633,6 +664,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
                     const f32x4 v = *(const f32x4*)(part + (size_t)(((wave * TN + i) * TM + j) * 64 + lane) * 4);
                     acc[i][j] = (o == 0) ? v : acc[i][j] + v;
                 }
+        }
         }
     }
 
@@ -924,6 +956,8 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
         static const int env_persist = [] { const char* e = getenv("NV_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
         p.debug = env_debug;
         p.persist = env_persist;
+        static const int env_sc1 = [] { const char* e = getenv("NV_GEMM_SLAB_SC1"); return e ? atoi(e) : 1; }();   // A/B: +0.7 % on the training step
+        p.slab_sc1 = env_sc1;
         p.group_m = env_group < 1 ? 1 : env_group;
         // default: partition the LARGER operand across the 8 XCD L2s (read once), replicate the smaller one
         p.col_strips = env_order >= 0 ? env_order : ((long)N > (long)M ? 1 : 0);
