@@ -843,9 +843,15 @@ int launch(const GemmArgs& p, hipStream_t st) {
     if (BM == 256 && BN == 256 && p.slabs && p.counters) {
         const int rem = tiles % CUS, KT = (p.K + BKT - 1) / BKT;
         if (rem > 0 && rem <= CUS / 2) {
+            // slices of >= ~20 K-tiles: shorter ones are dominated by their prologue + slab hand-off (M=4744, tools/gemm_probe.py --cold:
+            // K=4096 o_proj forward / dgrad 893 / 852 TF with 4 slices of 16, 957 / 894 with 3; the 344-K-tile gate|up dgrad
+            // 1198 with 4 slices, 1229 with 5).  NV_GEMM_MAXSPLIT / NV_GEMM_MINSLICE: measurement knobs.
+            static const int max_split = [] { const char* e = getenv("NV_GEMM_MAXSPLIT"); return e ? atoi(e) : 6; }();
+            static const int min_slice = [] { const char* e = getenv("NV_GEMM_MINSLICE"); return e ? atoi(e) : 20; }();
             int split = CUS / rem;
-            if (split > 4) split = 4;
-            if (split > KT / 8) split = KT / 8;
+            if (split > max_split) split = max_split;
+            if (split > KT / min_slice) split = KT / min_slice;
+            if (split * rem > MAX_SLABS) split = MAX_SLABS / rem;
             if (split >= 2) { q.full_blocks = tiles - rem; q.rem = rem; q.split = split; }
         } else if (rem > CUS / 2) {
             // 50-80 % full last round: two UNEVEN slices per tail tile.  The rem long slices occupy rem CUs; the CUS - rem others
