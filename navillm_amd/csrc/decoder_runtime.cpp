@@ -100,7 +100,8 @@ static int linear(const nv_decoder* p, const Layer& ly, int kind, const void* x,
 }
 
 // One incremental step over the K/V cache (navillm_amd/kvcache.py::KVCacheLM.extend is the host side):
-//   x        [M, d] bf16   embeddings of the new rows (block layout: sample b owns rows b*N .. b*N+N-1, padded rows allowed)
+//   x        [M, d] bf16   embeddings of the new rows, any order (the host packs them sample after sample); M == B is taken to mean
+//                          ONE new row per sample, row r = sample r (the decode step)
 //   pos      [M] int32     position of every row;  crow [M]: cache row it is scattered to (a junk row for padding);
 //   grow     [M] int32     cache row whose attention output it reads back
 //   kv0      [B] int32     zeros (samples are left-aligned in the cache);  attn_buf [B*cap, d] bf16, lse [B, H, cap] fp32

@@ -116,6 +116,7 @@ class KVCacheLM:
         """Bring the cache to the prompts `ids_list` (B python lists of token ids, no padding) and return the final-norm
         hidden state of each sample's LAST token, [B, d] bf16.
 
+        (return_rows="all": the hidden states of all new rows, packed sample after sample, with their offsets.)
         vis_idx_list[b][j] = row of `vis_all` ([R, d] fp32, device) added to token j's embedding, or -1;
         vis_keys[r] identifies row r across calls: equal keys = the same constant embedding (a `<hist>` token of an
         earlier step), `False` = never reusable (candidates change every step).  Tokens are reused from the cache while
@@ -136,26 +137,25 @@ class KVCacheLM:
             P.append(int(diff[0]) if diff.size else k)
             n.append(Lb - P[-1])
             new_state.append((ids, codes))
-        N = max(n)
-        M = B * N
-        junk = B * cap
-        ids_new = np.full(M, cfg.pad_token_id, np.int32)
+        # the new rows, PACKED sample after sample (no padding to the longest suffix: every kernel of the step is row-wise, and at
+        # ~100 new tokens per sample the padded block layout cost a whole extra 256-row GEMM tile row on a typical step)
+        off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+        M = int(off[-1])
+        ids_new = np.empty(M, np.int32)
         vix_new = np.full(M, -1, np.int32)
-        pos_new = np.zeros(M, np.int32)
-        crow = np.full(M, junk, np.int32)                      # cache row each block row scatters to
-        grow = np.zeros(M, np.int32)                           # cache row each block row gathers its attention output from
+        pos_new = np.empty(M, np.int32)
+        crow = np.empty(M, np.int32)                           # cache row each new row scatters to ...
         last = np.zeros(B, np.int32)
         for b in range(B):
-            s, e = b * N, b * N + n[b]
+            s, e = int(off[b]), int(off[b + 1])
             ids_new[s:e] = new_state[b][0][P[b]:]
             if vis_idx_list is not None:
                 vix_new[s:e] = vis_idx_list[b][P[b]:]
             ar = np.arange(P[b], P[b] + n[b], dtype=np.int32)
             pos_new[s:e] = ar
             crow[s:e] = b * cap + ar
-            grow[s:e] = b * cap + ar
-            grow[e:b * N + N] = b * cap
             last[b] = e - 1
+        grow = crow                                            # ... and reads its attention output back from
         # one pinned staging buffer, one H2D copy for all six index arrays
         packed = np.concatenate([ids_new, vix_new, pos_new, crow, grow, last])
         idx = ops.h2d(torch.from_numpy(packed), dev)
@@ -180,7 +180,7 @@ class KVCacheLM:
         self.state = new_state
         self.last_stats = {"prefix": P, "new": n, "block_rows": M}
         if want_all:
-            return hs_all, (N, n)
+            return hs_all, (off, n)
         return hs
 
     # ------------------------------------------------------------------ generation

@@ -153,6 +153,7 @@ class NavModel(nn.Module):
         self._row_map = None
         self.episode = None              # PrefixEpisode (begin_episode): static prompt prefix computed once per training episode
         self.fp8 = None                  # Fp8DecoderWeights after to_fp8_weight_only()
+        self._gen_kv = None              # K/V cache object kept between generate() calls
         self.flop_log = None             # bench: list of ("lm", tokens, sum of S_b^2, backward?) / ("lm_head", rows, backward?) per LM call
         self.attn_hf_rounding = False    # tests only: attention forward through the parity instrument nv_attn_fwd_hfround_bf16
         self.kv = None                   # KVCacheLM (enable_kv_cache): prefix reuse across no-grad navigation steps + generation
@@ -565,8 +566,11 @@ class NavModel(nn.Module):
         from .kvcache import KVCacheLM
         B, S = ids_cpu.shape
         need = S + max_new_tokens
-        kv = self.kv if (self.kv is not None and self.kv.B == B and self.kv.cap >= need) else \
-            KVCacheLM(self, B, capacity=(need + 127) // 128 * 128)
+        # reuse the cache object of the previous call when it fits: its buffers, its native layer table and the captured decode
+        # graph (evaluation calls generate() once per batch with the same B and max_new_tokens)
+        kv = self.kv if (self.kv is not None and self.kv.B == B and self.kv.cap >= need) else self._gen_kv
+        if kv is None or kv.B != B or kv.cap < need:
+            kv = self._gen_kv = KVCacheLM(self, B, capacity=(need + 127) // 128 * 128)
         ids_l, vix_l, vis_all, _ = self._vis_layout(ids_cpu, am_cpu, cand_vis, hist_vis, None)
         tok = self.lang_model.tokenizer
         eos = getattr(tok, "eos_token_id", None)
