@@ -145,7 +145,30 @@ def inference_extras(a, model, wrapped, crit, ep):
     infer_kv = {"nav_steps_per_s_per_gpu": round(a.batch * STEPS_PER_EPISODE / (time.perf_counter() - t1), 2),
                 "steps": STEPS_PER_EPISODE, "last_step_new_tokens": model.kv.last_stats["new"],
                 "what": "one whole episode (first step = full prefill), K/V of the prompt prefix reused from step to step"}
+    infer_kv["two_batches_in_flight"] = two_batches_in_flight(a, model, wrapped, ep, STEPS_PER_EPISODE)
     return infer, infer_kv
+
+
+def two_batches_in_flight(a, model, wrapped, ep, steps, **ep_kw):
+    """the same K/V-reuse rollout with TWO independent batches of `a.batch` episodes software-pipelined (navillm_amd/synthetic.py:
+    rollout_interleaved): run alone a batch alternates ~16 ms of host work with ~20 ms of GPU work per step; two batches hide
+    each other's host phase.  Same kernels, same batch per forward, own K/V cache per batch."""
+    from navillm_amd.synthetic import SyntheticEpisodes, rollout_interleaved
+    from navillm_amd.kvcache import KVCacheLM
+    eps = [SyntheticEpisodes(model.cfg, a.batch, seed=ep.seed + 101 * k, instr_len=a.instr_len, device=model.device, **ep_kw) for k in range(2)]
+    keep = model.kv
+    kvs = [KVCacheLM(model, a.batch, capacity=1024) for _ in eps]
+    for rep in range(2):
+        for e, kv in zip(eps, kvs):
+            e.reset(); kv.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rollout_interleaved(wrapped, eps, kvs, steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    model.kv = keep
+    return {"nav_steps_per_s_per_gpu": round(2 * a.batch * steps / dt, 2), "steps": steps, "batches": 2,
+            "what": "two batches of %d episodes, the host phase of one overlapped with the GPU phase of the other" % a.batch}
 
 
 def algorithmic_flops(cfg, log):
@@ -254,6 +277,7 @@ def long_horizon_extra(a, cfg, model, wrapped, crit, device, seed, T=64):
             dt = time.perf_counter() - t0
     out["inference_kv_reuse"] = {"nav_steps_per_s_per_gpu": round(a.batch * T / dt, 2), "steps": T, "S_last": int(ep.S_hist[-1]),
                                  "new_tokens_last_step": model.kv.last_stats["new"]}
+    out["inference_kv_reuse"]["two_batches_in_flight"] = two_batches_in_flight(a, model, wrapped, ep, T, max_frontier=35)
     model.kv = None
     model.train()
     # training at the far end: the episode state above is at t = 64; run 6 more training steps there

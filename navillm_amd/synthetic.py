@@ -84,6 +84,7 @@ class SyntheticEpisodes:
         Matterport graph most candidates of a late step are nodes seen before, so the frontier saturates; the action head is
         100-way (nav_model.py:82-85), i.e. stop + at most 99 unvisited candidates)."""
         self.cfg, self.B, self.N = cfg, batch_size, n_views
+        self.seed = seed
         self.max_frontier = max_frontier
         self.task = task                  # which agent's prompts: r2r | reverie | soon | cvdn (tasks/agents/*.py)
         self.rng = np.random.RandomState(seed)
@@ -317,6 +318,63 @@ def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accu
             raise NotImplementedError(feedback)
         ep.advance(nav, actions, out["fuse_embeds"])
     return loss, logits
+
+
+# --------------------------------------------------------------------------- inference: two episode batches in flight
+# A validation rollout is a strict chain per batch -- action t decides observation t+1 -- and per step the host builds inputs for
+# ~16 ms (maps, prompts, index tables; the reference's agent does the same work in Python) before the GPU gets ~20 ms of decoder
+# work: run alone, the two alternate and each idles half the time (tools/kv_trace.py: GPU busy 50 %).  Two INDEPENDENT batches
+# hide each other's host phase: while the GPU runs batch A's step, the host prepares batch B's.  Nothing changes per batch
+# (same kernels, same batch size per forward, same trajectories); each batch has its own K/V cache.
+def nav_step_launch(model, ep, kv=None, feedback="argmax", temperature=1.0):
+    """enqueue one no-grad navigation step of `ep` and return a handle; never waits for the GPU.  `kv`: this batch's KVCacheLM."""
+    inner = model.module if hasattr(model, "module") else model
+    if kv is not None:
+        inner.kv = kv
+    with torch.no_grad():
+        pin = ep.panorama_inputs()
+        pano = model("panorama", pin)
+        pe, pm = pano["pano_embeds"], pano["pano_masks"]
+        ep.update_maps(pe, pm, pin["cand_vpids"])
+        nav = ep.nav_inputs(pe, pm, pin["cand_vpids"])
+        ids, am = ep.tokenise(nav, inner.lang_model.cls_token[0])
+        nav["input_ids"], nav["attention_mask"] = ids, am
+        out = model("navigation", nav)
+        logits = out["fuse_logits"]
+        ep.teacher_targets(nav, False)                       # keeps the episode's RNG stream identical to nav_step's
+        if feedback == "argmax":
+            act = logits.float().argmax(1)
+        elif feedback == "sample":
+            act = torch.distributions.Categorical(torch.softmax(logits / temperature, 1).float()).sample()
+        else:
+            raise NotImplementedError(feedback)
+        host = torch.empty(act.shape, dtype=act.dtype).pin_memory()
+        host.copy_(act, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+    return {"nav": nav, "fuse_embeds": out["fuse_embeds"], "actions": host, "event": ev, "logits": logits}
+
+
+def nav_step_finish(ep, h):
+    """wait for the step's actions (only), then move the episodes on"""
+    h["event"].synchronize()
+    ep.advance(h["nav"], h["actions"], h["fuse_embeds"])
+
+
+def rollout_interleaved(model, eps, kvs, steps, feedback="argmax", temperature=1.0):
+    """`steps` navigation steps of every batch in `eps` (each with its K/V cache in `kvs`), software-pipelined: the host
+    prepares batch i+1 while the GPU runs batch i.  Returns the logits of the last step per batch."""
+    pending = [None] * len(eps)
+    last = [None] * len(eps)
+    for t in range(steps):
+        for i, ep in enumerate(eps):
+            if pending[i] is not None:
+                nav_step_finish(ep, pending[i])
+            pending[i] = nav_step_launch(model, ep, kvs[i], feedback, temperature)
+            last[i] = pending[i]["logits"]
+    for i, ep in enumerate(eps):
+        nav_step_finish(ep, pending[i])
+    return last
 
 
 # --------------------------------------------------------------------------- the other training sub-tasks of a rollout

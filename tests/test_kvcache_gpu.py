@@ -478,3 +478,39 @@ def test_decode_attention_vs_fp32_reference_and_tile_kernel(lens):
     torch.cuda.synchronize()
     trow = torch.stack([tile[b * cap + lens[b] - 1] for b in range(B)]).float().cpu().view(B, H, hd)
     assert (got - trow).abs().max().item() <= 2 ** -6 * max(1.0, ref.abs().max().item())
+
+
+def test_two_batches_in_flight_walk_the_same_trajectories_as_sequential_rollouts():
+    """rollout_interleaved (host phase of one batch under the GPU phase of the other, own K/V cache per batch) == the two
+    rollouts run one after the other: same viewpoints visited, same final logits"""
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.kvcache import KVCacheLM
+    from navillm_amd.losses import CrossEntropyLoss
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step, rollout_interleaved
+    cfg = _mid_cfg(layers=2)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=3)
+    m.eval()
+    crit = CrossEntropyLoss()
+    B, T = 3, 7
+    mk = lambda k: SyntheticEpisodes(cfg, B, seed=50 + k, instr_len=60, device=torch.device(DEV))
+    # reference: the same two batches stepped alternately WITH a sync after every step (the candidate permutation of
+    # forward_navigation draws from torch's global RNG, so the order of the model calls must be the same: A0 B0 A1 B1 ...)
+    ref_eps = [mk(0), mk(1)]
+    ref_kvs = [KVCacheLM(m, B, capacity=512) for _ in ref_eps]
+    seq_logits = [None, None]
+    torch.manual_seed(7)
+    with torch.no_grad():
+        for t in range(T):
+            for i, ep in enumerate(ref_eps):
+                m.kv = ref_kvs[i]
+                _, lg = nav_step(m, crit, ep, train=False)
+                seq_logits[i] = lg.float().cpu()
+    seq_pos = [list(e.cur) for e in ref_eps]
+    m.kv = None
+    torch.manual_seed(7)
+    eps = [mk(0), mk(1)]
+    kvs = [KVCacheLM(m, B, capacity=512) for _ in eps]
+    last = rollout_interleaved(m, eps, kvs, T)
+    assert [list(e.cur) for e in eps] == seq_pos
+    for a, b in zip(last, seq_logits):
+        assert torch.equal(a.float().cpu(), b)
