@@ -132,6 +132,7 @@ def inference_extras(a, model, wrapped, crit, ep):
         torch.cuda.synchronize()
     infer = {"nav_steps_per_s_per_gpu": round(a.batch * a.infer_steps / (time.perf_counter() - t1), 2),
              "steps": a.infer_steps, "what": "panorama + navigation forward only, argmax actions, eval mode"}
+    infer["two_batches_in_flight"] = two_batches_in_flight(a, model, wrapped, ep, a.infer_steps, reuse=False)
     model.enable_kv_cache(a.batch, capacity=1024)
     with torch.no_grad():
         for rep in range(2):                    # one warm episode, one timed episode
@@ -149,7 +150,7 @@ def inference_extras(a, model, wrapped, crit, ep):
     return infer, infer_kv
 
 
-def two_batches_in_flight(a, model, wrapped, ep, steps, **ep_kw):
+def two_batches_in_flight(a, model, wrapped, ep, steps, reuse=True, **ep_kw):
     """the same K/V-reuse rollout with TWO independent batches of `a.batch` episodes software-pipelined (navillm_amd/synthetic.py:
     rollout_interleaved): run alone a batch alternates ~16 ms of host work with ~20 ms of GPU work per step; two batches hide
     each other's host phase.  Same kernels, same batch per forward, own K/V cache per batch."""
@@ -157,10 +158,12 @@ def two_batches_in_flight(a, model, wrapped, ep, steps, **ep_kw):
     from navillm_amd.kvcache import KVCacheLM
     eps = [SyntheticEpisodes(model.cfg, a.batch, seed=ep.seed + 101 * k, instr_len=a.instr_len, device=model.device, **ep_kw) for k in range(2)]
     keep = model.kv
-    kvs = [KVCacheLM(model, a.batch, capacity=1024) for _ in eps]
+    kvs = [KVCacheLM(model, a.batch, capacity=1024) if reuse else False for _ in eps]
     for rep in range(2):
         for e, kv in zip(eps, kvs):
-            e.reset(); kv.reset()
+            e.reset()
+            if reuse:
+                kv.reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         rollout_interleaved(wrapped, eps, kvs, steps)

@@ -330,7 +330,7 @@ def nav_step_launch(model, ep, kv=None, feedback="argmax", temperature=1.0):
     """enqueue one no-grad navigation step of `ep` and return a handle; never waits for the GPU.  `kv`: this batch's KVCacheLM."""
     inner = model.module if hasattr(model, "module") else model
     if kv is not None:
-        inner.kv = kv
+        inner.kv = kv if kv is not False else None           # False: full recompute (no K/V reuse)
     with torch.no_grad():
         pin = ep.panorama_inputs()
         pano = model("panorama", pin)
