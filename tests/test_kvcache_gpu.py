@@ -415,8 +415,9 @@ def test_rope_scatter_equals_rope_then_scatter():
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
 
 
+@pytest.mark.parametrize("big", [False, True])
 @pytest.mark.parametrize("fp8w", [False, True])
-def test_fused_decode_layers_equal_the_unfused_sequence(monkeypatch, fp8w):
+def test_fused_decode_layers_equal_the_unfused_sequence(monkeypatch, fp8w, big):
     """nv_decoder_extend with <= 16 new rows: 6 fused launches per layer == the 11-launch sequence, bit for bit (hidden states of
     all rows and the cache contents), bf16 and weight-only fp8"""
     from navillm_amd.nav_model import NavModel
@@ -429,14 +430,15 @@ def test_fused_decode_layers_equal_the_unfused_sequence(monkeypatch, fp8w):
     B = 4
     g = torch.Generator().manual_seed(2)
     prompt = [torch.randint(3, cfg.base_vocab_size, (50 + 7 * b,), generator=g).tolist() for b in range(B)]
-    more = [p + torch.randint(3, cfg.base_vocab_size, (1 + (b % 3),), generator=g).tolist() for b, p in enumerate(prompt)]
+    # big: > 16 new rows (tile GEMMs; only RoPE + scatter are fused there)
+    more = [p + torch.randint(3, cfg.base_vocab_size, ((9 if big else 1) + (b % 3),), generator=g).tolist() for b, p in enumerate(prompt)]
     res = {}
     for fused in ("0", "1"):
         monkeypatch.setenv("NV_DECODER_FUSED", fused)
         kv = KVCacheLM(m, B, capacity=128)
         kv.extend(prompt)
         hs_all, _ = kv.extend(more, return_rows="all")
-        assert kv.last_stats["block_rows"] <= 16
+        assert (kv.last_stats["block_rows"] > 16) == big
         torch.cuda.synchronize()
         res[fused] = (hs_all.clone(), [q.clone() for q in kv.qkv])
     assert torch.equal(res["0"][0].view(torch.int16), res["1"][0].view(torch.int16))
