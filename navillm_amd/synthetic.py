@@ -348,8 +348,9 @@ def nav_step_launch(model, ep, kv=None, feedback="argmax", temperature=1.0):
             act = torch.distributions.Categorical(torch.softmax(logits / temperature, 1).float()).sample()
         else:
             raise NotImplementedError(feedback)
-        host = torch.empty(act.shape, dtype=act.dtype).pin_memory()
-        host.copy_(act, non_blocking=True)
+        ring = ep.__dict__.setdefault("_act_ring", [torch.empty(act.shape, dtype=act.dtype).pin_memory() for _ in range(2)])
+        host = ring[ep.t & 1]                                 # pinned landing buffers, allocated once (two: a step's actions are read
+        host.copy_(act, non_blocking=True)                    # after the next step of the OTHER batch was launched, never later)
         ev = torch.cuda.Event()
         ev.record()
     return {"nav": nav, "fuse_embeds": out["fuse_embeds"], "actions": host, "event": ev, "logits": logits}
