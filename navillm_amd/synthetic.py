@@ -10,6 +10,7 @@ Per nav step, in the reference's order:
   last step) -> teacher action -> history append -> move.
 """
 import contextlib
+import os
 import math
 import zlib
 
@@ -79,12 +80,19 @@ def view_angle_features(angle_feat_size=4):
 class SyntheticEpisodes:
     """B lock-step episodes on one rank."""
 
-    def __init__(self, cfg, batch_size, seed, instr_len=512, n_views=36, device=None, max_frontier=None, task="r2r"):
+    def __init__(self, cfg, batch_size, seed, instr_len=512, n_views=36, device=None, max_frontier=None, task="r2r", fast_maps=True):
         """max_frontier: cap on the number of known-but-unvisited nodes per map (long-horizon episodes: in a real
         Matterport graph most candidates of a late step are nodes seen before, so the frontier saturates; the action head is
         100-way (nav_model.py:82-85), i.e. stop + at most 99 unvisited candidates)."""
         self.cfg, self.B, self.N = cfg, batch_size, n_views
         self.seed = seed
+        # fast_maps: the maps' node embeddings live in ONE device matrix per batch (running sums + counts, row = node id + 1) and the
+        # visited flags in host sets, instead of one device tensor per node in `GraphMap.node_embeds` and one side-car call per
+        # node: `update_maps` is then three index ops and `nav_inputs` one gather per step, for any map size (the per-node form
+        # is what mp3d_agent.py:304-371 / graph_utils.py:119-142 do: ~1000 tiny device ops per 8-episode step at 100 map slots).
+        # Same arithmetic -- sum in arrival order, divide by the count at read time -- hence bit-identical embeddings
+        # (tests/test_round2_gpu.py::test_fast_maps_equal_the_per_node_maps).
+        self.fast_maps = fast_maps and os.environ.get("NAVILLM_FAST_MAPS", "1") != "0"     # (env: A/B measurements)
         self.max_frontier = max_frontier
         self.task = task                  # which agent's prompts: r2r | reverie | soon | cvdn (tasks/agents/*.py)
         self.rng = np.random.RandomState(seed)
@@ -107,9 +115,32 @@ class SyntheticEpisodes:
         self.history = [[] for _ in range(B)]
         self.hist_vis = [[] for _ in range(B)]
         self.n_nodes = [1] * B
+        self.vis_nodes = [set() for _ in range(B)]             # viewpoints the agent has stood on (= FloydGraph.visited)
+        self._store_rows = 0
         self.obs = [self._observe(b) for b in range(B)]
         for b in range(B):
-            self.gmaps[b].update_graph(self.obs[b])
+            self._update_graph(b)
+
+    def _update_graph(self, b):
+        self.gmaps[b].update_graph(self.obs[b])
+        self.vis_nodes[b].add(self.obs[b]["viewpoint"])
+
+    def _visited(self, b, vp):
+        return (vp in self.vis_nodes[b]) if self.fast_maps else self.gmaps[b].graph.visited(vp)
+
+    def _store(self, rows_needed, d, device):
+        """device store of the node embeddings: E_sum [B, R, d] fp32 running sums, E_cnt [B, R] counts; row 0 = the zero row of
+        the stop slot / padding (count 1), node id k lives in row k + 1"""
+        if self._store_rows < rows_needed:
+            R = max(256, 1 << (rows_needed - 1).bit_length())
+            E_sum = torch.zeros(self.B, R, d, dtype=torch.float32, device=device)
+            E_cnt = torch.zeros(self.B, R, dtype=torch.float32, device=device)
+            E_cnt[:, 0] = 1.0
+            if self._store_rows:
+                E_sum[:, :self._store_rows] = self.E_sum
+                E_cnt[:, :self._store_rows] = self.E_cnt
+            self.E_sum, self.E_cnt, self._store_rows = E_sum, E_cnt, R
+        return self.E_sum, self.E_cnt
 
     def _observe(self, b):
         """new panorama at the current node: K candidates (mostly new frontier nodes, sometimes a known one)."""
@@ -118,11 +149,10 @@ class SyntheticEpisodes:
         known = [v for v in self.pos[b] if v != self.cur[b]]
         saturated = False
         if self.max_frontier is not None:
-            gr = self.gmaps[b].graph
-            frontier = [v for v in known if not gr.visited(v)]
+            frontier = [v for v in known if not self._visited(b, v)]
             saturated = len(frontier) >= self.max_frontier
             if saturated:
-                known = frontier + [v for v in known if gr.visited(v)][:2]     # mostly unvisited nodes: the walk can go on
+                known = frontier + [v for v in known if self._visited(b, v)][:2]     # mostly unvisited nodes: the walk can go on
         for j in range(K):
             if known and (saturated or self.rng.rand() < 0.25):
                 vp = known[self.rng.randint(len(known))]
@@ -173,6 +203,31 @@ class SyntheticEpisodes:
     def update_maps(self, pano_embeds, pano_masks, cand_vpids):
         avg = ops.masked_mean_f32(pano_embeds.detach().contiguous(), pano_masks.to(torch.float32).contiguous())
         pe = pano_embeds.detach()
+        if self.fast_maps:
+            B, N, d = pe.shape
+            need = 1 + max(len(g._graph.idx) for g in self.gmaps)
+            E_sum, E_cnt = self._store(need, d, pe.device)
+            R = self._store_rows
+            cur_rows, add_rows, add_src = [], [], []
+            for b, gmap in enumerate(self.gmaps):
+                idx = gmap._graph.idx
+                gmap.node_step_ids[self.cur[b]] = self.t + 1
+                cur_rows.append(b * R + idx[self.cur[b]] + 1)
+                vis = self.vis_nodes[b]
+                for j, vp in enumerate(cand_vpids[b]):
+                    if vp not in vis:
+                        add_rows.append(b * R + idx[vp] + 1)
+                        add_src.append(b * N + j)
+            packed = ops.h2d(torch.tensor(cur_rows + add_rows + add_src, dtype=torch.int64), pe.device)
+            nb, na = len(cur_rows), len(add_rows)
+            cur_t, rows_t, src_t = packed[:nb], packed[nb:nb + na], packed[nb + na:]
+            Ef, Cf = E_sum.view(B * R, d), E_cnt.view(B * R)
+            Ef.index_copy_(0, cur_t, avg)                                        # visited node: rewrite with its own panorama mean
+            Cf.index_fill_(0, cur_t, 1.0)
+            if na:                                                               # frontier nodes: one more view pointing at them
+                Ef.index_add_(0, rows_t, pe.reshape(B * N, d).index_select(0, src_t))    # (a node appears at most once per step:
+                Cf.index_add_(0, rows_t, torch.ones(na, dtype=torch.float32, device=pe.device))   # the additions do not race)
+            return
         for b, gmap in enumerate(self.gmaps):
             gmap.node_step_ids[self.cur[b]] = self.t + 1
             gmap.update_node_embed(self.cur[b], avg[b], rewrite=True)
@@ -184,30 +239,42 @@ class SyntheticEpisodes:
         B, d, dev = self.B, self.cfg.hidden_size, self.device
         vpids, vis, steps, embeds = [], [], [], []
         for b, gmap in enumerate(self.gmaps):
-            visited = [k for k in gmap.node_positions if gmap.graph.visited(k)]
-            unvisited = [k for k in gmap.node_positions if not gmap.graph.visited(k)]
+            visited = [k for k in gmap.node_positions if self._visited(b, k)]
+            unvisited = [k for k in gmap.node_positions if not self._visited(b, k)]
             gv = [None] + visited + unvisited                                  # enc_full_graph (configs/multi.yaml:109)
             vpids.append(gv)
             vis.append([0] + [1] * len(visited) + [0] * len(unvisited))
             steps.append([gmap.node_step_ids.get(v, 0) for v in gv])
-            e = [gmap.get_node_embed(v) for v in gv[1:]]
-            embeds.append(torch.stack([torch.zeros_like(e[0])] + e, 0))
+            if not self.fast_maps:
+                e = [gmap.get_node_embed(v) for v in gv[1:]]
+                embeds.append(torch.stack([torch.zeros_like(e[0])] + e, 0))
         G = max(len(v) for v in vpids)
-        gmask = torch.zeros(B, G, dtype=torch.bool)
-        gvis = torch.zeros(B, G, dtype=torch.bool)
-        gstep = torch.zeros(B, G, dtype=torch.int64)
+        gmask_np = np.zeros((B, G), dtype=bool)
+        gvis_np = np.zeros((B, G), dtype=bool)
+        gstep_np = np.zeros((B, G), dtype=np.int64)
+        gmask, gvis, gstep = torch.from_numpy(gmask_np), torch.from_numpy(gvis_np), torch.from_numpy(gstep_np)   # views, filled below
         gpos = torch.zeros(B, G, 7)
         gpos_np = gpos.numpy()
         gids = np.full((B, G), -1, dtype=np.int32)                            # integer node ids for the side-car's match tables
-        gimg = torch.zeros(B, G, d, device=dev)
+        gimg = None if self.fast_maps else torch.zeros(B, G, d, device=dev)
         for b, gmap in enumerate(self.gmaps):
             n = len(vpids[b])
-            gmask[b, :n] = True
-            gvis[b, :n] = torch.tensor(vis[b]).bool()
-            gstep[b, :n] = torch.tensor(steps[b])
+            gmask_np[b, :n] = True
+            gvis_np[b, :n] = vis[b]
+            gstep_np[b, :n] = steps[b]
             gmap.get_pos_fts(self.cur[b], vpids[b], self.heading[b], 0.0, out=gpos_np[b, :n])   # all slots, one C call, in place
             gids[b, :n] = gmap.node_ids(vpids[b])
-            gimg[b, :n] = embeds[b]
+            if not self.fast_maps:
+                gimg[b, :n] = embeds[b]
+        if self.fast_maps:
+            # slot -> store row: node id + 1; the stop slot (id -1) and the padding (-1) -> row 0 = zeros / count 1
+            R = self._store_rows
+            rows = (gids.astype(np.int64) + 1) + (np.arange(B, dtype=np.int64) * R)[:, None]
+            rows_t = ops.h2d(torch.from_numpy(rows.reshape(-1)), dev)
+            # sum * (1 / count): what torch's `tensor / python_int` (graph_utils.py:137-142) computes on the device -- a division by
+            # a host scalar is carried out as a multiplication by its fp32 reciprocal -- so the means are bit-identical to it
+            inv = (1.0 / self.E_cnt.view(B * R).index_select(0, rows_t))[:, None]
+            gimg = (self.E_sum.view(B * R, d).index_select(0, rows_t) * inv).view(B, G, d)
         Nv = pano_embeds.shape[1] + 1
         vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
         pm = torch.cat([torch.ones_like(pano_masks[:, :1]), pano_masks], 1)
@@ -255,7 +322,7 @@ class SyntheticEpisodes:
                 continue
             gv = nav["gmap_vpids"][b]
             opts = [gv.index(c["viewpointId"]) for c in self.obs[b]["candidate"]
-                    if not self.gmaps[b].graph.visited(c["viewpointId"])]
+                    if not self._visited(b, c["viewpointId"])]
             tg.append(opts[self.rng.randint(len(opts))] if opts else 0)
         return torch.tensor(tg, dtype=torch.int64)
 
@@ -272,7 +339,7 @@ class SyntheticEpisodes:
         self.t += 1
         self.obs = [self._observe(b) for b in range(self.B)]
         for b in range(self.B):
-            self.gmaps[b].update_graph(self.obs[b])
+            self._update_graph(b)
 
 
 def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accum=1, final=None, feedback=None, temperature=1.0):

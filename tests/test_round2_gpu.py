@@ -600,3 +600,44 @@ def test_philox_dropout_kernel_statistics_and_backward_mask():
     assert Fn.dropout(xg, 0.4, False) is xg and n % 4 == 0
     t = torch.ones(1001, device=DEV)                                                    # n % 4 != 0 tail
     assert ops.dropout_f32(t, 0.5, 1, 0).shape == t.shape
+
+
+def test_fast_maps_equal_the_per_node_maps():
+    """SyntheticEpisodes(fast_maps=True) -- node embeddings in one device matrix per batch (index_copy / index_add / gather) and
+    visited flags in host sets -- against the per-node form of mp3d_agent.py:304-371 / graph_utils.py:119-142 (one device tensor
+    per node, one side-car call per visited() query): bit-identical map embeddings, masks, step ids and pose features at every
+    step of a 12-step rollout with a saturating frontier, and the same walk"""
+    from navillm_amd import config as nvcfg
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.losses import CrossEntropyLoss
+    from navillm_amd.synthetic import SyntheticEpisodes
+    cfg = nvcfg.NavConfig(hidden_size=256, num_layers=1, num_heads=2, intermediate_size=512, base_vocab_size=500, enc_hidden_size=128,
+                          enc_num_heads=4, enc_intermediate_size=256, image_feat_size=768)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=2)
+    m.eval()
+    runs = {}
+    for fast in (False, True):
+        ep = SyntheticEpisodes(cfg, 4, seed=77, instr_len=30, device=torch.device(DEV), max_frontier=6, fast_maps=fast)
+        torch.manual_seed(5)
+        rec = []
+        with torch.no_grad():
+            for t in range(12):
+                pin = ep.panorama_inputs()
+                pano = m("panorama", pin)
+                ep.update_maps(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+                nav = ep.nav_inputs(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+                ids, am = ep.tokenise(nav, m.lang_model.cls_token[0])
+                nav["input_ids"], nav["attention_mask"] = ids, am
+                out = m("navigation", nav)
+                rec.append({k: nav[k].clone().cpu() for k in ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_visited_masks", "gmap_masks")})
+                rec[-1]["vpids"] = [list(v) for v in nav["gmap_vpids"]]
+                rec[-1]["logits"] = out["fuse_logits"].float().cpu()
+                ep.teacher_targets(nav, False)
+                ep.advance(nav, out["fuse_logits"].float().argmax(1).cpu(), out["fuse_embeds"])
+        runs[fast] = (rec, list(ep.cur))
+    assert runs[False][1] == runs[True][1]
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert a["vpids"] == b["vpids"]
+        for k in ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_visited_masks", "gmap_masks", "logits"):
+            assert torch.equal(a[k], b[k]), k
+    assert runs[True][0][-1]["gmap_img_embeds"].shape[1] > 12          # the maps did grow
