@@ -56,16 +56,23 @@ def make_cfg(a):
 
 
 class GemmTimer:
-    """HIP events around every bf16 GEMM launch, on the stream the kernels are launched on."""
+    """HIP events around the bf16 GEMM launches, on the stream the kernels are launched on.  Only while `active`: bracketing
+    all 384 GEMM launches of every step with two events each costs the step 0.9 % (43.30 vs 43.68 nav-steps/s, ABAB on one box), so
+    the timed region instruments every SAMPLE_EVERY-th step (the first timed step always; 5 and 6 steps per episode are coprime, so
+    the sampled steps walk through all positions of an episode)."""
+    SAMPLE_EVERY = 5
 
     def __init__(self):
         self.recs = []
+        self.active = True
 
     def install(self, ops):
         self.ops, self.orig = ops, ops.gemm_bf16
         timer = self
 
         def timed(layout, A, B, out=None, R=None, epilogue=0, tile_cfg=0):
+            if not timer.active:
+                return timer.orig(layout, A, B, out=out, R=R, epilogue=epilogue, tile_cfg=tile_cfg)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = timer.orig(layout, A, B, out=out, R=R, epilogue=epilogue, tile_cfg=tile_cfg)
@@ -78,6 +85,8 @@ class GemmTimer:
         self.orig_rope = ops.gemm_qkv_rope
 
         def timed_rope(x, W, cos_t, sin_t, S, rope_cols, out=None, pos_i32=None):     # the q|k|v projection (NT + RoPE epilogue)
+            if not timer.active:
+                return timer.orig_rope(x, W, cos_t, sin_t, S, rope_cols, out=out, pos_i32=pos_i32)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = timer.orig_rope(x, W, cos_t, sin_t, S, rope_cols, out=out, pos_i32=pos_i32)
@@ -546,6 +555,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.warmup, a.warmup + a.steps):
+        timer.active = (i - a.warmup) % GemmTimer.SAMPLE_EVERY == 0
         loss = one_step(i)
     torch.cuda.synchronize()
     if world > 1:
@@ -625,6 +635,7 @@ def main():
         line.update(extras)
         if g is not None:
             allg = timer.summary(layouts=(0, 1, 2))
+            n_sampled = (a.steps + GemmTimer.SAMPLE_EVERY - 1) // GemmTimer.SAMPLE_EVERY      # timed steps that carried the events
             # the dominant kernel is ONE template (gemm_bf16_kernel) in three operand layouts.  With the backward on a
             # single stream (the default) every launch's event bracket is its kernel duration, so the roofline is taken
             # over all of them; with the optional wgrad side stream only the forward launches run alone.
@@ -633,16 +644,17 @@ def main():
             line["roofline"] = {"bound": "mfma", "achieved": round(r["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": round(r["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
                                 "traffic": gemm_traffic_from_profile(),
-                                "kernel": "gemm_bf16_kernel<256,256,2,4,64,2,*,*,*,4> -- every bf16 GEMM launch of the timed steps "
-                                          "(forward y = x W^T, dgrad, wgrad of qkv / o / gate|up / down in every layer)"
+                                "kernel": "gemm_bf16_kernel<256,256,2,4,64,2,*,*,*,4> -- every bf16 GEMM launch of every %d-th timed step, "
+                                          "%d of the %d (forward y = x W^T, dgrad, wgrad of qkv / o / gate|up / down in every layer; "
+                                          "bracketing all steps costs the step 0.9 %%)" % (GemmTimer.SAMPLE_EVERY, n_sampled, a.steps)
                                           if not model.overlap_wgrad else
                                           "gemm_bf16_kernel<256,256,2,4,64,2,true,true,*,4> (forward launches only: with the wgrad "
                                           "side stream the backward brackets overlap)",
                                 "launches": r["launches"], "avg_launch_ms": round(r["avg_launch_ms"], 4),
                                 "flops_per_launch": r["flops_per_launch"],
                                 "by_layout_tflops": {n: (round(v["tflops"], 1) if v else None) for n, v in per.items()},
-                                "all_gemm_flops_per_step": allg["flops_per_launch"] * allg["launches"] / a.steps,
-                                "gemm_share_of_step": round(allg["gemm_seconds"] / dt, 3),
+                                "all_gemm_flops_per_step": allg["flops_per_launch"] * allg["launches"] / n_sampled,
+                                "gemm_share_of_step": round(allg["gemm_seconds"] / n_sampled / (dt / a.steps), 3),
                                 "note": "peak = nominal dense bf16 MFMA; with N(0,1) operands the MFMA pipe of this part sustains "
                                         "1.87-2.0 PFLOP/s (power-limited clock; tools/ubench/mix_rate.hip, DESIGN.md §4); "
                                         "traffic = 2*FETCH_SIZE+WRITE_SIZE per launch, averaged over the same launches as `achieved`, from the separate "
