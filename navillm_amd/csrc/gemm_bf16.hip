@@ -28,6 +28,15 @@ enum { EPI_STORE = 0, EPI_ACCUM = 1, EPI_RESID = 2, EPI_BIAS = 3, EPI_SWIGLU_BWD
 
 constexpr int MAX_SLABS = 512;   // fp32 partial tiles the split-K tail may have in flight (workspace = MAX_SLABS * 256 KiB + 4 KiB)
 
+// C-tile store: 0 plain, 1 non-temporal (default: C is consumed by the NEXT kernel, whose blocks mostly sit on other XCDs), 2
+// write-through (sc1) -- NV_GEMM_C_STORE.  Measured on the training step: nt +0.3 %, sc1 +-0 (the idea that the ~6 us idle gap
+// after every kernel is the write-back of dirty C lines did not hold: write-through C leaves the gaps where they were).
+__device__ __forceinline__ void store_c(bf16_t* cp, const u32x4& t, int mode) {
+    if (mode == 1) __builtin_nontemporal_store(t, (u32x4*)cp);
+    else if (mode == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(cp), "v"(t) : "memory");
+    else *(u32x4*)cp = t;
+}
+
 struct GemmArgs {
     const bf16_t* A; const bf16_t* B; bf16_t* C;
     const bf16_t* R;        // EPI_RESID: residual [M,N] (ldr) ; EPI_BIAS: bias[N] ; EPI_SWIGLU_BWD: gate|up [M,2N] (ldr)
@@ -39,6 +48,7 @@ struct GemmArgs {
     // split-K tail (see launch()): blocks >= full_blocks are K-slices of the last, partial round of tiles
     int full_blocks, rem, split;
     int kcut;               // split == 2 only: K-tiles of slice 0 (the rest is slice 1); 0 = equal slices
+    int c_nt;               // C-tile store mode (store_c)
     int slab_sc1;           // split-K hand-off through write-through (sc1) slab stores / loads instead of release + acquire fences
     int tail_first;         // > 0: the first `tail_first` items are the tail K-slices (padded to a multiple of 8 with no-op items),
                             // the full tiles follow: the slab hand-off + reduction of the split tiles then overlaps the full tiles
@@ -742,7 +752,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
                             t[q] = pack2bf(rbf(x0 * c0) + rbf(sgn * y0 * s0), rbf(x1 * c1) + rbf(sgn * y1 * s1));
                         }
                     }
-                    *(u32x4*)cp = t;
+                    store_c(cp, t, p.c_nt);
                     continue;
                 }
                 if (EPI == EPI_SWIGLU_BWD) {
@@ -763,7 +773,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
                     *(u32x4*)(cp + p.N) = ou;
                     continue;
                 }
-                *(u32x4*)cp = t;
+                store_c(cp, t, p.c_nt);
             }
         }
         return;
@@ -964,6 +974,8 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
         p.persist = env_persist;
         static const int env_sc1 = [] { const char* e = getenv("NV_GEMM_SLAB_SC1"); return e ? atoi(e) : 1; }();   // A/B: +0.7 % on the training step
         p.slab_sc1 = env_sc1;
+        static const int env_cst = [] { const char* e = getenv("NV_GEMM_C_STORE"); return e ? atoi(e) : 1; }();   // nt: +0.3 % on the step (ABAB: 43.40 / 43.50 / 43.41 / 43.57)
+        p.c_nt = env_cst;
         p.group_m = env_group < 1 ? 1 : env_group;
         // default: partition the LARGER operand across the 8 XCD L2s (read once), replicate the smaller one
         p.col_strips = env_order >= 0 ? env_order : ((long)N > (long)M ? 1 : 0);
