@@ -422,7 +422,7 @@ def cpu_baseline(a, cfg, seed):
     cores = usable_cpus()
     torch.set_num_threads(cores)
     P = {k: v.requires_grad_(True) for k, v in synth_state_dict(c, seed).items()}
-    ep = SyntheticEpisodes(c, 1, seed=seed, instr_len=a.instr_len, device=torch.device("cpu"))
+    ep = SyntheticEpisodes(c, 1, seed=seed, instr_len=a.instr_len, device=torch.device("cpu"), fast_maps=False)   # per-node maps: host tensors
     pin = ep.panorama_inputs()
     t0 = time.time()
     pano = O.scene_encoder(P, c, pin["view_img_fts"], pin["view_lens"], pin["loc_fts"], pin["nav_types"])

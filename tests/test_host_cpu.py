@@ -413,3 +413,17 @@ def test_episode_prefix_ids_from_prompt_strings():
             assert not any(t in cfg.special_token_ids for t in p)
     og = tok(object_grounding_prompt("reverie", instr, 2, 5), add_special_tokens=True)["input_ids"]
     assert og[:len(pre[1])] != pre[1]           # the grounding prompt starts with another sentence: its own episode prefix would differ
+
+
+def test_bench_cpu_baseline_leg_runs_on_a_tiny_config():
+    """bench.py's `cpu_baseline` (the oracle timed on the host, rank 0 at N=1) builds its inputs with the synthetic driver on CPU
+    tensors: keep that path alive (a driver change once broke it and the line carried `value: null`)."""
+    import importlib.util
+    import types
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = tiny_cfg("bf16")
+    out = bench.cpu_baseline(types.SimpleNamespace(instr_len=24), cfg, seed=3)
+    assert out["kind"] == "port" and out["unit"] == "nav-steps/s" and out["value"] is not None and out["value"] > 0
+    assert 1 <= out["cores"] <= (os.cpu_count() or 1)
