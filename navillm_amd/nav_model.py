@@ -147,7 +147,7 @@ class NavModel(nn.Module):
         self.rope_sin = emb.sin().to(BF16).to(self.device).contiguous()
         self._anchor = torch.zeros(1, device=self.device, requires_grad=True)
         self.arena = Fn.ActivationArena(cfg, self.device)
-        self.overlap_wgrad = os.environ.get("NAVILLM_OVERLAP_WGRAD", "0") == "1"   # wgrad GEMMs on a side stream (A/B knob)
+        self.overlap_wgrad = int(os.environ.get("NAVILLM_OVERLAP_WGRAD", "0") or 0)   # wgrad GEMMs on a side stream (A/B knob)
         self.prune_last_layer = True     # navigation/grounding: last decoder layer computed for the <cls_1> rows only
         self.pack_rows = os.environ.get("NAVILLM_PACK_ROWS", "1") != "0"   # LM over the real tokens only (no left-padding rows)
         self._row_map = None
