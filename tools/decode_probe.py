@@ -13,7 +13,8 @@ model = NavModel(nav_config=cfg, device=dev, seed=0)
 model.eval()
 if "--fp8" in sys.argv:
     model.to_fp8_weight_only()
-B, L, N = 8, 600, 64
+B = int(next((a.split('=')[1] for a in sys.argv if a.startswith('--batch=')), 8))
+L, N = 600, 64
 g = torch.Generator().manual_seed(0)
 ids = [[1] + torch.randint(3, cfg.base_vocab_size, (L - 1 + b,), generator=g).tolist() for b in range(B)]
 wbytes = 2 * cfg.num_layers * (4 * cfg.hidden_size ** 2 + 3 * cfg.hidden_size * cfg.intermediate_size) / (2 if "--fp8" in sys.argv else 1)
