@@ -132,3 +132,27 @@ def test_dp_world2_real_backward_matches_mean_of_single_rank_gradients():
         err = (got - want).abs().max().item()
         scale = want.abs().max().item()
         assert err <= 0.01 * scale + 1e-6, (k, err, scale)
+
+
+def test_two_rank_rehearsal_on_one_gpu_prints_one_n2_line():
+    """The N > 1 control flow of bench.py with REAL kernels on a box with one GPU (NAVILLM_BENCH_REHEARSAL=1: both ranks share
+    GPU 0, torch.distributed on gloo, the gradient exchange staged through the host): `--gpus 2` without a torchrun environment
+    relaunches itself under torch.distributed.run, both ranks build the model, wrap it in NavDataParallel, run warmup + timed steps
+    incl. the exchange from inside the episode's last backward, agree on the max-over-ranks clock -- and stdout carries exactly ONE
+    JSON line with n_gpus = 2, marked as a rehearsal."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NAVILLM_BENCH_REHEARSAL="1", NAVILLM_BUILD_REUSE="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--model", "tiny", "--steps", "7", "--warmup", "1",
+                        "--prewarm", "1", "--instr-len", "40", "--batch", "2", "--no-extras", "--no-cpu-baseline", "--infer-steps", "0"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 7 and d["value"] > 0 and "rehearsal" in d
+    assert d["config"]["parallelism"] == "dp2" and d["dp"]["reduce"] == "step"
