@@ -256,7 +256,7 @@ class KVCacheLM:
         g = {"max_steps": max(max_steps, 64), "graph": None, "graph_key": None,
              "state": torch.zeros((n,), dtype=I32, device=dev), "hs": torch.zeros((B, cfg.hidden_size), dtype=BF16, device=dev),
              "x": torch.zeros((B, cfg.hidden_size), dtype=BF16, device=dev), "logits": torch.zeros((B, vp), dtype=BF16, device=dev),
-             "fin_host": torch.zeros((B,), dtype=I32).pin_memory()}
+             "fin_host": [torch.zeros((B,), dtype=I32).pin_memory() for _ in range(3)]}     # landing buffers of the lagging `fin` poll
         g["out"] = torch.zeros((g["max_steps"], B), dtype=I32, device=dev)
         self._greedy = g
         return g
@@ -314,7 +314,7 @@ class KVCacheLM:
                 ev.synchronize()
                 if bool(snap.all()):
                     break
-            snap = torch.empty((B,), dtype=I32).pin_memory()
+            snap = g["fin_host"][t % 3]                        # at most two polls are outstanding
             snap.copy_(g["state"][B:2 * B], non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
