@@ -76,6 +76,9 @@ class FlatAdamW(torch.optim.Optimizer):
     def step(self, closure=None):
         self._dp_flush()
         st = self.store
+        dp = getattr(self.model, "_dp", None)
+        if dp is not None:
+            dp.merge_touched()           # a tensor any rank has a gradient for is updated (and starts its step count) on every rank
         for n in st.touched:
             if n not in self.born:
                 self.born[n] = self.step_count

@@ -349,6 +349,30 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
             self.sync_gradients()
 
     @torch.no_grad()
+    def merge_touched(self):
+        """Union over ranks of `FlatStore.touched` (which tensors have ever received a gradient = which tensors AdamW updates,
+        navillm_amd/optim.py).  Touching depends on the LOCAL batch (`obj_projector` only when the batch carries objects,
+        nav_model.py:111-119; `lm_head` only in the LM-loss modes), while the averaged gradient is the same on every rank: the
+        reference's DDP(find_unused_parameters=True) writes the reduced gradient on every rank as soon as ANY rank used the
+        parameter (tools/optims.py:52-54), so every rank must start that parameter's AdamW state in the same step or the
+        replicas diverge for good.  One tiny MAX-reduction of a 0/1 vector over the parameter names per optimizer step."""
+        if self._world() <= 1:
+            return
+        st = self.module.store
+        names = st.names["lm"] + st.names["f32"]
+        host = torch.tensor([1.0 if n in st.touched else 0.0 for n in names], dtype=torch.float32)
+        if self.comm is not None:
+            v = host.to(st.device)
+            self.comm.allreduce_mean_(v)             # mean > 0  <=>  some rank touched it
+            host = v.cpu()
+        else:
+            on_dev = st.device.type == "cuda" and dist.get_backend(self.group) != "gloo"
+            v = host.to(st.device) if on_dev else host
+            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
+            host = v.cpu()
+        st.touched.update(n for n, f in zip(names, host.tolist()) if f > 0.0)
+
+    @torch.no_grad()
     def sync_gradients(self):
         """Explicit one-shot reduction of every slice."""
         if self._world() > 1 or self.force_sync:

@@ -124,6 +124,23 @@ def _worker(rank, world, port, q):
     ok &= all_mean(2) and not ddp._pending
     ddp.flush()
     ok &= all_mean(2)
+    # ---- which tensors AdamW updates must agree across ranks (`obj_projector` is touched only when the LOCAL batch
+    # carries objects): the union over ranks is taken before the optimizer assigns step counts
+    st.touched.clear()
+    st.touch_layers()
+    only_rank1 = st.names["f32"][0]
+    if rank == 1:
+        st.touch(only_rank1)
+    ddp.merge_touched()
+    ok &= only_rank1 in st.touched
+    got = [None] * world
+    dist.all_gather_object(got, sorted(st.touched))
+    ok &= got[0] == got[1]
+    from navillm_amd.optim import active_segments
+    born = {n: 0 for n in st.touched}
+    segs = [None] * world
+    dist.all_gather_object(segs, active_segments(st, born))
+    ok &= segs[0] == segs[1]
     # task-id broadcast (tasks/loaders.py:176-179)
     ok &= broadcast_task_id(5 if rank == 0 else 9, dev) == 5
     q.put((rank, bool(ok)))
