@@ -287,6 +287,9 @@ int nv_decoder_greedy_step(const nv_decoder* p, void* hs, const void* embed, con
 typedef struct nv_ctx nv_ctx;
 int nv_comm_unique_id_bytes(void);                       /* 128 */
 int nv_comm_unique_id(void* id_out);                     /* rank 0; ship the bytes to the other ranks out of band */
+int nv_comm_rccl_version(void);                          /* NCCL_VERSION_CODE of the librccl bound at run time (22707 on ROCm 7.2) */
+/*   nv_comm_init refuses a librccl whose major version is not 2 and then VERIFIES the enum values this library restates from
+ *   rccl.h (ncclAvg, ncclBfloat16, ncclFloat32) with a mean all-reduce of known bf16 / fp32 vectors over the new communicator */
 int nv_comm_init(nv_ctx** out, const void* id, int rank, int world);   /* collective; current HIP device */
 int nv_comm_rank(const nv_ctx* c);
 int nv_comm_world(const nv_ctx* c);

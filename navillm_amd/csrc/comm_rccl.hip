@@ -28,6 +28,7 @@ struct Rccl {
     int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
     int (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
     int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t);
+    int (*GetVersion)(int*);
     bool ok;
 };
 
@@ -50,7 +51,8 @@ Rccl* rccl() {
         q.Broadcast = (int (*)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t))dlsym(h, "ncclBroadcast");
         q.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t))dlsym(h, "ncclReduceScatter");
         q.AllGather = (int (*)(const void*, void*, size_t, int, ncclComm_t, hipStream_t))dlsym(h, "ncclAllGather");
-        q.ok = q.GetUniqueId && q.CommInitRank && q.CommDestroy && q.AllReduce && q.Broadcast && q.ReduceScatter && q.AllGather;
+        q.GetVersion = (int (*)(int*))dlsym(h, "ncclGetVersion");
+        q.ok = q.GetVersion && q.GetUniqueId && q.CommInitRank && q.CommDestroy && q.AllReduce && q.Broadcast && q.ReduceScatter && q.AllGather;
         return q;
     }();
     return &r;
@@ -68,6 +70,49 @@ struct nv_ctx {
 extern "C" {
 
 int nv_comm_unique_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
+
+// NCCL_VERSION_CODE of the librccl bound at run time (22707 = 2.27.7 on ROCm 7.2), or a negative status
+int nv_comm_rccl_version(void) {
+    if (!rccl()->ok) return NV_ERR_COMM;
+    int v = 0;
+    if (rccl()->GetVersion(&v) != ncclSuccess) return NV_ERR_COMM;
+    return v;
+}
+
+// The enum values above are restated from rccl.h (no link- or compile-time dependency on a particular librccl), so they are
+// CHECKED against the library that was actually bound, once per communicator: a mean all-reduce of known bf16 and fp32
+// vectors.  Rank r contributes {r+1, 3*4^(r&1)} (x1.5 in fp32): a library whose ncclAvg / ncclBfloat16 / ncclFloat32 had other
+// values would return the sum / max / min / product, or the mean of the same bits read as another type (bf16 3 and 12 read
+// as fp16 average to 2.375, not 7.5).  Collective: every rank runs it inside nv_comm_init.
+static int comm_self_check(nv_ctx* c) {
+    const int W = c->world, r = c->rank;
+    struct { uint16_t b[8]; float f[8]; } h, o;
+    memset(&h, 0, sizeof(h));
+    auto bf = [](float x) { uint32_t u; memcpy(&u, &x, 4); return (uint16_t)(u >> 16); };     // exact for these values
+    const float v0 = (float)(r + 1), v1 = 3.f * ((r & 1) ? 4.f : 1.f);
+    h.b[0] = bf(v0); h.b[1] = bf(v1);
+    h.f[0] = 1.5f * v0; h.f[1] = 1.5f * v1;
+    void* d = nullptr;
+    if (hipMalloc(&d, sizeof(h)) != hipSuccess) return NV_ERR_COMM;
+    int rc = NV_OK;
+    if (hipMemcpy(d, &h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) rc = NV_ERR_COMM;
+    char* p = (char*)d;
+    if (rc == NV_OK && rccl()->AllReduce(p, p, 8, ncclBfloat16, ncclAvg, c->comm, (hipStream_t)0) != ncclSuccess) rc = NV_ERR_COMM;
+    if (rc == NV_OK && rccl()->AllReduce(p + 16, p + 16, 8, ncclFloat32, ncclAvg, c->comm, (hipStream_t)0) != ncclSuccess) rc = NV_ERR_COMM;
+    if (rc == NV_OK && (hipStreamSynchronize((hipStream_t)0) != hipSuccess || hipMemcpy(&o, d, sizeof(o), hipMemcpyDeviceToHost) != hipSuccess))
+        rc = NV_ERR_COMM;
+    hipFree(d);
+    if (rc != NV_OK) return rc;
+    double e0 = 0, e1 = 0;
+    for (int q = 0; q < W; ++q) { e0 += q + 1; e1 += 3.0 * ((q & 1) ? 4.0 : 1.0); }
+    e0 /= W; e1 /= W;
+    auto f_of = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
+    auto close = [](double got, double want) { const double d_ = got - want; return (d_ < 0 ? -d_ : d_) <= 0.01 * want; };
+    if (!close(f_of(o.b[0]), e0) || !close(f_of(o.b[1]), e1) || !close(o.f[0], 1.5 * e0) || !close(o.f[1], 1.5 * e1)) return NV_ERR_COMM;
+    for (int i = 2; i < 8; ++i)
+        if (o.b[i] != 0 || o.f[i] != 0.f) return NV_ERR_COMM;
+    return NV_OK;
+}
 
 // rank 0 calls this and ships the 128 bytes to the other ranks out of band (file, TCP store, MPI, ...)
 int nv_comm_unique_id(void* id_out) {
@@ -88,7 +133,11 @@ int nv_comm_init(nv_ctx** out, const void* id, int rank, int world) {
     nv_ctx* c = (nv_ctx*)malloc(sizeof(nv_ctx));
     if (!c) return NV_ERR_ARG;
     c->rank = rank; c->world = world; c->comm = nullptr;
+    // the hand-restated ABI slice is for NCCL major version 2 (rccl.h of ROCm 7.x: 2.2x); refuse anything else up front
+    const int ver = nv_comm_rccl_version();
+    if (ver < 20000 || ver >= 30000) { free(c); return NV_ERR_COMM; }
     if (rccl()->CommInitRank(&c->comm, world, uid, rank) != ncclSuccess) { free(c); return NV_ERR_COMM; }
+    if (comm_self_check(c) != NV_OK) { rccl()->CommDestroy(c->comm); free(c); return NV_ERR_COMM; }
     *out = c;
     return NV_OK;
 }

@@ -108,6 +108,7 @@ SIGNATURES = {
     # data-parallel exchange over RCCL (nv_ctx* travels as void*)
     "nv_comm_unique_id_bytes": (i, []),
     "nv_comm_unique_id": (i, [vp]),
+    "nv_comm_rccl_version": (i, []),
     "nv_comm_init": (i, [C.POINTER(C.c_void_p), vp, i, i]),
     "nv_comm_rank": (i, [vp]),
     "nv_comm_world": (i, [vp]),

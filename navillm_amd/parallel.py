@@ -37,6 +37,10 @@ def init_distributed_device(backend=None, device_index=None):
     plane (rendezvous, barriers, the bench's max-over-ranks clock); gradients travel through `RcclComm`.
     `device_index` overrides LOCAL_RANK (rehearsing the N-rank control flow on a box with fewer GPUs: every rank on GPU 0, gloo)."""
     local_rank, rank, world = world_info_from_env()
+    # the host driver of the MI355X nodes only supports dmabuf IPC: without this RCCL's intra-node setup (and CUDA-tensor sharing
+    # across processes) fails with `hipIpcGetMemHandle: invalid argument`.  Must be in the environment before the first HIP call
+    # of the process to be safe; a launcher-level export is the robust form (INTEGRATION.md §2).
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if torch.cuda.is_available():
         local_rank = local_rank if device_index is None else device_index
         torch.cuda.set_device(local_rank)
