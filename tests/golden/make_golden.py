@@ -22,6 +22,10 @@ Outputs (all small, committed):
     g11_fp8_*.npz      weight-only fp8: navigation logits of the reference run on de-quantised weights; a quantisation vector
                        (weights -> scales, e4m3fn codes, de-quantised values) and the 256-entry decode table, all from torch's float8_e4m3fn
     g1_encoder_real_F{1024,768}.npz   scene encoder at its real size (h=1024, 16 heads, ff=4096, 36 ragged views)
+    g12_episode_*.npz  (round 3) a 3-step R2R EPISODE through the reference: panorama -> navigation -> CE -> backward() at every
+                       step, the chosen slot's fuse_embeds appended to the history (mp3d_agent.py:683-778), gradients
+                       ACCUMULATED over the steps (train.py:86-89 steps the optimizer only afterwards): per-step logits,
+                       losses, history rows and the accumulated parameter gradients
 
 Three shims, all outside the reference tree (the third -- fp32 RoPE
 frequencies, see build_reference -- undoes a transformers 4.28 -> 5.15 drift): the bert-large-uncased
@@ -580,6 +584,91 @@ G10_OG = ["obj_pos_embeddings.0.weight", "obj_pos_embeddings.1.bias", "img_embed
           "img_embeddings.obj_projector.1.weight"]
 
 
+G12_TARGETS = [[2, 3, 4], [0, -100, 5], [3, 4, 0]]      # per step: unvisited map slots / stop (0) / ended sample (-100)
+
+
+def gen_episode(prec, seed=11, T_steps=3):
+    """G12: one training episode of the rollout loop (mp3d_agent.py:659-778, teacher forcing) on fabricated inputs: per step
+    `model('panorama')`, `model('navigation')` with the history the PREVIOUS steps produced (`hist_vis[b].append(fuse_embeds[b][a_t])`
+    unless a_t == -100, :774-778), `criterion(logits, targets) * train_ml / B / accum` and an immediate `backward()` (:750-757);
+    no zero_grad in between -- the fixture's gradients are what `optimizer.step()` would see (train.py:86-89)."""
+    from tasks.agents.r2r import R2RAgent
+    cfg = nvcfg.tiny(precision=prec)
+    tag = "bf16" if cfg.lm_is_bf16 else "fp32"
+    print(f"[{tag}] G12 episode")
+    model = build_reference(cfg, seed)
+    lm = model.lang_model
+    g = torch.Generator().manual_seed(31337)
+    B, N = 3, 8
+    train_ml, accum = 0.8, 2
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-100, reduction="sum")
+    hist_vis = [[] for _ in range(B)]
+    model.zero_grad()
+    arrs, steps_meta = {}, []
+    for t in range(T_steps):
+        pin, cand_k = pano_inputs(cfg, g, B, N)
+        pano = model("panorama", dict(pin))
+        hist_t = [len(h) for h in hist_vis]
+        nin = nav_inputs(cfg, g, pano["pano_embeds"], pano["pano_masks"], cand_k, [0] * B)
+        nin["hist_vis"] = [list(h) for h in hist_vis]
+        nin["history"] = [["<hist>"] * n for n in hist_t]
+        cand_nums = (nin["gmap_masks"] & ~nin["gmap_visited_masks"]).sum(-1)
+        prompts = [R2RAgent.get_navigation_prompt(None, INSTR[b], hist_t[b], int(cand_nums[b]), lm.cls_token[0]) for b in range(B)]
+        nin["prompts"] = prompts
+        nin["instruction"] = INSTR
+        tok = lm.tokenize(prompts)
+        torch.manual_seed(5000 + t)
+        perms = [torch.randperm(int(cand_nums[b]) - 1) for b in range(B)]
+        torch.manual_seed(5000 + t)
+        nout = model("navigation", nin)
+        targets = torch.tensor(G12_TARGETS[t])
+        loss = crit(nout["fuse_logits"], targets) * train_ml / B / accum
+        loss.backward()
+        for b in range(B):
+            if int(targets[b]) != -100:
+                hist_vis[b].append(nout["fuse_embeds"][b][int(targets[b])])
+        # static prefix of each prompt (everything up to "### History:") in token ids: the longest common prefix of the two
+        # tokenisations, so that a sub-word merge across the cut cannot matter
+        plens = []
+        for b in range(B):
+            full = lm.tokenizer(prompts[b], add_special_tokens=True)["input_ids"]
+            cut = prompts[b].index("### History:") + len("### History:")
+            head = lm.tokenizer(prompts[b][:cut], add_special_tokens=True)["input_ids"]
+            n = 0
+            while n < min(len(full), len(head)) and full[n] == head[n]:
+                n += 1
+            plens.append(n)
+        pre = f"s{t}/"
+        for k, v in pin.items():
+            arrs[pre + k] = v
+        for k in ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_visited_masks", "gmap_masks", "vp_pos_fts"):
+            arrs[pre + k] = nin[k]
+        arrs[pre + "nav_pano_masks"] = nin["pano_masks"]
+        arrs[pre + "input_ids"] = tok["input_ids"]
+        arrs[pre + "attention_mask"] = tok["attention_mask"]
+        arrs[pre + "pano_embeds"] = pano["pano_embeds"]
+        arrs[pre + "fuse_logits"] = nout["fuse_logits"]
+        arrs[pre + "fuse_embeds"] = nout["fuse_embeds"]
+        arrs[pre + "loss"] = loss
+        steps_meta.append(dict(gmap_vpids=nin["gmap_vpids"], vp_cand_vpids=nin["vp_cand_vpids"], hist_t=hist_t, prompts=prompts,
+                               targets=targets.tolist(), perms=[p_.tolist() for p_ in perms], seed_before_nav=5000 + t,
+                               prefix_lens=plens))
+    gnames = ["out_head.0.weight", "out_head.0.bias", "img_embeddings.img_linear.weight",
+              "img_embeddings.mapper.weight", "vp_pos_embeddings.0.weight", "vp_pos_embeddings.1.weight",
+              "gmap_pos_embeddings.0.weight", "gmap_step_embeddings.weight", "token_type_embeddings.weight",
+              "lang_model.model.layers.0.self_attn.q_proj.weight", "lang_model.model.layers.0.self_attn.k_proj.weight",
+              "lang_model.model.layers.0.self_attn.v_proj.weight", "lang_model.model.layers.1.self_attn.o_proj.weight",
+              "lang_model.model.layers.1.mlp.down_proj.weight", "lang_model.model.layers.0.mlp.up_proj.weight",
+              "lang_model.model.layers.0.input_layernorm.weight", "lang_model.model.layers.1.post_attention_layernorm.weight",
+              "lang_model.model.norm.weight", "img_embeddings.pano_encoder.layers.0.self_attn.in_proj_weight",
+              "img_embeddings.pano_encoder.layers.1.linear1.weight", "img_embeddings.layer_norm.weight",
+              "img_embeddings.loc_linear.weight", "img_embeddings.nav_type_embedding.weight"]
+    arrs.update({"acc/" + k: v for k, v in grad_fixture(model, gnames).items()})
+    arrs["hist_final_flat"] = torch.stack([v for vis in hist_vis for v in vis], 0)
+    meta = dict(steps=steps_meta, train_ml=train_ml, accum=accum, B=B, hist_final=[len(h) for h in hist_vis])
+    save(f"g12_episode_{tag}.npz", **arrs, meta=np.array(json.dumps(meta)))
+
+
 def pad(ts):
     m = max(t.shape[0] for t in ts)
     return torch.stack([torch.cat([t, torch.zeros(m - t.shape[0], *t.shape[1:])], 0) for t in ts], 0)
@@ -710,6 +799,10 @@ def main():
     if "--only-encoder-real" in sys.argv:        # add the real-size G1 without touching the other fixtures
         gen_encoder_real_size()
         return
+    if "--only-episode" in sys.argv:             # add G12 without touching the other fixtures
+        for prec in ("fp32", "amp_bf16"):
+            gen_episode(prec)
+        return
     if "--only-generation" in sys.argv:          # add G9 without touching the other fixtures
         for prec in ("fp32", "amp_bf16"):
             c = nvcfg.tiny(precision=prec)
@@ -726,6 +819,8 @@ def main():
     gen_prompts()
     gen_graph()
     gen_adamw()
+    for prec in ("fp32", "amp_bf16"):
+        gen_episode(prec)
 
 
 if __name__ == "__main__":

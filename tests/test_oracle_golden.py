@@ -296,3 +296,41 @@ def test_g11_fp8_weight_only(tag):
     # and the quantisation really changes the result (the fixture is not the unquantised G3 again)
     fin = np.isfinite(z["fuse_logits"])
     assert np.abs(z["fuse_logits"][fin] - z3["fuse_logits"][fin]).max() > 5e-3
+
+
+@pytest.mark.parametrize("tag", ["fp32", "bf16"])
+def test_g12_episode_accumulated_gradients(tag):
+    """the oracle through a whole 3-step episode (panorama -> navigation -> CE -> backward per step, history appended from its
+    OWN fuse_embeds, gradients accumulated) against the reference's run of the same episode (mp3d_agent.py:659-778)"""
+    from util import episode_step_batch, grad_fixture_errors
+    z = gold(f"g12_episode_{tag}.npz")
+    meta = meta_of(z)
+    cfg, P = tiny_weights(tag)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    B = meta["B"]
+    hist = [[] for _ in range(B)]
+    atol = 2e-5 if tag == "fp32" else 1.6e-2
+    for t in range(len(meta["steps"])):
+        pre = f"s{t}/"
+        pano = O.scene_encoder(P, cfg, T(z[pre + "view_img_fts"]), T(z[pre + "view_lens"]), T(z[pre + "loc_fts"]), T(z[pre + "nav_types"]))
+        close(pano["pano_embeds"], z[pre + "pano_embeds"], 2e-5, what=f"step {t} pano_embeds")
+        batch, ms = episode_step_batch(z, meta, t, pano["pano_embeds"], hist)
+        torch.manual_seed(ms["seed_before_nav"])
+        out = O.navigation(P, cfg, batch, T(z[pre + "input_ids"]), T(z[pre + "attention_mask"]))
+        assert [p.tolist() for p in out["perms"]] == ms["perms"]
+        close(out["fuse_embeds"], z[pre + "fuse_embeds"], 2e-5, what=f"step {t} fuse_embeds")
+        close(out["fuse_logits"], z[pre + "fuse_logits"], atol, what=f"step {t} fuse_logits")
+        tg = torch.tensor(ms["targets"])
+        loss = O.action_loss(out["fuse_logits"], tg) * meta["train_ml"] / B / meta["accum"]
+        close(loss, z[pre + "loss"], atol, what=f"step {t} loss")
+        loss.backward()
+        for b in range(B):
+            if ms["targets"][b] != -100:
+                hist[b].append(out["fuse_embeds"][b][ms["targets"][b]].detach())
+    assert [len(h) for h in hist] == meta["hist_final"]
+    close(torch.stack([v for h in hist for v in h], 0), z["hist_final_flat"], 2e-5, what="history rows")
+    errs = grad_fixture_errors(z, "acc", lambda n: P[n].grad)
+    assert errs and max(errs.values()) < (1e-4 if tag == "fp32" else 6e-2), errs
+    ref_with_grad = [str(s) for s in z["acc/grad_names_with_grad"]]
+    with_grad = sorted(k for k, v in P.items() if v.grad is not None and bool((v.grad != 0).any()))
+    assert set(with_grad) <= set(ref_with_grad)

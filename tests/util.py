@@ -70,6 +70,24 @@ def nav_batch_from_gold(z, pano_embeds):
     ), m
 
 
+def episode_step_batch(z, meta, t, pano_embeds, hist_vis):
+    """`model('navigation', batch)` dict of step t of g12_episode_*.npz around the caller's own `pano_embeds` and the history
+    rows `hist_vis` (B lists of [d] tensors) the caller's previous steps produced -- as the rollout loop builds it
+    (mp3d_agent.py:702-728)."""
+    ms = meta["steps"][t]
+    pre = f"s{t}/"
+    vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
+    assert [len(h) for h in hist_vis] == ms["hist_t"]
+    return dict(
+        gmap_vpids=ms["gmap_vpids"], gmap_img_embeds=T(z[pre + "gmap_img_embeds"]), gmap_step_ids=T(z[pre + "gmap_step_ids"]),
+        gmap_pos_fts=T(z[pre + "gmap_pos_fts"]), gmap_visited_masks=T(z[pre + "gmap_visited_masks"]),
+        gmap_masks=T(z[pre + "gmap_masks"]), vp_img_embeds=vp_img, pano_masks=T(z[pre + "nav_pano_masks"]),
+        vp_pos_fts=T(z[pre + "vp_pos_fts"]), vp_cand_vpids=ms["vp_cand_vpids"],
+        hist_vis=[list(h) for h in hist_vis], history=[["<hist>"] * n for n in ms["hist_t"]],
+        data_type=["r2r"] * len(ms["hist_t"]), prompts=ms["prompts"],
+    ), ms
+
+
 def grad_fixture_errors(z, prefix, get_grad):
     """relative errors of the gradients stored by make_golden.grad_fixture under `prefix/`:
     -> {name: rel err} over `grad/` (whole tensor), `gradsub/` ([::3, ::5] sub-block) and `rownorm/` entries."""
