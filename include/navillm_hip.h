@@ -266,7 +266,9 @@ int nv_rope_scatter_rows_bf16(const void* qkv, const void* cos_t, const void* si
                               int hd, int ld, void* stream);
 /* ---- greedy decoding with the decisions on the device (HF generate(do_sample=False), models/nav_model.py:324-341,388-402;
  *      special-id mask models/modified_lm.py:122-124).  state = nv_decode_state_ints(B) int32:
- *      tok[B] | fin[B] | len[B] | pos[B] | crow[B] | grow[B] | last[B] | dyn[2] | cnt[1].
+ *      tok[B] | fin[B] | len[B] | pos[B] | crow[B] | grow[B] | last[B] | dyn[2] | cnt[1] | overflow[1].  `overflow` is sticky: set when a
+ *      sample's cache is full (len == cap) at a step -- that sample is marked finished and its further tokens are `pad`; the caller
+ *      must treat a non-zero overflow word as an error (state[7*B+3]).
  *      nv_decode_pick_bf16: masked argmax of logits [B, ldl] (ids >= V and [special0, special0+nspecial) excluded, ties -> smallest
  *      id), finished rows emit `pad`, a row finishes on `eos`; out[cnt, b] = token.  nv_decode_advance: cache indices of the new
  *      token from len, dyn = {max len + 1, 128-aligned min len}, len += 1, cnt += 1.  nv_decoder_greedy_step: lm_head -> pick ->

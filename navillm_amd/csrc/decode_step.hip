@@ -6,7 +6,7 @@
 // (lm_head -> pick -> advance -> embed -> 32 decoder layers) has frozen launch arguments and is replayed from a hipGraph
 // (navillm_amd/kvcache.py); the host only polls the `fin` flags, a step or two behind.
 //
-// state layout (int32, one buffer): tok[B] | fin[B] | len[B] | pos[B] | crow[B] | grow[B] | last[B] | dyn[2] | cnt[1]
+// state layout (int32, one buffer): tok[B] | fin[B] | len[B] | pos[B] | crow[B] | grow[B] | last[B] | dyn[2] | cnt[1] | overflow[1]
 #include "nv_common.h"
 
 namespace {
@@ -65,7 +65,9 @@ __global__ __launch_bounds__(PICK_T) void decode_pick_kernel(const bf16_t* __res
 }
 
 // one block: the token picked for sample b goes to cache row b*cap + len[b] at position len[b]; dyn = {max len + 1, 128-aligned
-// first query row}; len += 1; cnt += 1.  A full cache (len == cap) sends the row to the junk row B*cap and stops growing.
+// first query row}; len += 1; cnt += 1.  A full cache (len == cap) sends the row to the junk row B*cap, stops growing, marks the sample
+// FINISHED (it emits `pad` from the next step on: its query would be read back from the shared junk row, i.e. be garbage) and
+// raises the sticky `overflow` word, which the host must check -- a full cache is an error of the caller, not a silent wrong answer.
 __global__ __launch_bounds__(64) void decode_advance_kernel(int* __restrict__ state, int B, int cap) {
     __shared__ int smax, smin;
     const int tid = threadIdx.x;
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(64) void decode_advance_kernel(int* __restrict__ st
         grow[b] = b * cap + Lc;
         last[b] = b;
         if (!full) len[b] = L + 1;
+        else { state[B + b] = 1; state[7 * B + 3] = 1; }
         atomicMax(&smax, Lc);
         atomicMin(&smin, Lc);
     }
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(64) void decode_advance_kernel(int* __restrict__ st
 
 extern "C" {
 
-int nv_decode_state_ints(int B) { return B > 0 ? 7 * B + 3 : 0; }
+int nv_decode_state_ints(int B) { return B > 0 ? 7 * B + 4 : 0; }
 
 int nv_decode_pick_bf16(const void* logits, int ldl, int V, int special0, int nspecial, int* state, int* out, int max_steps, int B, int eos,
                         int pad, void* stream) {

@@ -74,7 +74,12 @@ class KVCacheLM:
     # ------------------------------------------------------------------ the native layer loop (navillm_amd/csrc/decoder_runtime.cpp)
     def _decoder(self):
         m, cfg, st = self.model, self.model.cfg, self.model.store
-        key = (id(m.fp8), m.fp8 is not None and m.fp8.resident is not None, m.store.param["lm"].data_ptr(), ops._st())
+        # keyed by what the layer table POINTS AT, not by the stream (with the stream in the key the decoder was torn
+        # down and rebuilt -- ~200 ctypes calls and a fresh split-K workspace allocation + memset -- INSIDE the hipGraph capture of
+        # the greedy step, which runs on a side stream).  The split-K workspace handed to the decoder is only touched by the tile
+        # GEMMs of prefill-sized steps (M > 16), which always run on the stream the decoder was created on; the captured decode
+        # step (M = B <= 16) runs the weight streamers and never reads it.
+        key = (id(m.fp8), m.fp8 is not None and m.fp8.resident is not None, m.store.param["lm"].data_ptr())
         if self._dec is not None and self._dec_key == key:
             return self._dec
         L = ops._L()
@@ -261,10 +266,11 @@ class KVCacheLM:
         self._greedy = g
         return g
 
-    def _greedy_step(self, g, eos, pad, stream):
+    def _greedy_step(self, g, eos, pad, stream, dec):
+        """`dec`: the native decoder, resolved by the caller BEFORE any stream capture (nothing here may allocate or rebuild)"""
         m, cfg, st = self.model, self.model.cfg, self.model.store
         sp = cfg.special_token_ids
-        rc = ops._L().nv_decoder_greedy_step(self._decoder(), g["hs"].data_ptr(), st.p("lang_model.model.embed_tokens.weight").data_ptr(),
+        rc = ops._L().nv_decoder_greedy_step(dec, g["hs"].data_ptr(), st.p("lang_model.model.embed_tokens.weight").data_ptr(),
                                              st.lm_head_padded().data_ptr(), st.vocab_pad, cfg.vocab_size, sp[0], len(sp), g["logits"].data_ptr(),
                                              g["x"].data_ptr(), g["state"].data_ptr(), g["out"].data_ptr(), g["max_steps"], self.kv0.data_ptr(),
                                              self.attn.data_ptr(), self.lse.data_ptr(), self.B, self.cap, eos, pad, self._ws.data_ptr(),
@@ -279,15 +285,17 @@ class KVCacheLM:
         B, dev = self.B, self.model.device
         g = self._greedy_state(max_new_tokens)
         L = ops._L()
-        need = L.nv_decoder_workspace_bytes(self._decoder(), B)
+        dec = self._decoder()
+        need = L.nv_decoder_workspace_bytes(dec, B)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=dev)
         if USE_HIP_GRAPH and g["graph"] is None:
             # one eager step on a scratch state BEFORE the prefill: the kernels' first-use initialisation (hipFuncSetAttribute, device
             # queries) must not happen inside a stream capture.  It writes cache row 0 of every sample, which the prefill rewrites.
             g["state"].zero_()
-            self._greedy_step(g, eos, pad, ops._st())
+            self._greedy_step(g, eos, pad, ops._st(), dec)
         Hs = self.extend(seqs, vix, vis_all, keys)
+        assert self._decoder() is dec, "the decoder table changed between prefill and decode"
         n = g["state"].numel()
         init = np.zeros(n, np.int32)
         init[2 * B:3 * B] = [len(x) for x in seqs]
@@ -299,7 +307,7 @@ class KVCacheLM:
             side.wait_stream(torch.cuda.current_stream())
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
-                self._greedy_step(g, eos, pad, torch.cuda.current_stream().cuda_stream)
+                self._greedy_step(g, eos, pad, torch.cuda.current_stream().cuda_stream, dec)
             g["graph"], g["graph_key"] = graph, key            # capture enqueues nothing: the first replay is step 0
         events = []
         steps = 0
@@ -307,7 +315,7 @@ class KVCacheLM:
             if USE_HIP_GRAPH:
                 g["graph"].replay()
             else:
-                self._greedy_step(g, eos, pad, ops._st())
+                self._greedy_step(g, eos, pad, ops._st(), dec)
             steps += 1
             if len(events) >= 2:                               # flags as of two steps ago: the host stays ahead of the GPU
                 ev, snap = events.pop(0)
@@ -320,6 +328,8 @@ class KVCacheLM:
             ev.record()
             events.append((ev, snap))
         toks = g["out"][:steps].cpu().numpy()                  # [steps, B]; syncs
+        if int(g["state"][7 * B + 3].item()):
+            raise RuntimeError("KVCacheLM.generate: a sample's K/V cache filled up during decoding (prompt length + max_new_tokens > capacity)")
         # HF stops after the step in which the last unfinished row emitted eos: trim the steps the lagging poll let through
         fin = np.zeros(B, bool)
         keep = steps

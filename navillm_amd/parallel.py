@@ -245,29 +245,27 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
                 dist.all_reduce(probe, group=self.group)
 
     @torch.no_grad()
-    def calibrate(self, iters=2):
+    def calibrate(self, iters=5):
         """time all-reduce vs reduce-scatter+all-gather on one decoder-layer gradient slice and keep the faster for every
-        slice.  The slice's content is irrelevant and is restored; all ranks take the same decision (max over ranks)."""
+        slice.  The slice's content is irrelevant and is restored; all ranks take the same decision: each rank's figure is its
+        MEDIAN over `iters` timed launches, the decision is made on the max over ranks (exchanged through the communicator).
+        A collective that fails raises on the spot: a failure that only some ranks see must not be swallowed, or the ranks would
+        go on to issue different sequences of collectives and hang."""
         if self.comm is None or self.comm.world < 2:
             return None
         t = self.slices.layer[0]
         keep = t.clone()
         res = {}
         for algo in ("allreduce", "rs_ag"):
-            try:
-                self._reduce(t, algo)                      # warm the channels of this collective
-                torch.cuda.synchronize()
+            self._reduce(t, algo)                          # warm the channels of this collective
+            torch.cuda.synchronize()
+            times = []
+            for _ in range(iters):
                 t0 = time.perf_counter()
-                for _ in range(iters):
-                    self._reduce(t, algo)
+                self._reduce(t, algo)
                 torch.cuda.synchronize()
-                mine = (time.perf_counter() - t0) / iters
-            except Exception as e:                         # a collective this RCCL build rejects (symmetric on all ranks): never chosen
-                if algo == "allreduce":
-                    raise
-                res[algo] = float("inf")
-                res[algo + "_error"] = f"{type(e).__name__}: {e}"
-                continue
+                times.append(time.perf_counter() - t0)
+            mine = sorted(times)[len(times) // 2]
             # max over ranks through the communicator itself: rank r writes slot r (x world), mean-all-reduce, max on the host
             slots = torch.zeros(self.comm.world, dtype=torch.float32, device=t.device)
             slots[self.comm.rank] = mine * self.comm.world
@@ -276,10 +274,8 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
         t.copy_(keep)
         self.algo = "rs_ag" if res["rs_ag"] <= res["allreduce"] else "allreduce"
         nbytes = t.numel() * t.element_size()
-        self.calibration = {"slice_bytes": nbytes, "seconds": {k: (None if v == float("inf") else v) for k, v in res.items() if not k.endswith("_error")},
-                            "chosen": self.algo,
-                            "algbw_GBps": {k: round(nbytes / v / 1e9, 1) for k, v in res.items() if isinstance(v, float) and v not in (0.0, float("inf"))},
-                            "errors": {k: v for k, v in res.items() if k.endswith("_error")}}
+        self.calibration = {"slice_bytes": nbytes, "seconds": dict(res), "chosen": self.algo, "iters": iters,
+                            "algbw_GBps": {k: round(nbytes / v / 1e9, 1) for k, v in res.items() if v > 0.0}, "errors": {}}
         return self.calibration
 
     # ---- the DDP protocol

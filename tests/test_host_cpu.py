@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     # argument validation happens before any launch
     assert L.nv_gemm_bf16(0, None, None, None, None, 4, 4, 64, 64, 64, 4, 0, 0, 0, None) == -1
     assert L.nv_gemv_pre(None, None, None, None, None, None, 8, 64, 64, 64, 64, 64, 0, 0, None, 0.0, 0, None) == -1
-    assert L.nv_decode_state_ints(8) == 7 * 8 + 3 and L.nv_decode_state_ints(0) == 0
+    assert L.nv_decode_state_ints(8) == 7 * 8 + 4 and L.nv_decode_state_ints(0) == 0
     assert L.nv_decode_pick_bf16(None, 0, 0, 0, 0, None, None, 0, 0, 0, 0, None) == -1
     assert L.nv_attn_decode_bf16(None, None, None, None, 1, 1, 128, 16, None) == -1
 

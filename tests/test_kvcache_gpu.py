@@ -275,6 +275,18 @@ def test_decode_pick_and_advance_kernels_vs_torch():
     assert s[4 * B:5 * B].tolist() == [b * cap + int(lens[b]) for b in range(B)] == s[5 * B:6 * B].tolist()
     assert s[6 * B:7 * B].tolist() == list(range(B))
     assert s[7 * B:7 * B + 3].tolist() == [301, 128, 2]
+    assert int(s[7 * B + 3]) == 0                               # no cache filled up
+    # a FULL cache: the token goes to the junk row, the sample is marked finished and the sticky overflow word is raised
+    st2 = torch.zeros(n, dtype=torch.int32)
+    st2[2 * B:3 * B] = torch.tensor([cap, 10, cap - 1, 20, 30], dtype=torch.int32)
+    std2 = st2.to(DEV)
+    lib.check(L.nv_decode_advance(std2.data_ptr(), B, cap, ops._st()), "advance")
+    lib.check(L.nv_decode_advance(std2.data_ptr(), B, cap, ops._st()), "advance")      # sample 2 fills up in the first, overflows in the second
+    torch.cuda.synchronize()
+    s2 = std2.cpu()
+    assert int(s2[7 * B + 3]) == 1 and s2[B:2 * B].tolist() == [1, 0, 1, 0, 0]
+    assert s2[2 * B:3 * B].tolist() == [cap, 12, cap, 22, 32]
+    assert s2[4 * B:5 * B].tolist() == [B * cap, cap + 11, B * cap, 3 * cap + 21, 4 * cap + 31]
 
 
 def test_attention_with_device_side_lengths_equals_static_launch():

@@ -1,7 +1,7 @@
 """Turn the two rocprofv3 --pmc passes of tools/gpu_pmc_bench.sh (FETCH_SIZE, WRITE_SIZE) into
 profiles/r01_gemm_pmc_traffic.txt and profiles/r01_gemm_traffic.json (bytes per forward-GEMM launch).
 Usage: pmc_traffic.py FETCH_DB WRITE_DB OUT_TXT OUT_JSON"""
-import collections, json, re, sqlite3, sys
+import collections, hashlib, json, os, re, sqlite3, sys
 
 def per_kernel(db):
     c = sqlite3.connect(db)
@@ -43,7 +43,9 @@ total, total_all = (2 * f_avg + w_avg) * 1024, (2 * fa_avg + wa_avg) * 1024
 lines.append(f"# forward (NT) GEMM launches: avg FETCH_SIZE {f_avg:.0f} KiB, WRITE_SIZE {w_avg:.0f} KiB -> corrected traffic {total/1e9:.3f} GB per launch")
 lines.append(f"# ALL 256x256 GEMM launches (NT + NN + TN): avg FETCH_SIZE {fa_avg:.0f} KiB, WRITE_SIZE {wa_avg:.0f} KiB -> corrected traffic {total_all/1e9:.3f} GB per launch")
 open(sys.argv[3], "w").write("\n".join(lines) + "\n")
-json.dump({"hbm_bytes_per_forward_gemm_launch": int(total), "hbm_bytes_per_gemm_launch_all_layouts": int(total_all),
+_src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "navillm_amd", "csrc", "gemm_bf16.hip")
+json.dump({"gemm_source_sha256": hashlib.sha256(open(_src, "rb").read()).hexdigest(),     # bench.py refuses the file when the kernel changed since
+           "hbm_bytes_per_forward_gemm_launch": int(total), "hbm_bytes_per_gemm_launch_all_layouts": int(total_all),
            "fetch_kib_avg": f_avg, "write_kib_avg": w_avg, "launches_forward": fw["F"][0], "launches_all": al["F"][0],
            "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 FETCH_SIZE half-count correction", "source": sys.argv[3]}, open(sys.argv[4], "w"))
 print(lines[-2]); print(lines[-1])
