@@ -114,7 +114,8 @@ def _rank_main(rank, world, port, q):
     cal = ddp.calibrate(iters=1)
     p0 = {k: v.clone().cpu() for k, v in model.store.param.items()}
     g = _step(model, ddp, 100 + rank, dev=str(dev))
-    q.put((rank, {k: v.cpu() for k, v in g.items()}, p0, cal))
+    pack = lambda d: {k: v.detach().cpu().float().numpy() for k, v in d.items()}      # by value: shared-memory handles die with the rank
+    q.put((rank, pack(g), pack(p0), cal))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -133,7 +134,8 @@ def test_dp_world2_real_backward_matches_mean_of_single_rank_gradients():
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(120)
-    (_, g0, p0, cal0), (_, g1, p1, _) = res
+    unpack = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    (_, g0, p0, cal0), (_, g1, p1, _) = [(r_[0], unpack(r_[1]), unpack(r_[2]), r_[3]) for r_ in res]
     for k in g0:
         assert torch.equal(p0[k], p1[k]), "parameters were not broadcast from rank 0"
         assert torch.equal(g0[k], g1[k]), "ranks disagree on the averaged gradient"
@@ -194,7 +196,9 @@ def _shared_gpu_rank(rank, world, port, q, reduce, final_overlap):
     opt.step()
     torch.cuda.synchronize()
     p1 = {k: v.clone().cpu() for k, v in model.store.param.items()}
-    q.put((rank, {k: v.cpu() for k, v in g.items()}, g_after, p0, p1, dict(opt.born), pending))
+    # by VALUE (numpy, bf16 widened exactly to fp32): torch tensors would travel as shared-memory handles that die with this process
+    pack = lambda d: {k: v.detach().cpu().float().numpy() for k, v in d.items()}
+    q.put((rank, pack(g), pack(g_after), pack(p0), pack(p1), dict(opt.born), pending))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -217,13 +221,15 @@ def test_dp_world2_shared_gpu_real_backward_mean_and_replica_consistency(reduce,
     res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(120)
-    (_, g0, ga0, p00, p10, born0, pend0), (_, g1, ga1, p01, p11, born1, pend1) = res
+    unpack = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    (_, g0, ga0, p00, p10, born0, pend0), (_, g1, ga1, p01, p11, born1, pend1) = \
+        [(r_[0],) + tuple(unpack(x) for x in r_[1:5]) + tuple(r_[5:]) for r_ in res]
     # the reference: both ranks' episodes on ONE model holding rank 0's weights, averaged on the host in fp32
     model = NavModel(nav_config=_cfg(), device=torch.device(DEV), seed=4)
     model.train()
     for k in p00:
         assert torch.equal(p00[k], p01[k]), "parameters were not broadcast from rank 0"
-        assert torch.equal(p00[k], model.store.param[k].cpu())
+        assert torch.equal(p00[k], model.store.param[k].cpu().float())
     a = _episode(model, model, 100, with_objects=(reduce == "backward"))
     b = _episode(model, model, 101, with_objects=True)
     if reduce == "step" and not final_overlap:
