@@ -96,6 +96,8 @@ int nv_rope_rows_t_bf16(void* qkv, const void* cos_t, const void* sin_t, const i
 /*   K/V gradients of a cached prompt prefix, summed over the steps of an episode in fp32 (navillm_amd/episode.py):
  *   accum : acc[rows[i], 0..2d) += dqkv[rows[i], d..3d)        inject: dqkv[i, d..3d) += acc[rows[i], 0..2d)  (dqkv bf16 [*,3d]) */
 int nv_kv_grad_accum_f32(const void* dqkv, float* acc, const int* rows, int n, int d, void* stream);
+/*   set   : acc[rows[i], 0..2d)  = dqkv[rows[i], d..3d)        (the episode's first step: the accumulator is never zero-filled) */
+int nv_kv_grad_set_f32(const void* dqkv, float* acc, const int* rows, int n, int d, void* stream);
 int nv_kv_grad_inject_bf16(void* dqkv, const float* acc, const int* rows, int n, int d, void* stream);
 
 /* ---- HF LlamaMLP activation on packed gate|up [M, 2*ff]: h = bf16(bf16(silu(g)) * u) */

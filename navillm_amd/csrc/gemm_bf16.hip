@@ -137,7 +137,9 @@ __device__ __forceinline__ bf16x8 load_frag(LDS_PTR(char) tile, int r0, int kk, 
 // Per-lane fragment addressing for the software-pipelined main loop: everything that depends on the lane is
 // computed ONCE (2 VGPRs for a K-major operand, one per fragment for an MN-major one); tile index, k-step
 // and the second transposing read are immediates on the ds_read.
-template <int R, bool KMAJ, int NF>
+// FS = distance, in 16-row fragments, between a wave's consecutive fragments (1: the wave owns a contiguous block of rows;
+// WGM: the waves' fragment rows are interleaved, fragment j of wave-row wm is tile fragment j*WGM + wm -- see gemm_tile).
+template <int R, bool KMAJ, int NF, int FS = 1>
 struct FragAddr {
     int off[KMAJ ? 2 : NF];
     __device__ __forceinline__ void init(int w0, int lane) {     // w0 = wave's first row/col in the tile (% 16 == 0)
@@ -150,14 +152,14 @@ struct FragAddr {
             const int key = ((idx >> 2) & 3) | ((kg & 1) << 2);   // mn_key(krow): the same for both reads and both k-steps
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
-                const int slot = ((w0 >> 3) + 2 * j + ((idx & 3) >> 1)) ^ (key << 1);
+                const int slot = ((w0 >> 3) + 2 * FS * j + ((idx & 3) >> 1)) ^ (key << 1);
                 off[KMAJ ? 0 : j] = (kg * 8 + (idx >> 2)) * (R * 2) + (slot << 4) + (idx & 1) * 8;
             }
         }
     }
     __device__ __forceinline__ bf16x8 load(LDS_PTR(char) tile, int j, int kk) const {
         if (KMAJ) {
-            return *(LDS_PTR(bf16x8))(tile + off[KMAJ ? kk : 0] + j * 2048);
+            return *(LDS_PTR(bf16x8))(tile + off[KMAJ ? kk : 0] + j * (2048 * FS));
         } else {
             LDS_PTR(char) q = tile + off[KMAJ ? 0 : j] + kk * (32 * R * 2);
             s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))q);
@@ -173,12 +175,12 @@ struct FragAddr {
 // address register per K-tile -- all the vector ALU work that is left in that loop.  Every read is then
 // `ds_read vdst, vaddr offset:imm`.  asm("" : "+v") pins each address in its own VGPR (hipcc otherwise re-derives
 // them with v_add chains inside the loop).
-template <int R, bool KMAJ, int NF, int STAGE_STRIDE>
+template <int R, bool KMAJ, int NF, int STAGE_STRIDE, int FS = 1>
 struct FragAddr2 {
     static_assert((STAGE_STRIDE & (STAGE_STRIDE - 1)) == 0, "stage stride must be a power of two (xor toggle)");
     uint32_t off[KMAJ ? 2 : NF];
     __device__ __forceinline__ void init(int w0, int lane, uint32_t region) {   // region: LDS byte address of this operand's stage 0
-        FragAddr<R, KMAJ, NF> f;
+        FragAddr<R, KMAJ, NF, FS> f;
         f.init(w0, lane);
 #pragma unroll
         for (int q = 0; q < (KMAJ ? 2 : NF); ++q) {
@@ -195,7 +197,7 @@ struct FragAddr2 {
     }
     __device__ __forceinline__ bf16x8 load(int j, int kk) const {
         if (KMAJ) {
-            return *(LDS_PTR(bf16x8))(uintptr_t)(off[KMAJ ? kk : 0] + j * 2048);
+            return *(LDS_PTR(bf16x8))(uintptr_t)(off[KMAJ ? kk : 0] + j * (2048 * FS));
         } else {
             const uint32_t q = off[KMAJ ? 0 : j] + kk * (32 * R * 2);
             s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(uintptr_t)q);
@@ -231,11 +233,20 @@ __device__ __forceinline__ void swiglu_bwd_elem(float dh, float g, float u, floa
 
 // One work item (an output tile, or one K-slice of a tail tile) of the GEMM.  `first` = this block's first item: later
 // items of a persistent block start with the previous tile's C stores still in flight (see the kernel below).
-template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE>
+// TME (interleaved loop, PIPE 4, only): fragment rows per wave actually computed.  There the waves' 16-row fragments are
+// INTERLEAVED along M -- fragment j of wave-row wm is tile fragment j*WGM + wm -- so a tile may be cut off after any even number
+// of fragments and both wave-rows still carry the same load: BM_EFF = WGM*TME*16 rows (256, 224, 192, 160, 128 for TME = 8..4)
+// at TME/8 of the MFMA work.  The launcher picks TME per GEMM shape so that the tile count fills the 256 CUs' rounds
+// (small-M GEMMs: M = 670 -> 5 tile rows of 160 instead of 3 of 256, of which the last is 62 % padding; see plan_tme()).
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE, int TME>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, const bool first, LDS_PTR(char) smem) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr bool IL = (PIPE == 4);                       // interleaved fragment rows
+    constexpr int TMU = IL ? TME : TM;                     // fragment rows per wave in use
+    constexpr int BM_EFF = IL ? WGM * TME * 16 : BM;       // rows of C this tile covers
+    static_assert(TME >= 1 && TME <= TM && (IL || TME == TM), "TME < TM needs the interleaved loop");
     constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2;
     constexpr int LOADS = (A_BYTES + B_BYTES) / (NT * 16);     // buffer_load...lds per thread per stage
     static_assert(3 * LOADS < 64, "vmcnt immediate range");
@@ -252,7 +263,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     // in flight then form a group_m x (32/group_m) patch sharing A row panels AND B column panels in
     // that XCD's 4 MiB L2 (measured: strip order = 49% L2 hit rate on the forward GEMM).
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_m = (p.M + BM_EFF - 1) / BM_EFF;
     int tile_b = item, ks = 0, nsplit = 1, tail_u = 0;
     if (p.tail_first) {                      // uniform per block
         if (item < p.tail_first) {
@@ -289,7 +300,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         tm = grp * p.group_m + within % rows_here;
         tn = within / rows_here;
     }
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM_EFF, n0 = tn * BN;
 
     const u32x4 ra = make_desc(p.A, p.a_bytes);
     const u32x4 rb = make_desc(p.B, p.b_bytes);

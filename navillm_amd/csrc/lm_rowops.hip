@@ -392,6 +392,21 @@ __global__ __launch_bounds__(256) void kv_grad_accum_kernel(const bf16_t* __rest
         for (int j = 0; j < 8; ++j) a[j] += f[j];
     }
 }
+// the first step of an episode: acc[rows] = f32(dqkv K/V columns) -- no read of (and therefore no zero-fill of) the accumulator
+__global__ __launch_bounds__(256) void kv_grad_set_kernel(const bf16_t* __restrict__ dqkv, float* __restrict__ acc,
+                                                          const int* __restrict__ rows, int n, int d) {
+    const int per_row = 2 * d / 8;
+    const long total = (long)n * per_row;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+        const long r = rows[i / per_row];
+        const int c = (int)(i % per_row) * 8;
+        float f[8];
+        ld8(dqkv + r * 3 * d + d + c, f);
+        float* a = acc + r * 2 * d + c;
+        *(f32x4*)a = f32x4{f[0], f[1], f[2], f[3]};
+        *(f32x4*)(a + 4) = f32x4{f[4], f[5], f[6], f[7]};
+    }
+}
 __global__ __launch_bounds__(256) void kv_grad_inject_kernel(bf16_t* __restrict__ dqkv, const float* __restrict__ acc,
                                                              const int* __restrict__ rows, int n, int d) {
     const int per_row = 2 * d / 8;
@@ -516,6 +531,13 @@ int nv_kv_grad_accum_f32(const void* dqkv, float* acc, const int* rows, int n, i
     if (n == 0) return NV_OK;
     NV_LAUNCH(kv_grad_accum_kernel, dim3(grid_for((long)n * 2 * d / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dqkv, acc, rows,
               n, d);
+    return nv_check_launch();
+}
+int nv_kv_grad_set_f32(const void* dqkv, float* acc, const int* rows, int n, int d, void* stream) {
+    if (!dqkv || !acc || !rows || (d & 7)) return NV_ERR_ARG;
+    if (n == 0) return NV_OK;
+    NV_LAUNCH(kv_grad_set_kernel, dim3(grid_for((long)n * 2 * d / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dqkv, acc, rows, n,
+              d);
     return nv_check_launch();
 }
 int nv_kv_grad_inject_bf16(void* dqkv, const float* acc, const int* rows, int n, int d, void* stream) {

@@ -24,9 +24,19 @@ differences only: identical up to bf16 rounding of the rotated q/k, as in navill
 the prefix's weight gradients (one GEMM over the summed upstream gradient instead of six accumulations).  Parity against the
 per-step recompute is asserted in tests/test_episode_gpu.py (logits per step, every gradient buffer after the episode).
 
+Weight gradients are DEFERRED (round 3, `NAVILLM_EPISODE_DEFER_WGRAD=0` restores the per-step form): a suffix step has only
+~500-900 token rows, so its four weight-gradient GEMMs per layer contract over 8-14 K-tiles -- three rounds of 256x256 output
+tiles that are all prologue, epilogue and a read-modify-write of the 400 MB gradient slice.  With 288 GB of HBM the GEMM
+operands can simply stay: every step leaves its Linear inputs (n1, attn, n2, h) and output gradients (dqkv, dx1, dgu, dx) in
+per-layer episode buffers behind the prefix's rows (131 KB per token row and layer: 36 GB at 7B for a 6-step episode of B=8),
+and `finish()` runs ONE weight-gradient GEMM per weight over all ~8 300 rows of the episode -- fp32 accumulation across the
+whole episode and a single bf16 rounding, where the per-step form (and the reference's autograd) round after every step.
+
 This is an OPTIONAL mode (`NavModel.begin_episode`): the default training path, `bench.py`'s `value` included, recomputes the
 full prompt at every step like the reference.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -83,6 +93,8 @@ class PrefixEpisode:
         self._slab = {}
         self._wcache = {}
         self.stats = {"prefix_rows": 0, "suffix_rows": []}
+        self.defer_wgrad = os.environ.get("NAVILLM_EPISODE_DEFER_WGRAD", "1") != "0"
+        self._E, self._ecap, self._cursor, self._last_rows = None, 0, 0, 0
 
     # ------------------------------------------------------------------ helpers
     def _buf(self, tag, shape, dtype=BF16):
@@ -93,6 +105,30 @@ class PrefixEpisode:
             t = torch.empty((n,), dtype=dtype, device=self.m.device)
             self._slab[tag] = t
         return t[:n].view(*shape)
+
+    _EWIDTH = {"n1": (1, 0), "attn": (1, 0), "n2": (1, 0), "h": (0, 1), "dqkv": (3, 0), "dx1": (1, 0), "dgu": (0, 2), "dxo": (1, 0)}
+
+    def _ensure_rows(self, rows):
+        """per-layer episode buffers [capacity, width]: the Linear inputs (n1, attn, n2, h) and output gradients (dqkv, dx1, dgu,
+        dxo = gradient of the layer's output) of every token row the episode has pushed through the decoder so far -- prefix rows
+        first, then each step's block.  Grow-only; growing mid-episode copies the rows already written (first episodes only)."""
+        if self._E is not None and rows <= self._ecap:
+            return
+        cfg, dev = self.m.cfg, self.m.device
+        d, ff = cfg.hidden_size, cfg.intermediate_size
+        cap = int(rows * (1.5 if self._cursor else 1.1)) + 64      # growing mid-episode copies: do it rarely
+        new = []
+        for i in range(cfg.num_layers):
+            bufs = {}
+            for name, (cd, cf) in self._EWIDTH.items():
+                t = torch.empty((cap, cd * d + cf * ff), dtype=BF16, device=dev)
+                if self._E is not None and self._cursor:
+                    t[: self._cursor].copy_(self._E[i][name][: self._cursor])
+                bufs[name] = t
+            new.append(bufs)
+            if self._E is not None:
+                self._E[i] = None                      # release layer by layer: never two full copies resident
+        self._E, self._ecap = new, cap
 
     def _weights(self, i):
         """(Wqkv, Wo, Wgu, Wd, w1, w2, their six gradient views) of layer i: views of the flat store, built once"""
@@ -134,10 +170,21 @@ class PrefixEpisode:
         d, ff = cfg.hidden_size, cfg.intermediate_size
         x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_d, vix, None, out=self._buf("pE", (Mp, d)))
         layers = []
+        defer = self.defer_wgrad
+        if defer:
+            self._cursor = 0
+            self._ensure_rows(Mp + max(self._last_rows, Mp))     # first episode: assume the steps add about as many rows as the prefix has
+            self._cursor = Mp
         for i in range(L):
             Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
-            # kept until finish(): grow-only slabs, so prefixes of varying length do not churn the allocator
-            t = lambda name, width, dt=BF16: self._buf(f"p{i}.{name}", (Mp, width) if width else (Mp,), dt)
+            # kept until finish(): grow-only slabs, so prefixes of varying length do not churn the allocator; the four Linear
+            # inputs live in the episode buffers when the weight gradients are deferred (rows [0, Mp))
+            E = self._E[i] if defer else None
+
+            def t(name, width, dt=BF16, E=E, i=i):
+                if E is not None and name in E:
+                    return E[name][:Mp]
+                return self._buf(f"p{i}.{name}", (Mp, width) if width else (Mp,), dt)
             n1, rstd1 = ops.rmsnorm_fwd(x, w1, eps, out=t("n1", d), rstd=t("r1", 0, F32))
             qkv = ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, Lmax, 2 * H * hd, out=t("qkv", 3 * d), pos_i32=pos_d)
             ops.scatter_rows_bf16_(qkv, crow_d, self.cache[i])
@@ -150,10 +197,9 @@ class PrefixEpisode:
             h = ops.swiglu_fwd(gu, out=t("h", ff))
             x2 = ops.gemm_bf16(ops.NT, h, Wd, out=t("x2", d), R=x1, epilogue=ops.EPI_RESID)
             layers.append(dict(x=x, n1=n1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x1=x1, n2=n2, rstd2=rstd2, gu=gu, h=h))
-            self.dkv_acc[i].zero_()
-            x = x2
+            x = x2                                     # (dkv_acc needs no zero-fill: the first step SETS the prefix rows)
         self.prefix = dict(ids=[list(p) for p in prefix_ids], ids_np=ids, lens=lens, cu=cu_d, pos=pos_d, crow=crow_d, pos0=zero_pos0,
-                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0)
+                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0, kv_steps=0, defer=defer)
         self.stats = {"prefix_rows": Mp, "suffix_rows": []}
 
     # ------------------------------------------------------------------ one step: suffix rows over the cached prefix
@@ -210,11 +256,21 @@ class PrefixEpisode:
             cfg.intermediate_size
         M, Lmax, qmin = step["M"], step["Lmax"], step["qmin"]
         k = self.prefix["steps"]
+        defer = self.defer_wgrad and self.prefix["defer"]
+        r0 = self._cursor
+        if defer:
+            self._ensure_rows(r0 + M)
+            self._cursor = r0 + M
         x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), step["ids"], step["vix"], vis_all, out=self._buf("E", (M, d)))
         layers = []
         for i in range(L):
             Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
-            t = lambda name, width, dt=BF16: self._buf(f"s{i}.{name}", (M, width) if width else (M,), dt)
+            E = self._E[i] if defer else None
+
+            def t(name, width, dt=BF16, E=E, i=i):
+                if E is not None and name in E:
+                    return E[name][r0:r0 + M]          # this step's block of the episode buffers: kept for finish()'s weight gradients
+                return self._buf(f"s{i}.{name}", (M, width) if width else (M,), dt)
             n1, rstd1 = ops.rmsnorm_fwd(x, w1, eps, out=t("n1", d), rstd=t("r1", 0, F32))
             qkv = ops.gemm_bf16(ops.NT, n1, Wqkv, out=self._buf("qkv", (M, 3 * d)))
             ops.rope_rows_(qkv, m.rope_cos, m.rope_sin, step["pos"], H, hd)
@@ -233,7 +289,7 @@ class PrefixEpisode:
         x_last = ops.gather_rows_bf16(x, step["last"])
         Hs, rstdf = ops.rmsnorm_fwd(x_last, st.p("lang_model.model.norm.weight"), eps)
         self.prefix["steps"] = k + 1
-        return Hs, dict(step=step, layers=layers, x_last=x_last, rstdf=rstdf, serial=k + 1)
+        return Hs, dict(step=step, layers=layers, x_last=x_last, rstdf=rstdf, serial=k + 1, r0=r0, defer=defer)
 
     def _step_backward(self, saved, dH):
         m, cfg, st = self.m, self.m.cfg, self.m.store
@@ -246,7 +302,10 @@ class PrefixEpisode:
         st.touch_layers()
         m._dp_begin_backward()
         dx_last = ops.rmsnorm_bwd(dH, saved["x_last"], st.p("lang_model.model.norm.weight"), saved["rstdf"], st.g("lang_model.model.norm.weight"))
-        dx = self._buf("dx_a", (M, d))
+        defer, r0 = saved["defer"], saved["r0"]
+        first = self.prefix["kv_steps"] == 0           # the first backward of the episode SETS the prefix K/V-gradient accumulators
+        rows = slice(r0, r0 + M)
+        dx = self._E[L - 1]["dxo"][rows] if defer else self._buf("dx_a", (M, d))
         dx.zero_()
         ops.scatter_rows_bf16_(dx_last, step["last"], dx)
         other = self._buf("dx_b", (M, d))
@@ -255,27 +314,37 @@ class PrefixEpisode:
         for i in reversed(range(L)):
             Wqkv, Wo, Wgu, Wd, w1, w2, gqkv, go, ggu, gd, gw1, gw2 = self._weights(i)
             a = saved["layers"][i]
+            E = self._E[i] if defer else None
             dh = ops.gemm_bf16(ops.NN, dx, Wd, out=self._buf("dh", (M, cfg.intermediate_size)))
-            ops.gemm_bf16(ops.TN, dx, a["h"], out=gd, epilogue=ops.EPI_ACCUM)
-            dgu = ops.swiglu_bwd(a["gu"], dh, out=self._buf("dgu", (M, 2 * cfg.intermediate_size)))
+            if not defer:
+                ops.gemm_bf16(ops.TN, dx, a["h"], out=gd, epilogue=ops.EPI_ACCUM)
+            dgu = ops.swiglu_bwd(a["gu"], dh, out=E["dgu"][rows] if defer else self._buf("dgu", (M, 2 * cfg.intermediate_size)))
             dn2 = ops.gemm_bf16(ops.NN, dgu, Wgu, out=self._buf("dn2", (M, d)))
-            ops.gemm_bf16(ops.TN, dgu, a["n2"], out=ggu, epilogue=ops.EPI_ACCUM)
-            dx1 = ops.rmsnorm_bwd(dn2, a["x1"], w2, a["rstd2"], gw2, resid_grad=dx, out=self._buf("dx1", (M, d)))
+            if not defer:
+                ops.gemm_bf16(ops.TN, dgu, a["n2"], out=ggu, epilogue=ops.EPI_ACCUM)
+            dx1 = ops.rmsnorm_bwd(dn2, a["x1"], w2, a["rstd2"], gw2, resid_grad=dx, out=E["dx1"][rows] if defer else self._buf("dx1", (M, d)))
             dattn = ops.gemm_bf16(ops.NN, dx1, Wo, out=self._buf("dattn", (M, d)))
-            ops.gemm_bf16(ops.TN, dx1, a["attn"], out=go, epilogue=ops.EPI_ACCUM)
+            if not defer:
+                ops.gemm_bf16(ops.TN, dx1, a["attn"], out=go, epilogue=ops.EPI_ACCUM)
             # attention backward on the cache layout: dO is zero everywhere except this step's rows (written, used, zeroed again:
             # a full-buffer fill per layer was 3 % of the episode)
             ops.scatter_rows_bf16_(dattn, step["crow"], self.dout_full)
             ops.attn_bwd_strided(self.cache[i], self.attn_buf[i], self.dout_full, self.lse[i], self.kv0, B, Lmax, cap, H, hd, self.dqkv_full,
                                  q_row_min=qmin)
             ops.scatter_rows_bf16_(zeros_md, step["crow"], self.dout_full)
-            dqkv = ops.gather_rows_bf16(self.dqkv_full, step["crow"])
+            dqkv = ops.gather_rows_bf16(self.dqkv_full, step["crow"], out=E["dqkv"][rows] if defer else None)
             ops.rope_rows_t_(dqkv, m.rope_cos, m.rope_sin, step["pos"], H, hd)
-            ops.kv_grad_accum(self.dqkv_full, self.dkv_acc[i], self.prefix["crow"])     # what this step sends into the prefix's K/V
+            ops.kv_grad_accum(self.dqkv_full, self.dkv_acc[i], self.prefix["crow"], first=first)   # what this step sends into the prefix's K/V
             dn1 = ops.gemm_bf16(ops.NN, dqkv, Wqkv, out=self._buf("dn1", (M, d)))
-            ops.gemm_bf16(ops.TN, dqkv, a["n1"], out=gqkv, epilogue=ops.EPI_ACCUM)
-            ndx = ops.rmsnorm_bwd(dn1, a["x"], w1, a["rstd1"], gw1, resid_grad=dx1, out=other)
-            dx, other = ndx, dx
+            if not defer:
+                ops.gemm_bf16(ops.TN, dqkv, a["n1"], out=gqkv, epilogue=ops.EPI_ACCUM)
+            if defer:
+                ndx = ops.rmsnorm_bwd(dn1, a["x"], w1, a["rstd1"], gw1, resid_grad=dx1, out=self._E[i - 1]["dxo"][rows] if i > 0 else other)
+                dx = ndx
+            else:
+                ndx = ops.rmsnorm_bwd(dn1, a["x"], w1, a["rstd1"], gw1, resid_grad=dx1, out=other)
+                dx, other = ndx, dx
+        self.prefix["kv_steps"] += 1
         dvis = ops.vis_grad(dx, step["vis_rows"]) if step["vis_rows"].numel() else None
         self._embed_grad(dx, step["ids_np"])
         return dvis
@@ -302,31 +371,56 @@ class PrefixEpisode:
         m, cfg, st = self.m, self.m.cfg, self.m.store
         B, H, hd, L, d = self.B, cfg.num_heads, cfg.head_dim, cfg.num_layers, cfg.hidden_size
         Mp, Lmax = P["Mp"], P["Lmax"]
+        if P["kv_steps"] == 0:                         # no step ran a backward: nothing to propagate (and dkv_acc holds no data)
+            self.prefix = None
+            self._cursor = 0
+            return
+        defer = P["defer"]
+        R = self._cursor if defer else Mp               # token rows of the whole episode: prefix [0, Mp) + every step's block
         st.touch_layers()
         dx = None
         for i in reversed(range(L)):
             Wqkv, Wo, Wgu, Wd, w1, w2, gqkv, go, ggu, gd, gw1, gw2 = self._weights(i)
             a = P["layers"][i]
-            dqkv = self._buf("p.dqkv", (Mp, 3 * d))
+            E = self._E[i] if defer else None
+            dqkv = E["dqkv"][:Mp] if defer else self._buf("p.dqkv", (Mp, 3 * d))
             dx1 = None
             if dx is not None:                    # (the top layer's prefix outputs feed nothing: only its K/V carry gradient)
                 dh = ops.gemm_bf16(ops.NN, dx, Wd, out=self._buf("p.dh", (Mp, cfg.intermediate_size)))
-                ops.gemm_bf16(ops.TN, dx, a["h"], out=gd, epilogue=ops.EPI_ACCUM)
-                dgu = ops.swiglu_bwd(a["gu"], dh, out=self._buf("p.dgu", (Mp, 2 * cfg.intermediate_size)))
+                if not defer:
+                    ops.gemm_bf16(ops.TN, dx, a["h"], out=gd, epilogue=ops.EPI_ACCUM)
+                dgu = ops.swiglu_bwd(a["gu"], dh, out=E["dgu"][:Mp] if defer else self._buf("p.dgu", (Mp, 2 * cfg.intermediate_size)))
                 dn2 = ops.gemm_bf16(ops.NN, dgu, Wgu, out=self._buf("p.dn2", (Mp, d)))
-                ops.gemm_bf16(ops.TN, dgu, a["n2"], out=ggu, epilogue=ops.EPI_ACCUM)
-                dx1 = ops.rmsnorm_bwd(dn2, a["x1"], w2, a["rstd2"], gw2, resid_grad=dx, out=self._buf("p.dx1", (Mp, d)))
+                if not defer:
+                    ops.gemm_bf16(ops.TN, dgu, a["n2"], out=ggu, epilogue=ops.EPI_ACCUM)
+                dx1 = ops.rmsnorm_bwd(dn2, a["x1"], w2, a["rstd2"], gw2, resid_grad=dx, out=E["dx1"][:Mp] if defer else self._buf("p.dx1", (Mp, d)))
                 dattn = ops.gemm_bf16(ops.NN, dx1, Wo, out=self._buf("p.dattn", (Mp, d)))
-                ops.gemm_bf16(ops.TN, dx1, a["attn"], out=go, epilogue=ops.EPI_ACCUM)
+                if not defer:
+                    ops.gemm_bf16(ops.TN, dx1, a["attn"], out=go, epilogue=ops.EPI_ACCUM)
                 ops.attn_bwd_varlen(a["qkv"], a["attn"], dattn, a["lse"], P["cu"], P["pos0"], B, Lmax, H, hd, dqkv, q_row_min=0, rope=None)
             else:
                 dqkv.zero_()
             ops.kv_grad_inject(dqkv, self.dkv_acc[i], P["crow"])
             ops.rope_rows_t_(dqkv, m.rope_cos, m.rope_sin, P["pos"], H, hd)
             dn1 = ops.gemm_bf16(ops.NN, dqkv, Wqkv, out=self._buf("p.dn1", (Mp, d)))
-            ops.gemm_bf16(ops.TN, dqkv, a["n1"], out=gqkv, epilogue=ops.EPI_ACCUM)
-            dx = ops.rmsnorm_bwd(dn1, a["x"], w1, a["rstd1"], gw1, resid_grad=dx1, out=self._buf(f"p.dx{i & 1}", (Mp, d)))
+            if defer:
+                # the episode's weight gradients of this layer: ONE GEMM per weight over every token row (prefix + all steps), fp32
+                # accumulation over the whole contraction.  The top layer's prefix rows carry no gradient outside q|k|v.
+                lo = 0 if dx is not None else Mp
+                if R > lo:
+                    ops.gemm_bf16(ops.TN, E["dxo"][lo:R], E["h"][lo:R], out=gd, epilogue=ops.EPI_ACCUM)
+                    ops.gemm_bf16(ops.TN, E["dgu"][lo:R], E["n2"][lo:R], out=ggu, epilogue=ops.EPI_ACCUM)
+                    ops.gemm_bf16(ops.TN, E["dx1"][lo:R], E["attn"][lo:R], out=go, epilogue=ops.EPI_ACCUM)
+                ops.gemm_bf16(ops.TN, E["dqkv"][:R], E["n1"][:R], out=gqkv, epilogue=ops.EPI_ACCUM)
+                dx = ops.rmsnorm_bwd(dn1, a["x"], w1, a["rstd1"], gw1, resid_grad=dx1,
+                                     out=self._E[i - 1]["dxo"][:Mp] if i > 0 else self._buf("p.dx0", (Mp, d)))
+            else:
+                ops.gemm_bf16(ops.TN, dqkv, a["n1"], out=gqkv, epilogue=ops.EPI_ACCUM)
+                dx = ops.rmsnorm_bwd(dn1, a["x"], w1, a["rstd1"], gw1, resid_grad=dx1, out=self._buf(f"p.dx{i & 1}", (Mp, d)))
             m._dp_layer_done(i, [])
+        if defer:
+            self._last_rows = R - Mp
+            self._cursor = 0
         self._embed_grad(dx, P["ids_np"])
         self.prefix = None
         dp = getattr(m, "_dp", None)

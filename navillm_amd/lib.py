@@ -34,6 +34,7 @@ SIGNATURES = {
     "nv_rope_rows_bf16": (i, [vp, vp, vp, ip, i, i, i, i, vp]),
     "nv_rope_rows_t_bf16": (i, [vp, vp, vp, ip, i, i, i, i, vp]),
     "nv_kv_grad_accum_f32": (i, [vp, fp, ip, i, i, vp]),
+    "nv_kv_grad_set_f32": (i, [vp, fp, ip, i, i, vp]),
     "nv_kv_grad_inject_bf16": (i, [vp, fp, ip, i, i, vp]),
     "nv_swiglu_fwd_bf16": (i, [vp, vp, i, i, vp]),
     "nv_swiglu_bwd_bf16": (i, [vp, vp, vp, i, i, vp]),

@@ -224,9 +224,10 @@ def scale_dev_bf16(x, scale_dev_f32, out=None, accumulate=False):
     return out
 
 
-def gather_rows_bf16(src, rows_i32):
+def gather_rows_bf16(src, rows_i32, out=None):
     n, d = rows_i32.numel(), src.shape[1]
-    out = torch.empty((n, d), dtype=BF16, device=src.device)
+    if out is None:
+        out = torch.empty((n, d), dtype=BF16, device=src.device)
     _lib.check(_L().nv_gather_rows_bf16(src.data_ptr(), rows_i32.data_ptr(), out.data_ptr(), n, d, _st()), "nv_gather_rows_bf16")
     return out
 
@@ -298,8 +299,13 @@ def rope_rows_t_(qkv, cos_t, sin_t, pos_i32, H, hd):
     return qkv
 
 
-def kv_grad_accum(dqkv_full, acc_f32, rows_i32):
+def kv_grad_accum(dqkv_full, acc_f32, rows_i32, first=False):
+    """first: acc[rows] = ... instead of += (the accumulator then needs no zero-fill)"""
     d = dqkv_full.shape[1] // 3
+    if first:
+        _lib.check(_L().nv_kv_grad_set_f32(dqkv_full.data_ptr(), acc_f32.data_ptr(), rows_i32.data_ptr(), rows_i32.numel(), d, _st()),
+                   "nv_kv_grad_set_f32")
+        return
     _lib.check(_L().nv_kv_grad_accum_f32(dqkv_full.data_ptr(), acc_f32.data_ptr(), rows_i32.data_ptr(), rows_i32.numel(), d, _st()),
                "nv_kv_grad_accum_f32")
 

@@ -36,12 +36,14 @@ def _episode(model, cfg, steps, use_prefix, seed=31, B=3, instr_len=180):
     return logits, grads, (stats if use_prefix else None)
 
 
-@pytest.mark.parametrize("size", ["mid", "7b-width"])
-def test_prefix_episode_matches_per_step_recompute(size):
+@pytest.mark.parametrize("size,defer", [("mid", "1"), ("mid", "0"), ("7b-width", "1")])
+def test_prefix_episode_matches_per_step_recompute(size, defer, monkeypatch):
     """mid: d=512, 3 layers; 7b-width: Vicuna-7B's d=4096 / 32 heads / ff=11008 with two layers (multi-tile GEMMs, split-K tails,
-    32 heads in the strided attention backward)"""
+    32 heads in the strided attention backward).  defer: the episode's weight gradients as ONE GEMM per weight over all token rows
+    at finish() (default) or accumulated step by step."""
     from navillm_amd.nav_model import NavModel
     from navillm_amd import config as nvcfg
+    monkeypatch.setenv("NAVILLM_EPISODE_DEFER_WGRAD", defer)
     cfg = _mid_cfg() if size == "mid" else nvcfg.vicuna_7b(image_feat_size=768, num_layers=2, base_vocab_size=2000)
     m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
     m.eval()                                                        # dropout off: both runs see the same encoder outputs

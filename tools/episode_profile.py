@@ -17,7 +17,8 @@ model.train()
 opt = FlatAdamW(model, lr=3e-5)
 crit = CrossEntropyLoss()
 ep = SyntheticEpisodes(cfg, 8, seed=1234, instr_len=512, device=dev)
-for rep in range(3):
+reps = int(os.environ.get("EPISODE_REPS", "3"))
+for rep in range(reps):
     ep.reset()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
