@@ -43,6 +43,12 @@ def parse():
     ap.add_argument("--extras-on-tiny", action="store_true", help="run the extras with --model tiny too (rehearsals)")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-3 (mixed tasks) and config-4 (64-step) extra measurements")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch GEMM event timing")
+    ap.add_argument("--mode", default=os.environ.get("NAVILLM_BENCH_MODE", "prefix_reuse"), choices=["prefix_reuse", "recompute"],
+                    help="how the training step treats the prompt's static prefix (instruction + template, ~530 of ~650 tokens): "
+                         "prefix_reuse (default) = forward once per episode, K/V reused by every step, one deferred prefix backward "
+                         "(navillm_amd/episode.py; gradients pinned to the reference by fixture G12); recompute = the whole prompt "
+                         "through the LM at every step like the reference's rollout.  The other mode is measured too and reported "
+                         "under `other_mode`.")
     return ap.parse_args()
 
 
@@ -136,6 +142,54 @@ def gemm_traffic_from_profile():
         return d.get("hbm_bytes_per_gemm_launch_all_layouts", d["hbm_bytes_per_forward_gemm_launch"]), f"profiles/{name}"
     return None, ("no PMC profile of the current gemm_bf16.hip under profiles/ (older ones refused: " + ", ".join(stale) + ")") if stale \
         else "no PMC profile under profiles/"
+
+
+MODE_WHAT = {
+    "prefix_reuse": "per 6-step episode the prompt's static prefix (task sentence + instruction + history header, ~530 of ~650 tokens) goes "
+                    "through the LM forward ONCE (K/V cached per layer); every nav step pushes only its suffix rows (history, candidates, "
+                    "hints, <cls_1>) forward and backward over the cache; one deferred backward through the prefix with the summed K/V "
+                    "gradients and ONE weight-gradient GEMM per weight over all of the episode's token rows close the episode "
+                    "(navillm_amd/episode.py).  Same losses and gradients as the per-step recompute up to bf16 rounding order -- the weights "
+                    "are frozen inside an episode (train.py:86-89) -- pinned to the reference's own 3-step episode by fixture G12 "
+                    "(tests/test_parity_gpu.py::test_g12_episode_accumulated_gradients_vs_reference[prefix_reuse])",
+    "recompute": "the whole ~650-token prompt goes through the LM forward and backward at every nav step, as the reference's rollout "
+                 "does it (tasks/agents/mp3d_agent.py:726,756)",
+}
+
+
+def roofline_of(timer, dt, steps, mode, model):
+    """the `roofline` object for the bf16 GEMM family over the launches the timer bracketed (HIP events on the launch stream)"""
+    g = timer.summary()
+    if g is None:
+        return None
+    allg = timer.summary(layouts=(0, 1, 2))
+    n_sampled = (steps + GemmTimer.SAMPLE_EVERY - 1) // GemmTimer.SAMPLE_EVERY      # timed steps that carried the events
+    # the dominant kernel is ONE template (gemm_bf16_kernel) in three operand layouts.  With the backward on a single stream (the
+    # default) every launch's event bracket is its kernel duration, so the roofline is taken over all of them; with the optional
+    # wgrad side stream only the forward launches run alone.
+    r = g if model.overlap_wgrad else allg
+    per = {n: timer.summary(layouts=(l,)) for n, l in (("forward_NT", 0), ("dgrad_NN", 1), ("wgrad_TN", 2))}
+    traffic, traffic_src = gemm_traffic_from_profile()
+    if mode != "recompute":
+        traffic, traffic_src = None, "the committed PMC profile is of the recompute-mode step (see other_mode)"
+    return {"bound": "mfma", "achieved": round(r["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(r["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "gemm_bf16_kernel<256,256,2,4,64,2,*,*,*,4,TME> -- every bf16 GEMM launch of every %d-th timed step, "
+                      "%d of the %d (forward y = x W^T, dgrad, wgrad of qkv / o / gate|up / down in every layer; in prefix_reuse mode the "
+                      "suffix steps' few-hundred-row GEMMs run the cut-off 128..224 x 256 tiles; bracketing all steps costs the step 0.9 %%)"
+                      % (GemmTimer.SAMPLE_EVERY, n_sampled, steps)
+                      if not model.overlap_wgrad else
+                      "gemm_bf16_kernel<256,256,2,4,64,2,true,true,*,4,*> (forward launches only: with the wgrad side stream the backward brackets overlap)",
+            "launches": r["launches"], "avg_launch_ms": round(r["avg_launch_ms"], 4),
+            "flops_per_launch": r["flops_per_launch"],
+            "by_layout_tflops": {n: (round(v["tflops"], 1) if v else None) for n, v in per.items()},
+            "all_gemm_flops_per_step": allg["flops_per_launch"] * allg["launches"] / n_sampled,
+            "gemm_share_of_step": round(allg["gemm_seconds"] / n_sampled / (dt / steps), 3),
+            "note": "peak = nominal dense bf16 MFMA; with N(0,1) operands the MFMA pipe of this part sustains 1.87-2.0 PFLOP/s "
+                    "(power-limited clock; tools/ubench/mix_rate.hip, DESIGN.md §4); traffic = 2*FETCH_SIZE+WRITE_SIZE per launch from the "
+                    "separate rocprofv3 --pmc passes committed under profiles/ (`traffic_source`; null when that profile was taken from "
+                    "another version of gemm_bf16.hip or another training mode)"}
 
 
 def inference_extras(a, model, wrapped, crit, ep):
@@ -245,41 +299,6 @@ def mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed):
                        f"cvdn, {STEPS_PER_EPISODE} nav steps each with per-step backward, and one ScanQA batch; B={a.batch}; clip+AdamW after each; "
                        f"algorithmic FLOPs per SURVEY.md §8d incl. lm_head in the LM-loss modes"}
     model.flop_log = None
-    return res
-
-
-def prefix_reuse_extra(a, cfg, model, wrapped, opt, crit, device, seed):
-    """NOT the headline: the same 6-step training episodes with the prompt's static prefix (instruction + fixed template,
-    ~530 of ~650 tokens) pushed through the LM forward and backward ONCE per episode instead of at every step
-    (navillm_amd/episode.py: exact by linearity of backpropagation while the weights are frozen inside an episode; parity vs
-    the per-step recompute in tests/test_episode_gpu.py).  `value` above recomputes the whole prompt at every step like the
-    reference does."""
-    from navillm_amd.synthetic import SyntheticEpisodes, prefix_reuse_episode
-    ep = SyntheticEpisodes(cfg, a.batch, seed=seed, instr_len=a.instr_len, device=device)
-    res = None
-    for rep in range(3):                      # first episode warms allocations and shapes
-        ep.reset()
-        model.flop_log = None
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        prefix_reuse_episode(wrapped, crit, ep, STEPS_PER_EPISODE)
-        opt.clip_grad_norm_(40.0); opt.step(); opt.zero_grad()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        st = model.episode.stats
-        S = [int(s) for s in ep.S_hist[-STEPS_PER_EPISODE:]]
-        recompute_rows = a.batch * sum(S)
-        d, ff, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_layers
-        f_recompute = 3.0 * (2.0 * L * (4 * d * d + 3 * d * ff) * recompute_rows + 2.0 * L * d * a.batch * sum(s * s for s in S))
-        res = {"nav_steps_per_s_per_gpu": round(a.batch * STEPS_PER_EPISODE / dt, 2), "ms_per_step": round(dt / STEPS_PER_EPISODE * 1e3, 1),
-               "token_rows_per_episode": {"prefix_once": int(st["prefix_rows"]), "suffix_per_step": [int(x) for x in st["suffix_rows"]],
-                                          "per_step_recompute": int(recompute_rows)},
-               "recompute_equivalent_tflops": round(f_recompute / dt / 1e12, 1),
-               "what": "6-step episodes, B=%d: prefix forward once, per-step suffix forward+backward, one deferred prefix backward, clip+AdamW; "
-                       "'recompute_equivalent_tflops' = algorithmic FLOPs of the per-step-recompute formulation divided by this wall time "
-                       "(it exceeds what the GEMMs execute: the point of the restructuring)" % a.batch}
-    model.episode = None
-    torch.cuda.empty_cache()
     return res
 
 
@@ -542,48 +561,90 @@ def main():
             wrapped.calibrate()        # all-reduce vs reduce-scatter + all-gather on one layer slice: keep the faster
     crit = CrossEntropyLoss()
     ep = SyntheticEpisodes(cfg, a.batch, seed=seed, instr_len=a.instr_len, device=device)
-    timer = GemmTimer()
+    import contextlib
 
-    def one_step(i):
-        last = (i % STEPS_PER_EPISODE) == STEPS_PER_EPISODE - 1
-        loss, logits = nav_step(wrapped, crit, ep, train=True, last=last)
-        if last:
-            opt.clip_grad_norm_(40.0)
-            opt.step()
-            opt.zero_grad()
-            ep.reset()
-        return loss
+    def make_step(mode):
+        prefix = mode == "prefix_reuse"
+
+        def one_step(i):
+            """iteration i of the rollout loop (tasks/agents/mp3d_agent.py:660) for the rank's B episodes; every 6th one ends the
+            episodes: (prefix mode: the prefix's single backward,) clip(40) + AdamW + zero_grad (train.py:86-89)"""
+            pos = i % STEPS_PER_EPISODE
+            last = pos == STEPS_PER_EPISODE - 1
+            if prefix and pos == 0:
+                model.begin_episode(ep.prefix_ids())          # static prompt prefix: forward once, K/V cached per layer
+            loss, logits = nav_step(wrapped, crit, ep, train=True, last=last, final=last and not prefix)
+            if last:
+                if prefix:
+                    ctx = wrapped.final_backward if hasattr(wrapped, "final_backward") else contextlib.nullcontext
+                    with ctx():                               # the LAST backward before the optimizer step: DP exchanges from inside it
+                        model.finish_episode()
+                opt.clip_grad_norm_(40.0)
+                opt.step()
+                opt.zero_grad()
+                ep.reset()
+            return loss
+        return one_step
+
+    def run_mode(mode, steps, warmup, prewarm, sync_ranks):
+        """`prewarm` untimed setup steps + `warmup` untimed steps, then `steps` timed ones bracketed by barrier + synchronize on both
+        sides -> (seconds (max over ranks), GemmTimer, last loss)"""
+        one_step = make_step(mode)
+        model.episode_abort()
+        ep.reset()
+        for i in range(prewarm):        # setup, not part of the protocol's W/K accounting
+            one_step(i)
+        model.episode_abort()
+        ep.reset()
+        for i in range(warmup):
+            one_step(i)
+        tm = GemmTimer()
+        if not a.no_profile:
+            tm.install(ops)
+        torch.cuda.synchronize()
+        if world > 1 and sync_ranks:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = None
+        for i in range(warmup, warmup + steps):
+            tm.active = (i - warmup) % GemmTimer.SAMPLE_EVERY == 0
+            loss = one_step(i)
+        torch.cuda.synchronize()
+        if world > 1 and sync_ranks:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if not a.no_profile:
+            tm.uninstall()
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if REHEARSAL else device)
+        if world > 1 and sync_ranks:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), tm, loss
 
     phase("model built")
-    for i in range(a.prewarm):          # setup, not part of the protocol's W/K accounting
-        one_step(i)
-    ep.reset()
-    for i in range(a.warmup):
-        one_step(i)
-    if not a.no_profile:
-        timer.install(ops)
-    phase("warm; timing starts")
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.warmup, a.warmup + a.steps):
-        timer.active = (i - a.warmup) % GemmTimer.SAMPLE_EVERY == 0
-        loss = one_step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if not a.no_profile:
-        timer.uninstall()
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if REHEARSAL else device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt, timer, loss = run_mode(a.mode, a.steps, a.warmup, a.prewarm, True)
+    seq_len_main = int(max(ep.S_hist)) if ep.S_hist else None
+    main_stats = dict(model.episode.stats) if (a.mode == "prefix_reuse" and model.episode is not None) else None
 
     phase(f"timed region done: {dt:.2f} s")
+    # ---- the OTHER training mode, same process, same model (reported under `other_mode`, never `value`)
+    other = None
+    if not a.no_extras or a.model != "tiny":
+        other_mode = "recompute" if a.mode == "prefix_reuse" else "prefix_reuse"
+        try:
+            o_steps = 2 * STEPS_PER_EPISODE
+            o_dt, o_timer, o_loss = run_mode(other_mode, o_steps, 0, STEPS_PER_EPISODE, False)
+            other = {"mode": other_mode, "nav_steps_per_s_per_gpu": round(a.batch * o_steps / o_dt, 2), "steps": o_steps,
+                     "ms_per_step": round(o_dt / o_steps * 1e3, 2), "roofline": roofline_of(o_timer, o_dt, o_steps, other_mode, model)}
+            if other_mode == "prefix_reuse" and model.episode is not None:
+                other["token_rows_last_episode"] = {"prefix_once": int(model.episode.stats["prefix_rows"]),
+                                                    "suffix_per_step": [int(x) for x in model.episode.stats["suffix_rows"]]}
+        except Exception as e:          # never take the headline line (or a rank) down
+            other = {"mode": other_mode, "error": f"{type(e).__name__}: {e}"}
+        model.episode_abort()
+        model.zero_grad()
+        ep.reset()
     # ---- untimed extra: the same nav step without loss/backward (validation rollout, mp3d_agent.py:530-590)
     infer = infer_kv = None
     if a.infer_steps > 0:
@@ -607,7 +668,6 @@ def main():
     if not a.no_extras and (a.model != "tiny" or a.extras_on_tiny):
         for name, fn in (("mixed_task_training_config3", lambda: mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed + 100)),
                          ("long_horizon_config4", lambda: long_horizon_extra(a, cfg, model, wrapped, crit, device, seed + 200)),
-                         ("training_prefix_reuse", lambda: prefix_reuse_extra(a, cfg, model, wrapped, opt, crit, device, seed + 400)),
                          ("fp8_weight_only_13b_config5", lambda: fp8_13b_extra(a, device, seed + 300) if world == 1 else None)):
             phase(name)
             try:        # never take the headline line (or a rank) down
@@ -623,7 +683,6 @@ def main():
 
     if rank == 0:
         value = a.batch * a.steps * world / dt
-        g = timer.summary()
         line = {
             "metric": "nav-steps/sec (whole node), Vicuna-7B + 36-view scene enc", "value": round(value, 3),
             "unit": "nav-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -632,9 +691,16 @@ def main():
             "config": {"workload": f"{a.model} + 36-view x {a.feat}-d scene encoder, R2R-shaped synthetic episodes, "
                                    f"batch={a.batch}/GPU, {a.instr_len}-token instructions, training step (fwd+bwd, "
                                    f"clip+AdamW every {STEPS_PER_EPISODE} steps)",
-                       "global_batch": a.batch * world, "seq_len": int(max(ep.S_hist)) if ep.S_hist else None,
-                       "parallelism": f"dp{world}", "loss": float(loss.detach()) if loss is not None else None},
+                       "global_batch": a.batch * world, "seq_len": seq_len_main,
+                       "parallelism": f"dp{world}", "loss": float(loss.detach()) if loss is not None else None,
+                       "training_mode": a.mode,
+                       "training_mode_what": MODE_WHAT[a.mode]},
         }
+        if main_stats is not None:
+            line["config"]["token_rows_last_episode"] = {"prefix_once": int(main_stats["prefix_rows"]),
+                                                         "suffix_per_step": [int(x) for x in main_stats["suffix_rows"]]}
+        if other is not None:
+            line["other_mode"] = other
         if REHEARSAL:
             line["rehearsal"] = "all ranks shared GPU 0 over gloo: control-flow check only, the numbers are meaningless"
         if world > 1:
@@ -647,34 +713,9 @@ def main():
         if infer_kv is not None:
             line["inference_prefix_kv_reuse"] = infer_kv
         line.update(extras)
-        if g is not None:
-            allg = timer.summary(layouts=(0, 1, 2))
-            n_sampled = (a.steps + GemmTimer.SAMPLE_EVERY - 1) // GemmTimer.SAMPLE_EVERY      # timed steps that carried the events
-            # the dominant kernel is ONE template (gemm_bf16_kernel) in three operand layouts.  With the backward on a
-            # single stream (the default) every launch's event bracket is its kernel duration, so the roofline is taken
-            # over all of them; with the optional wgrad side stream only the forward launches run alone.
-            r = g if model.overlap_wgrad else allg
-            per = {n: timer.summary(layouts=(l,)) for n, l in (("forward_NT", 0), ("dgrad_NN", 1), ("wgrad_TN", 2))}
-            traffic, traffic_src = gemm_traffic_from_profile()
-            line["roofline"] = {"bound": "mfma", "achieved": round(r["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                                "unit": "TFLOP/s", "frac": round(r["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
-                                "traffic": traffic, "traffic_source": traffic_src,
-                                "kernel": "gemm_bf16_kernel<256,256,2,4,64,2,*,*,*,4> -- every bf16 GEMM launch of every %d-th timed step, "
-                                          "%d of the %d (forward y = x W^T, dgrad, wgrad of qkv / o / gate|up / down in every layer; "
-                                          "bracketing all steps costs the step 0.9 %%)" % (GemmTimer.SAMPLE_EVERY, n_sampled, a.steps)
-                                          if not model.overlap_wgrad else
-                                          "gemm_bf16_kernel<256,256,2,4,64,2,true,true,*,4> (forward launches only: with the wgrad "
-                                          "side stream the backward brackets overlap)",
-                                "launches": r["launches"], "avg_launch_ms": round(r["avg_launch_ms"], 4),
-                                "flops_per_launch": r["flops_per_launch"],
-                                "by_layout_tflops": {n: (round(v["tflops"], 1) if v else None) for n, v in per.items()},
-                                "all_gemm_flops_per_step": allg["flops_per_launch"] * allg["launches"] / n_sampled,
-                                "gemm_share_of_step": round(allg["gemm_seconds"] / n_sampled / (dt / a.steps), 3),
-                                "note": "peak = nominal dense bf16 MFMA; with N(0,1) operands the MFMA pipe of this part sustains "
-                                        "1.87-2.0 PFLOP/s (power-limited clock; tools/ubench/mix_rate.hip, DESIGN.md §4); "
-                                        "traffic = 2*FETCH_SIZE+WRITE_SIZE per launch, averaged over the same launches as `achieved`, from the separate "
-                                        "rocprofv3 --pmc passes of this command committed under profiles/ (`traffic_source`; null when the committed "
-                                        "profile was taken from another version of gemm_bf16.hip)"}
+        rl = roofline_of(timer, dt, a.steps, a.mode, model)
+        if rl is not None:
+            line["roofline"] = rl
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         phase("done")

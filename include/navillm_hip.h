@@ -33,7 +33,8 @@ extern "C" {
  *   layout 2 "TN": A[K,M] B[K,N]  (wgrad    dW = dy^T x)         any K
  *   epilogue 0 store | 1 C = bf16(C + bf16(acc))  (grad accumulation)
  *            2 C = bf16(R[m,n] + bf16(acc))       (residual add)   | 3 C = bf16(acc + R[n]) (bias)
- *   tile_cfg 0 auto | 1 128x128 | 2 256x128 | 3 256x256.   lda/ldb multiples of 8, A/B 16-B aligned. */
+ *   tile_cfg 0 planned per shape | 1 128x128 | 8 256x256 | 84..88 the 256-wide tile cut off after 4..8 fragment rows per wave
+ *   (128 / 160 / 192 / 224 / 256 x 256; forward and dgrad layouts).   lda/ldb multiples of 8, A/B 16-B aligned. */
 int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K, int lda,
                  int ldb, int ldc, int ldr, int epilogue, int tile_cfg, void* stream);
 
@@ -53,6 +54,10 @@ int nv_gemv_bf16(const void* A, const void* W, void* C, const void* R, int M, in
  *   nv_gemm_bf16(NT) + nv_rope_bf16. */
 int nv_gemm_bf16_rope(const void* A, const void* W, void* C, const void* rope_cos, const void* rope_sin, const int* pos, int M,
                       int N, int K, int lda, int ldw, int ldc, int S, int rope_cols, void* workspace, void* stream);
+/*   the same with an explicit tile configuration (nv_gemm_bf16_ws's `tile_cfg`: 0 planned, 8 = 256x256, 84..88 = the 256-wide tile
+ *   cut off after 4..8 fragment rows per wave) */
+int nv_gemm_bf16_rope_cfg(const void* A, const void* W, void* C, const void* rope_cos, const void* rope_sin, const int* pos, int M,
+                          int N, int K, int lda, int ldw, int ldc, int S, int rope_cols, int tile_cfg, void* workspace, void* stream);
 
 /* ---- weight-only fp8 (OCP e4m3fn, one fp32 scale per output channel) for the LM's Linear layers: SURVEY.md §8f item 4 /
  *      BASELINE config 5 (Vicuna-13B inference).  W[n,:] ~= s[n]*q[n,:], s[n] = max|W[n,:]|/448, q = e4m3fn(W/s) (RNE).  The

@@ -21,6 +21,7 @@
 #include <type_traits>
 #include <utility>
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
@@ -343,132 +344,26 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         }
     };
 
-    if constexpr (PIPE == 5) {
-        // ---- "ping-pong": the two waves of a SIMD take turns on the matrix pipe ---------------------------------------
-        // A workgroup's waves w and w+4 share a SIMD.  Waves 0-3 (group A) and 4-7 (group B) run the same K loop half
-        // a step apart: while one group issues nothing but the 64 MFMAs of a K-tile, the other does all of its memory
-        // work for its next K-tile (24 fragment reads; group A also issues the CU's 64 LDS-DMAs, 16 per wave, because a
-        // stage always frees up right before one of A's memory slots).  Slots are separated by one s_barrier each
-        // (two per K-tile), fragments need no double buffering (a wave is either loading them or multiplying with them).
-        //   slot 2k  : A = MFMAs(k) then vmcnt(0)           | B = reads(k)
-        //   slot 2k+1: A = reads(k+1) + DMA(tile k+2 -> stage k%2) | B = MFMAs(k)
-        static_assert(NSTAGE == 2 && BKT == 64 && TM == 8 && TN == 4 && NT == 512, "ping-pong loop: 256x256x64, 8 waves");
-        static_assert(A_BYTES == B_BYTES, "one toggle serves both stage images");
-        FragAddr2<BM, A_KMAJ, TM, A_BYTES> fa2;
-        FragAddr2<BN, B_KMAJ, TN, B_BYTES> fb2;
-        fa2.init(wm * WTM, lane, smem_addr);
-        fb2.init(wn * WTN, lane, smem_addr + 2 * A_BYTES);
-        if (smem_addr & 0xffffu) __builtin_trap();
-        const bool grpA = __builtin_amdgcn_readfirstlane(wave) < 4;
-        bf16x8 fa[2][TM], fb[2][TN];
-        auto reads = [&]() {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int j = 0; j < TM; ++j) fa[kk][j] = fa2.load(j, kk);
-#pragma unroll
-                for (int i = 0; i < TN; ++i) fb[kk][i] = fb2.load(i, kk);
-            }
-        };
-        auto mma = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][i], fa[kk][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto flip = [&]() { fa2.flip(); fb2.flip(); };
-        stage(0, 0);
-        if (KT > 1) stage(1, 1);
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (grpA) {
-            // DMA addressing for the 4 issuing waves: piece `it` of an operand image = 4 KiB (chunk = it*4 + wave)
-            constexpr int ND = 256;
-            const int tidA = tid & 255;
-            const uint32_t a_pst = (uint32_t)((A_KMAJ ? (ND / 64) * (1024 / (BKT * 2)) : (ND / 64) * (1024 / (BM * 2))) * 2) * (uint32_t)p.lda;
-            const uint32_t b_pst = (uint32_t)((B_KMAJ ? (ND / 64) * (1024 / (BKT * 2)) : (ND / 64) * (1024 / (BN * 2))) * 2) * (uint32_t)p.ldb;
-            uint32_t pva[2], pvb[2];        // by piece parity: the MN-major swizzle key alternates with it
-#pragma unroll
-            for (int par = 0; par < 2; ++par) {
-                pva[par] = piece_voff<BM, A_KMAJ, ND, BKT>(m0, 0, p.lda, tidA, par) - par * a_pst;
-                pvb[par] = piece_voff<BN, B_KMAJ, ND, BKT>(n0, 0, p.ldb, tidA, par) - par * b_pst;
-                asm volatile("" : "+v"(pva[par]));
-                asm volatile("" : "+v"(pvb[par]));
-            }
-            const uint32_t m0base = __builtin_amdgcn_readfirstlane(smem_addr + (wave & 3) * 1024);
-            const uint32_t m0sum = 2 * m0base + A_BYTES;
-            uint32_t m0cur = m0base;
-            const uint32_t a_step = A_KMAJ ? BKT * 2 : (uint32_t)(BKT * 2) * (uint32_t)p.lda;
-            const uint32_t b_step = B_KMAJ ? BKT * 2 : (uint32_t)(BKT * 2) * (uint32_t)p.ldb;
-            uint64_t a_base = (uint64_t)p.A + (uint64_t)a_step * (kt0 + 2), b_base = (uint64_t)p.B + (uint64_t)b_step * (kt0 + 2);
-            uint32_t a_left = p.a_bytes - a_step * (uint32_t)(kt0 + 2), b_left = p.b_bytes - b_step * (uint32_t)(kt0 + 2);
-            reads();                                              // fragments of K-tile 0
-            for (int k = 0; k < KT; ++k) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                mma();                                            // slot 2k
-                if (k + 1 < KT) wait_vmcnt<0>();                  // tile k+1 (this wave's share) has landed
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                flip();                                           // slot 2k+1: fragments of K-tile k+1 ...
-                if (k + 1 < KT) reads();
-                if (k + 2 < KT) {                                 // ... and tile k+2 into the stage tile k just left
-                    const u32x4 da = make_desc((const void*)a_base, a_left);
-                    const u32x4 db = make_desc((const void*)b_base, b_left);
-                    static_for<16>([&](auto QC) {
-                        constexpr int q = decltype(QC)::value;
-                        if constexpr (q < 8) dma16_m0imm<q * (ND / 64) * 1024>(da, m0cur, pva[q & 1], a_pst * q);
-                        else dma16_m0imm<2 * A_BYTES + (q - 8) * (ND / 64) * 1024>(db, m0cur, pvb[q & 1], b_pst * (q - 8));
-                    });
-                    a_base += a_step; a_left -= a_step;
-                    b_base += b_step; b_left -= b_step;
-                }
-                m0cur = m0sum - m0cur;
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            for (int k = 0; k < KT; ++k) {
-                reads();                                          // slot 2k
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                mma();                                            // slot 2k+1
-                flip();
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    } else if constexpr (PIPE >= 1) {
+    if constexpr (PIPE >= 1) {
                 // ---- software-pipelined main loop (2 LDS stages, BK=64 = 2 k-steps of 32) ----------------------
         // Fragment registers are double-buffered: the ds_reads of k-step 1 are in flight under the MFMAs of
         // k-step 0, and the ds_reads of the NEXT tile's k-step 0 under the MFMAs of k-step 1.  One barrier
         // per K-tile, in the middle: it publishes tile kt+1 (DMA'd a full iteration earlier) and retires every
         // wave's reads of tile kt's buffer, which the DMA of tile kt+2 then overwrites.
         static_assert(NSTAGE == 2 && BKT == 64, "pipelined loop is written for 2 stages of BK=64");
-        FragAddr<BM, A_KMAJ, TM> fa_addr;
+        constexpr int FSA = IL ? WGM : 1;                      // fragment-row stride of a wave along M
+        FragAddr<BM, A_KMAJ, TM, FSA> fa_addr;
         FragAddr<BN, B_KMAJ, TN> fb_addr;
-        fa_addr.init(wm * WTM, lane);
+        fa_addr.init(IL ? wm * 16 : wm * WTM, lane);
         fb_addr.init(wn * WTN, lane);
         bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
         auto ldfr = [&](int buf, int kk, bf16x8(&fa)[TM], bf16x8(&fb)[TN]) {
             LDS_PTR(char) sa = smem + (PIPE >= 4 ? buf * A_BYTES : buf * (A_BYTES + B_BYTES));
             LDS_PTR(char) sb = smem + (PIPE >= 4 ? NSTAGE * A_BYTES + buf * B_BYTES : buf * (A_BYTES + B_BYTES) + A_BYTES);
 #pragma unroll
-            for (int j = 0; j < TM; ++j) fa[j] = fa_addr.load(sa, j, kk);
+            for (int j = 0; j < TMU; ++j) fa[j] = fa_addr.load(sa, j, kk);
 #pragma unroll
             for (int i = 0; i < TN; ++i) fb[i] = fb_addr.load(sb, i, kk);
-        };
-        auto mma = [&](bf16x8(&fa)[TM], bf16x8(&fb)[TN]) {
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
         };
         stage(0, 0);
         // counted wait only while nothing but DMA is in flight: a persistent block's later tiles still have the previous
@@ -476,7 +371,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         if (KT > 1) { stage(1, 1); if (first) wait_vmcnt<LOADS>(); else wait_vmcnt<0>(); } else { wait_vmcnt<0>(); }
         __builtin_amdgcn_s_barrier();
         ldfr(0, 0, fa0, fb0);
-        if constexpr (PIPE == 4) {
+        static_assert(PIPE == 4, "the software-pipelined prologue above serves the hand-interleaved loop only");
+        {
             // Hand-interleaved schedule: every non-MFMA instruction of a phase is slotted between groups of 4
             // MFMAs (an MFMA occupies the pipe for ~16 cycles but only one issue slot), so the matrix pipe never
             // waits for 12 ds_reads + 8 DMA issues to be pushed out first.  sched_barrier(0) after each group
@@ -489,10 +385,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
             // compiler-generated addressing cost were ~15% of the loop (tools/ubench/mix_rate.hip vs this kernel).
             static_assert(TM == 8 && TN == 4 && LOADS == 8, "interleave written for 128x64 wave tiles, 8 DMA/thread");
             constexpr int A_IT = A_BYTES / (NT * 16);
+            // DMA pieces of the A image a cut-off tile needs: a K-major piece is 64 rows (all of them for an MN-major image, whose
+            // pieces are k-rows)
+            constexpr int A_IT_EFF = A_KMAJ ? (BM_EFF + 63) / 64 : A_IT;
             static_assert(NSTAGE == 2 && 2 * A_BYTES <= 65536 && 2 * B_BYTES <= 65536, "stage offset must fit the ds_read immediate");
-            FragAddr2<BM, A_KMAJ, TM, A_BYTES> fa2;
+            static_assert(TME >= 4, "the read/MFMA slots below assume at least the first four A fragments are live");
+            FragAddr2<BM, A_KMAJ, TM, A_BYTES, WGM> fa2;
             FragAddr2<BN, B_KMAJ, TN, B_BYTES> fb2;
-            fa2.init(wm * WTM, lane, smem_addr);
+            fa2.init(wm * 16, lane, smem_addr);
             fb2.init(wn * WTN, lane, smem_addr + 2 * A_BYTES);
             // DMA source offsets: piece q of an operand = piece 0 + q * (a uniform number of bytes) -- the LDS swizzles
             // repeat every 8 KiB of image -- so ONE VGPR per operand plus a scalar offset per piece (the buffer bounds
@@ -520,19 +420,22 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
             if (smem_addr & 0xffffu) __builtin_trap();        // the xor stage toggles assume the dynamic LDS block starts 64 KiB-aligned (it starts at 0)
             auto body = [&](auto FULLC, bool more1, bool more2) {
                 constexpr bool FULL = decltype(FULLC)::value;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {                 // phase 1: MFMAs of k-step 0, loads of k-step 1
+                static_for<8>([&](auto CC) {                  // phase 1: MFMAs of k-step 0, loads of k-step 1
+                    constexpr int c = decltype(CC)::value;
                     // the 12 fragment reads go out in the first 6 groups, so the last one has two groups of MFMAs
                     // to land before the lgkmcnt(0) + barrier below (and before the loop-top wait of the next tile)
-                    if (c < 4) { fa1[c] = fa2.load(c, 1); fb1[c] = fb2.load(c, 1); }
-                    else if (c < 6) { fa1[2 * c - 4] = fa2.load(2 * c - 4, 1); fa1[2 * c - 3] = fa2.load(2 * c - 3, 1); }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = c >> 1, j = (c & 1) * 4 + e;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[i], fa0[j], acc[i][j], 0, 0, 0);
+                    if constexpr (c < 4) { fa1[c] = fa2.load(c, 1); fb1[c] = fb2.load(c, 1); }
+                    else if constexpr (c < 6) {
+                        if constexpr (2 * c - 4 < TME) fa1[2 * c - 4] = fa2.load(2 * c - 4, 1);
+                        if constexpr (2 * c - 3 < TME) fa1[2 * c - 3] = fa2.load(2 * c - 3, 1);
                     }
+                    static_for<4>([&](auto EC) {
+                        constexpr int e = decltype(EC)::value;
+                        constexpr int i = c >> 1, j = (c & 1) * 4 + e;
+                        if constexpr (j < TME) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[i], fa0[j], acc[i][j], 0, 0, 0);
+                    });
                     __builtin_amdgcn_sched_barrier(0);
-                }
+                });
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 wait_vmcnt<0>();
                 __builtin_amdgcn_s_barrier();
@@ -545,24 +448,32 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
                     constexpr int c = decltype(CC)::value;
                     if (FULL || more1) {
                         if constexpr (c < 4) { fa0[c] = fa2.load(c, 0); fb0[c] = fb2.load(c, 0); }
-                        else if constexpr (c < 6) { fa0[2 * c - 4] = fa2.load(2 * c - 4, 0); fa0[2 * c - 3] = fa2.load(2 * c - 3, 0); }
+                        else if constexpr (c < 6) {
+                            if constexpr (2 * c - 4 < TME) fa0[2 * c - 4] = fa2.load(2 * c - 4, 0);
+                            if constexpr (2 * c - 3 < TME) fa0[2 * c - 3] = fa2.load(2 * c - 3, 0);
+                        }
                     }
                     // one DMA piece of tile kt+2 per group (bunching them earlier measured 3-8% slower); M0 is written
                     // before the group's MFMAs and consumed after them (no s_nop, the hazard distance is free)
-                    if (FULL || more2) {
-                        if constexpr (c < A_IT) set_m0_imm<c * (NT / 64) * 1024>(m0cur);
-                        else set_m0_imm<2 * A_BYTES + (c - A_IT) * (NT / 64) * 1024>(m0cur);
+                    constexpr bool has_dma = (c >= A_IT) || (c < A_IT_EFF);     // A pieces beyond a cut-off tile's rows are skipped
+                    if constexpr (has_dma) {
+                        if (FULL || more2) {
+                            if constexpr (c < A_IT) set_m0_imm<c * (NT / 64) * 1024>(m0cur);
+                            else set_m0_imm<2 * A_BYTES + (c - A_IT) * (NT / 64) * 1024>(m0cur);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = c >> 1, j = (c & 1) * 4 + e;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[i], fa1[j], acc[i][j], 0, 0, 0);
-                    }
+                    static_for<4>([&](auto EC) {
+                        constexpr int e = decltype(EC)::value;
+                        constexpr int i = c >> 1, j = (c & 1) * 4 + e;
+                        if constexpr (j < TME) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[i], fa1[j], acc[i][j], 0, 0, 0);
+                    });
                     __builtin_amdgcn_sched_barrier(0);
-                    if (FULL || more2) {
-                        if constexpr (c < A_IT) dma16_m0set(da, pva, a_piece * c);
-                        else dma16_m0set(db, pvb, b_piece * (c - A_IT));
+                    if constexpr (has_dma) {
+                        if (FULL || more2) {
+                            if constexpr (c < A_IT) dma16_m0set(da, pva, a_piece * c);
+                            else dma16_m0set(db, pvb, b_piece * (c - A_IT));
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -577,23 +488,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
             int kt = 0;
             for (; kt + 2 < KT; ++kt) body(integral_constant<bool, true>{}, true, true);
             for (; kt < KT; ++kt) body(integral_constant<bool, false>{}, kt + 1 < KT, kt + 2 < KT);
-        } else {
-        for (int kt = 0; kt < KT; ++kt) {
-            const int buf = kt & 1;
-            ldfr(buf, 1, fa1, fb1);
-            mma(fa0, fb0);
-            // MFMAs are register-only: without a scheduling fence hipcc sinks them below the asm waits and
-            // the barrier (seen in the .s), which would serialise the phases again
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of this buffer have returned
-            wait_vmcnt<0>();                                      // my share of tile kt+1 has landed
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 2 < KT) stage(kt + 2, buf);
-            if (kt + 1 < KT) ldfr(buf ^ 1, 0, fa0, fb0);
-            mma(fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         }
     } else {
     // ---- NSTAGE-deep DMA pipeline: stages kt+1 .. kt+NSTAGE-1 are in flight while kt is computed.
@@ -630,7 +524,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j)
+                for (int j = 0; j < TMU; ++j)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
                                                            mine + ((((wave * TN + i) * TM + j) * 64 + lane) * 16), 0, 16);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -645,7 +539,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) {
+                    for (int j = 0; j < TMU; ++j) {
                         const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, part + ((((wave * TN + i) * TM + j) * 64 + lane) * 16), 0, 16));
                         acc[i][j] = (o == 0) ? v : acc[i][j] + v;
                     }
@@ -655,7 +549,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
 #pragma unroll
         for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int j = 0; j < TM; ++j)
+            for (int j = 0; j < TMU; ++j)
                 *(f32x4*)(mine + (size_t)(((wave * TN + i) * TM + j) * 64 + lane) * 4) = acc[i][j];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -681,7 +575,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) {
+                for (int j = 0; j < TMU; ++j) {
                     const f32x4 v = *(const f32x4*)(part + (size_t)(((wave * TN + i) * TM + j) * 64 + lane) * 4);
                     acc[i][j] = (o == 0) ? v : acc[i][j] + v;
                 }
@@ -705,8 +599,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     if (staged) {
         __syncthreads();                                  // every wave is done with the operand stages
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int ml = wm * WTM + j * 16 + mi;
+        for (int j = 0; j < TMU; ++j) {
+            const int ml = IL ? (j * WGM + wm) * 16 + mi : wm * WTM + j * 16 + mi;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 const int nl = wn * WTN + i * 16 + g * 4;
@@ -730,7 +624,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         const int n = n0 + c16 * 8;
         if (n < p.N) {
 #pragma unroll 4
-            for (int pass = 0; pass < BM / ROWS_PER_PASS; ++pass) {
+            for (int pass = 0; pass < BM_EFF / ROWS_PER_PASS; ++pass) {
                 const int ml = pass * ROWS_PER_PASS + r_in, m = m0 + ml;
                 if (m >= p.M) break;
                 u32x4 t = *(LDS_PTR(u32x4))(smem + ml * (BN * 2) + ((c16 ^ (ml & 15)) << 4));
@@ -790,8 +684,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         return;
     }
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * WTM + j * 16 + mi;
+    for (int j = 0; j < TMU; ++j) {
+        const int m = m0 + (IL ? (j * WGM + wm) * 16 + mi : wm * WTM + j * 16 + mi);
         if (m >= p.M) continue;
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
@@ -818,12 +712,98 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     }
 }
 
+// ---- host-side launch planning ------------------------------------------------------------------------------------------
+// Split-K tail: with one 256x256 block per CU, T tiles run in ceil(T/256) rounds and the last round is often nearly empty
+// (M=5152, N=4096: 336 tiles = 2 rounds for 1.31 rounds of work).  The tiles of a partial round that is at most half full are
+// cut into `split` K-slices so the round is ~full and 1/split as long.  Slices of >= ~20 K-tiles: shorter ones are dominated by
+// their prologue + slab hand-off (M=4744, tools/gemm_probe.py --cold: K=4096 o_proj forward / dgrad 893 / 852 TF with 4 slices
+// of 16, 957 / 894 with 3; the 344-K-tile gate|up dgrad 1198 with 4 slices, 1229 with 5).  NV_GEMM_MAXSPLIT / NV_GEMM_MINSLICE
+// are measurement knobs.  (Measured and removed in round 2/3: two uneven slices for a 50-80 % full round -- 3.5-8 % slower -- and
+// dispatching the tail slices first.)
+inline int tail_split(int rem, int KT) {
+    constexpr int CUS = 256;
+    if (rem <= 0 || rem > CUS / 2) return 1;
+    static const int max_split = [] { const char* e = getenv("NV_GEMM_MAXSPLIT"); return e ? atoi(e) : 6; }();
+    static const int min_slice = [] { const char* e = getenv("NV_GEMM_MINSLICE"); return e ? atoi(e) : 20; }();
+    int split = CUS / rem;
+    if (split > max_split) split = max_split;
+    if (split > KT / min_slice) split = KT / min_slice;
+    if (split * rem > MAX_SLABS) split = MAX_SLABS / rem;
+    return split >= 2 ? split : 1;
+}
+
+// Estimated duration (us) of the 256-wide tile kernel with TME fragment rows per wave (tile = 32*TME x 256) on an M x N x K
+// problem: full rounds of 256 tiles at t_k(TME) per 64-deep K-step, then the last partial round -- whole, at a K-step time that
+// shrinks a little with the fraction of CUs it occupies, or as split-K slices (slower K-steps: the slices of a tile share no
+// operand panels) plus the slab hand-off.  The constants are a least-squares fit (tools/fit_tme_model.py) to the durations
+// tools/gemm_tme_probe.py measured on MI355X for the four Linear shapes of Vicuna-7B at M = 500 .. 5134, forward (NT) and dgrad
+// (NN) layouts, TME = 4 .. 8 (profiles/r03_gemm_tme_probe.txt): rms error 7 % / 6 %.  What the fit says about the kernel: a
+// K-step costs 1.03 / 1.13 / 1.25 / 1.43 / 1.56 us at TME = 4 .. 8 -- half the MFMAs take two thirds of the time (the barrier,
+// the B-tile DMA and the fragment reads of B do not shrink with the tile), so a cut-off tile only pays where it removes a
+// mostly-empty round or a mostly-padding tile row.
+struct TmeModel { double tk[5], oh0, c0, fix0, fix1, kfrac; };
+inline const TmeModel& tme_model(bool b_kmaj) {
+    static const TmeModel nt{{1.032, 1.130, 1.250, 1.426, 1.559}, 0.0, 0.965, -30.2, 14.7, 1.331};
+    static const TmeModel nn{{1.047, 1.128, 1.238, 1.419, 1.618}, 0.0, 0.850, -19.4, 12.3, 1.255};
+    return b_kmaj ? nt : nn;
+}
+inline double est_us_256(int M, int N, int K, int tme, bool can_split, bool b_kmaj) {
+    const TmeModel& c = tme_model(b_kmaj);
+    const int bme = 32 * tme, KT = (K + 63) / 64;
+    const long T = (long)((M + bme - 1) / bme) * ((N + 255) / 256);
+    const double tk = c.tk[tme - 4], oh = c.oh0 * (0.5 + 0.5 * tme / 8.0);
+    const long full = T / 256;
+    const int rem = (int)(T % 256);
+    double t = full * (KT * tk + oh);
+    if (rem) {
+        const int split = can_split ? tail_split(rem, KT) : 1;
+        double f = rem * split / 256.0;
+        if (f > 1.0) f = 1.0;
+        const double tke = tk * (c.c0 + (1.0 - c.c0) * f);
+        if (split >= 2) {
+            double fix = c.fix0 + c.fix1 * split;
+            if (fix < 4.0) fix = 4.0;
+            t += (KT / (double)split) * tke * c.kfrac + oh + fix;
+        } else {
+            t += KT * tke + oh;
+        }
+    }
+    return t;
+}
+// 128x128 tile, two blocks per CU (tile_cfg 1), same probe: ~0.63 us per K-step while at most one block sits on a CU, 0.95 (NT) /
+// 0.80 (NN) with two; never with a long contraction (K >= 8192: 0.87-0.89 us per K-step even at 128 tiles)
+inline double est_us_128(int M, int N, int K, bool b_kmaj) {
+    if (K >= 8192) return 1e30;
+    const long T = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const int KT = (K + 63) / 64;
+    const long rounds = (T + 511) / 512;
+    return rounds * (KT * (T > 256 ? (b_kmaj ? 0.95 : 0.80) : 0.63) + 6.0);
+}
+// fragment rows per wave for this problem: the candidate with the smallest estimate; a cut-off tile must win by 3 %.
+// NV_GEMM_TME = 4..8 forces one (measurement), NV_GEMM_TME = 8 therefore restores the round-2 behaviour.
+inline int plan_tme(int M, int N, int K, bool can_split, bool b_kmaj, double* best_us) {
+    static const int forced = [] { const char* e = getenv("NV_GEMM_TME"); return e ? atoi(e) : 0; }();
+    if (forced >= 4 && forced <= 8) {
+        if (best_us) *best_us = est_us_256(M, N, K, forced, can_split, b_kmaj);
+        return forced;
+    }
+    int best = 8;
+    double tb = est_us_256(M, N, K, 8, can_split, b_kmaj);
+    const double t8 = tb;
+    for (int t = 7; t >= 4; --t) {
+        const double e = est_us_256(M, N, K, t, can_split, b_kmaj);
+        if (e < 0.97 * t8 && e < tb) { best = t; tb = e; }
+    }
+    if (best_us) *best_us = tb;
+    return best;
+}
+
 // Optional persistent form (NV_GEMM_PERSIST=1; off by default): the grid is at most one block per CU and each block walks
 // its work items (item, item + grid, ...; 256 % 8 == 0, so an item keeps the XCD its id implies); the C stores of tile i
 // drain while the first K-tiles of tile i+1 are already on their way into LDS.  Measured on MI355X: identical to the
 // hardware dispatcher placing one block per tile (1306 vs 1306 TFLOP/s at 5152x12288x4096) -- the ~10 us per round
 // of tiles that is not K-loop is prologue/epilogue latency inside the tile, not dispatch or store drain.
-template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE>
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE, int TME>
 __global__ __launch_bounds__(WGM* WGN * 64) __attribute__((amdgpu_waves_per_eu(1, ((NSTAGE * (BM + BN) * BKT * 2 > 80 * 1024) ? 1 : 2) * (WGM * WGN) / 4)))
 void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -833,7 +813,7 @@ void gemm_bf16_kernel(GemmArgs p) {
     for (int item = blockIdx.x; item < p.items; item += gridDim.x) {
         const bool first = item == (int)blockIdx.x;
         if (!first) __syncthreads();          // every wave is done with the LDS image of the previous tile's C
-        gemm_tile<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI, PIPE>(p, item, first, smem);
+        gemm_tile<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI, PIPE, TME>(p, item, first, smem);
     }
     // NV_GEMM_DEBUG bit 2 (measurement): block 0 leaves its core-clock cycles and 100 MHz wall ticks in the workspace
     // (bytes 2048..2063) -> average shader clock of the launch = 0.1 GHz * cycles / ticks
@@ -844,17 +824,18 @@ void gemm_bf16_kernel(GemmArgs p) {
     }
 }
 
-template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE = 0>
+template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE = 0, int TME = BM / WGM / 16>
 int launch(const GemmArgs& p, hipStream_t st) {
     constexpr int LDS = NSTAGE * (BM + BN) * BKT * 2;
-    auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI, PIPE>;
+    constexpr int BM_EFF = (PIPE == 4) ? WGM * TME * 16 : BM;
+    auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI, PIPE, TME>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return NV_ERR_LAUNCH;
         attr_done = true;
     }
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    const int tiles = ((p.M + BM_EFF - 1) / BM_EFF) * ((p.N + BN - 1) / BN);
     GemmArgs q = p;
     q.full_blocks = tiles; q.rem = 1; q.split = 1; q.kcut = 0; q.tail_first = 0;
     // Split-K tail: with one 256x256 block per CU, T tiles run in ceil(T/256) rounds and the last round is
@@ -863,32 +844,10 @@ int launch(const GemmArgs& p, hipStream_t st) {
     constexpr int CUS = 256;
     if (BM == 256 && BN == 256 && p.slabs && p.counters) {
         const int rem = tiles % CUS, KT = (p.K + BKT - 1) / BKT;
-        if (rem > 0 && rem <= CUS / 2) {
-            // slices of >= ~20 K-tiles: shorter ones are dominated by their prologue + slab hand-off (M=4744, tools/gemm_probe.py --cold:
-            // K=4096 o_proj forward / dgrad 893 / 852 TF with 4 slices of 16, 957 / 894 with 3; the 344-K-tile gate|up dgrad
-            // 1198 with 4 slices, 1229 with 5).  NV_GEMM_MAXSPLIT / NV_GEMM_MINSLICE: measurement knobs.
-            static const int max_split = [] { const char* e = getenv("NV_GEMM_MAXSPLIT"); return e ? atoi(e) : 6; }();
-            static const int min_slice = [] { const char* e = getenv("NV_GEMM_MINSLICE"); return e ? atoi(e) : 20; }();
-            int split = CUS / rem;
-            if (split > max_split) split = max_split;
-            if (split > KT / min_slice) split = KT / min_slice;
-            if (split * rem > MAX_SLABS) split = MAX_SLABS / rem;
-            if (split >= 2) { q.full_blocks = tiles - rem; q.rem = rem; q.split = split; }
-        } else if (rem > CUS / 2) {
-            // 50-80 % full last round: two UNEVEN slices per tail tile.  The rem long slices occupy rem CUs; the CUS - rem others
-            // work off the rem short slices, r = ceil(rem / (CUS - rem)) each; balanced when long = r * short.
-            // OFF by default (NV_GEMM_UNEVEN=1 enables): correct, but measured 3.5-8 % SLOWER where it applies (M=4744: q|k|v forward
-            // rem 144: 1189 -> 1147 TF; down-proj wgrad rem 176: 1168 -> 1069 TF) -- two 256-KiB fp32 slabs per tail tile through the
-            // fabric plus the reducer's serial read cost more than the third of a round the split saves.
-            static const int uneven = [] { const char* e = getenv("NV_GEMM_UNEVEN"); return e ? atoi(e) : 0; }();
-            const int r = (rem + (CUS - rem) - 1) / (CUS - rem);
-            const int kcut = (int)(((long)KT * r + r / 2) / (r + 1));
-            if (uneven && r <= 4 && KT - kcut >= 8 && 2 * rem <= MAX_SLABS) { q.full_blocks = tiles - rem; q.rem = rem; q.split = 2; q.kcut = kcut; }
-        }
+        const int split = tail_split(rem, KT);
+        if (split >= 2) { q.full_blocks = tiles - rem; q.rem = rem; q.split = split; }
     }
     const int ntail = q.split > 1 ? q.rem * q.split : 0;
-    static const int tail_first = [] { const char* e = getenv("NV_GEMM_TAIL_FIRST"); return e ? atoi(e) : 0; }();
-    if (ntail > 0 && tail_first && q.full_blocks > 0) q.tail_first = (ntail + 7) & ~7;
     q.items = q.full_blocks + (q.tail_first ? q.tail_first : ntail);
     // persistent blocks for the interleaved kernel (its prologue/epilogue are the per-tile fixed cost worth hiding)
     const int grid = (PIPE == 4 && p.persist && q.items > CUS) ? CUS : q.items;
@@ -896,29 +855,42 @@ int launch(const GemmArgs& p, hipStream_t st) {
     return nv_check_launch();
 }
 
+// cut-off tiles (TME < 8) are instantiated for the GEMMs of few-hundred-row steps (K/V-reuse inference, the suffix steps of
+// navillm_amd/episode.py) and of the forward pass: y = x W^T with the store / residual / RoPE epilogues, and the dgrad dx = dy W
+template <bool A_KMAJ, bool B_KMAJ, int EPI>
+constexpr bool tme_instances = (A_KMAJ && B_KMAJ && (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_ROPE)) || (A_KMAJ && !B_KMAJ && EPI == EPI_STORE);
+
+template <bool A_KMAJ, bool B_KMAJ, int EPI>
+int launch_tme(const GemmArgs& p, int tme, hipStream_t st) {
+    if constexpr (tme_instances<A_KMAJ, B_KMAJ, EPI>) {
+        switch (tme) {
+            case 4: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4, 4>(p, st);
+            case 5: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4, 5>(p, st);
+            case 6: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4, 6>(p, st);
+            case 7: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4, 7>(p, st);
+        }
+    }
+    return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4, 8>(p, st);
+}
+
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
 int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
-    // tile_cfg: 0 = auto, 1 = 128x128x64 2-stage (4 waves), 3 = 256x256x64 2-stage (8 waves), 6 = 3 with software-
-    //           pipelined fragments, 8 = 3 with the hand-interleaved, VALU-free main loop, 9 = 8-wave ping-pong
-    //           (experimental: measured 5-13% behind 8)
+    // tile_cfg: 0 = auto (128x128 or the 256-wide tile with the planned number of fragment rows), 1 = 128x128x64 2-stage (4 waves),
+    //           8 = 256x256x64 (8 waves, hand-interleaved VALU-free main loop), 84..88 = the same with TME = 4..8 fragment rows per
+    //           wave, i.e. a 128 / 160 / 192 / 224 / 256 x 256 tile (88 == 8; where no cut-off instance exists the full tile runs)
+    const bool can_split = p.slabs && p.counters;
     if (tile_cfg == 0) {
-        // measured on MI355X (profiles/r01_gemm_probe*.txt): the 256x256 tile wins from ~1.4 rounds
-        // of the 256 CUs upward, in all three layouts
-        const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        // hand-interleaved schedule (8) in all three layouts: since its addressing moved to SGPRs/immediates the
-        // wgrad (TN) instance no longer spills and beats the compiler-scheduled loop (6) by ~15%
-        // round 2 (tools/gemm_smallm.py, the few-hundred-row GEMMs of a K/V-reuse inference step): below 128 tiles the 256x256
-        // tile still wins when K is long (down_proj: K = 11008 / 13824) -- the whole launch is then a "partial round" that the
-        // split-K tail cuts into K-slices (M=800, N=4096, K=11008: 124 vs 150 us) -- and loses when K is short (o_proj: 74 vs 48 us)
-        tile_cfg = (t256 >= 128 || p.K >= 8192) ? 8 : 1;
+        // round 3: by estimated duration (est_us_*): the cut-off tiles move the break-even towards the 256-wide kernel
+        double t256;
+        const int tme = tme_instances<A_KMAJ, B_KMAJ, EPI> ? plan_tme(p.M, p.N, p.K, can_split, B_KMAJ, &t256)
+                                                           : (t256 = est_us_256(p.M, p.N, p.K, 8, can_split, B_KMAJ), 8);
+        if (est_us_128(p.M, p.N, p.K, B_KMAJ) < t256)
+            return launch<128, 128, 2, 2, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
+        return launch_tme<A_KMAJ, B_KMAJ, EPI>(p, tme, st);
     }
-    switch (tile_cfg) {
-        case 1: return launch<128, 128, 2, 2, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
-        case 3: if constexpr (EPI != EPI_SWIGLU_BWD && EPI != EPI_ROPE) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st); else return NV_ERR_ARG;
-        case 6: if constexpr (EPI != EPI_SWIGLU_BWD && EPI != EPI_ROPE) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 1>(p, st); else return NV_ERR_ARG;   // software-pipelined fragments
-        case 8: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4>(p, st);   // hand-interleaved phases
-        case 9: if constexpr (EPI <= EPI_RESID) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 5>(p, st); else return NV_ERR_ARG;   // ping-pong (experimental)
-    }
+    if (tile_cfg == 1) return launch<128, 128, 2, 2, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
+    if (tile_cfg == 8) return launch_tme<A_KMAJ, B_KMAJ, EPI>(p, 8, st);
+    if (tile_cfg >= 84 && tile_cfg <= 88) return launch_tme<A_KMAJ, B_KMAJ, EPI>(p, tile_cfg - 80, st);
     return NV_ERR_ARG;
 }
 
@@ -931,13 +903,11 @@ int dispatch_epi(const GemmArgs& p, int epi, int tile_cfg, hipStream_t st) {
         case EPI_BIAS: return dispatch_tile<A_KMAJ, B_KMAJ, EPI_BIAS>(p, tile_cfg, st);
         case EPI_ROPE:            // only the packed q|k|v projection uses it: NT layout, production tiles, staged epilogue
             if constexpr (A_KMAJ && B_KMAJ) {
-                if (tile_cfg == 3 || tile_cfg == 6) return NV_ERR_ARG;
                 return dispatch_tile<A_KMAJ, B_KMAJ, EPI_ROPE>(p, tile_cfg, st);
             }
             return NV_ERR_ARG;
         case EPI_SWIGLU_BWD:      // only the down-proj dgrad uses it: NN layout, production tiles
             if constexpr (A_KMAJ && !B_KMAJ) {
-                if (tile_cfg == 3 || tile_cfg == 6) return NV_ERR_ARG;
                 return dispatch_tile<A_KMAJ, B_KMAJ, EPI_SWIGLU_BWD>(p, tile_cfg, st);
             }
             return NV_ERR_ARG;
@@ -1018,13 +988,18 @@ extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C
 // y = x W^T for the packed q|k|v projection with RoPE applied to the first `rope_cols` columns (q and k) in the epilogue:
 // row m has position pos[m] (pos != NULL: packed rows) or m % S; cos/sin = nv_rope_bf16's [maxS][128] bf16 tables.  Bit-identical to
 // nv_gemm_bf16(NT) followed by nv_rope_bf16; saves one read+write pass over q and k.
+extern "C" int nv_gemm_bf16_rope_cfg(const void* A, const void* W, void* C, const void* rope_cos, const void* rope_sin, const int* pos,
+                                     int M, int N, int K, int lda, int ldw, int ldc, int S, int rope_cols, int tile_cfg, void* workspace,
+                                     void* stream) {
+    if (!rope_cos || !rope_sin || (!pos && S <= 0) || rope_cols < 0 || rope_cols > N || (rope_cols & 127)) return NV_ERR_ARG;
+    if ((ldc & 7) || (N & 7) || (((uintptr_t)C) & 15) || ((((uintptr_t)rope_cos) | ((uintptr_t)rope_sin)) & 15)) return NV_ERR_SHAPE;
+    return gemm_entry(0, A, W, C, rope_cos, M, N, K, lda, ldw, ldc, 0, EPI_ROPE, tile_cfg, workspace, stream, rope_sin, S > 0 ? S : 1,
+                      rope_cols, pos);
+}
 extern "C" int nv_gemm_bf16_rope(const void* A, const void* W, void* C, const void* rope_cos, const void* rope_sin, const int* pos,
                                  int M, int N, int K, int lda, int ldw, int ldc, int S, int rope_cols, void* workspace,
                                  void* stream) {
-    if (!rope_cos || !rope_sin || (!pos && S <= 0) || rope_cols < 0 || rope_cols > N || (rope_cols & 127)) return NV_ERR_ARG;
-    if ((ldc & 7) || (N & 7) || (((uintptr_t)C) & 15) || ((((uintptr_t)rope_cos) | ((uintptr_t)rope_sin)) & 15)) return NV_ERR_SHAPE;
-    return gemm_entry(0, A, W, C, rope_cos, M, N, K, lda, ldw, ldc, 0, EPI_ROPE, 0, workspace, stream, rope_sin, S > 0 ? S : 1, rope_cols,
-                      pos);
+    return nv_gemm_bf16_rope_cfg(A, W, C, rope_cos, rope_sin, pos, M, N, K, lda, ldw, ldc, S, rope_cols, 0, workspace, stream);
 }
 
 extern "C" int nv_gemm_bf16(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K,

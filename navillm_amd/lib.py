@@ -19,6 +19,7 @@ SIGNATURES = {
     "nv_gemm_bf16_workspace_bytes": (sz, []),
     "nv_gemm_bf16_ws": (i, [i, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, vp, vp]),
     "nv_gemm_bf16_rope": (i, [vp, vp, vp, vp, vp, ip, i, i, i, i, i, i, i, i, vp, vp]),
+    "nv_gemm_bf16_rope_cfg": (i, [vp, vp, vp, vp, vp, ip, i, i, i, i, i, i, i, i, i, vp, vp]),
     "nv_gemv_bf16": (i, [vp, vp, vp, vp, i, i, i, i, i, i, i, i, vp]),
     "nv_fp8_quant_rows": (i, [vp, vp, fp, i, i, i, i, vp]),
     "nv_fp8_dequant_rows": (i, [vp, fp, vp, i, i, i, i, vp]),

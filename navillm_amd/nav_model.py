@@ -286,6 +286,12 @@ class NavModel(nn.Module):
         if self.episode is not None:
             self.episode.finish()
 
+    def episode_abort(self):
+        """drop an episode that was begun but will not be finished (its deferred gradients are discarded)"""
+        if self.episode is not None:
+            self.episode.prefix = None
+            self.episode._cursor = 0
+
     def _lm_episode(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None):
         ids_l, vix_l, vis_all, _ = self._vis_layout(ids_cpu, am_cpu, cand_vis, hist_vis, obj_vis)
         return self.episode.lm(ids_l, vix_l, vis_all)

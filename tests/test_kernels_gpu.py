@@ -37,10 +37,12 @@ def assert_close(got, ref, rtol, atol_scale, what):
 
 
 # ------------------------------------------------------------------------------ bf16 GEMM
-@pytest.mark.parametrize("tile", [1, 3, 6, 8, 9])
+@pytest.mark.parametrize("tile", [0, 1, 8, 84, 85, 86, 87])
 @pytest.mark.parametrize("layout", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 192), (77, 520, 64), (1000, 384, 448)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 192), (77, 520, 64), (1000, 384, 448), (670, 1024, 320)])
 def test_gemm_bf16_layouts(layout, tile, M, N, K):
+    """tile: 0 = planned, 1 = 128x128, 8 = 256x256, 84..87 = the 256-wide tile cut off after 4..7 fragment rows per wave
+    (128 / 160 / 192 / 224 x 256; layouts without a cut-off instance run the full tile)"""
     from navillm_amd import ops
     if layout == 2:
         Kc = K + 37          # wgrad: ragged contraction length
@@ -93,16 +95,69 @@ def test_gemm_bf16_splitk_tail(layout, M, N, K):
         A, B = rnd(K, M, dtype=BF, seed=19), rnd(K, N, dtype=BF, seed=20, scale=0.05)
         ref = A.float().t() @ B.float()
     for rep in range(3):
-        out = ops.gemm_bf16(layout, A, B, tile_cfg=3 if rep < 2 else 6)
+        out = ops.gemm_bf16(layout, A, B, tile_cfg=8 if rep < 2 else 0)
         torch.cuda.synchronize()
         assert_close(out, ref, 2 ** -7, 2e-3, f"split-K tail layout={layout} {M}x{N}x{K} rep {rep}")
     ops.SPLITK_TAIL = False
     try:
-        out2 = ops.gemm_bf16(layout, A, B, tile_cfg=3)
+        out2 = ops.gemm_bf16(layout, A, B, tile_cfg=8)
     finally:
         ops.SPLITK_TAIL = True
     # same products, different summation split: equal up to fp32 reassociation before the bf16 rounding
     assert (out.float() - out2.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("tile", [84, 85, 86, 87])
+def test_gemm_bf16_cut_off_tiles_epilogues_and_split_tail(tile):
+    """the cut-off tiles (TME = 4..7 fragment rows per wave) through every epilogue they are instantiated for -- store, residual,
+    RoPE (vs the separate row kernel, bit for bit) -- on shapes with ragged M / N edges, and on a shape whose tile count leaves a
+    split-K tail (slab image of a cut-off tile); the full tile (8) is the reference for bit-identity of the K-sum order"""
+    from navillm_amd import ops
+    M, N, K = 670, 1536, 512
+    A, W = rnd(M, K, dtype=BF, seed=31), rnd(N, K, dtype=BF, seed=32, scale=0.05)
+    ref = A.float() @ W.float().t()
+    out = ops.gemm_bf16(0, A, W, tile_cfg=tile)
+    assert_close(out, ref, 2 ** -7, 2e-3, f"cut-off store tile={tile}")
+    full = ops.gemm_bf16(0, A, W, tile_cfg=8)
+    assert torch.equal(out, full), "a cut-off tile must give the full tile's result bit for bit (same K order per output)"
+    R = rnd(M, N, dtype=BF, seed=33)
+    out = ops.gemm_bf16(0, A, W, R=R, epilogue=ops.EPI_RESID, tile_cfg=tile)
+    assert torch.equal(out, ops.gemm_bf16(0, A, W, R=R, epilogue=ops.EPI_RESID, tile_cfg=8))
+    dY, Wn = rnd(M, K, dtype=BF, seed=34), rnd(K, N, dtype=BF, seed=35, scale=0.05)
+    out = ops.gemm_bf16(1, dY, Wn, tile_cfg=tile)
+    assert_close(out, dY.float() @ Wn.float(), 2 ** -7, 2e-3, f"cut-off dgrad tile={tile}")
+    assert torch.equal(out, ops.gemm_bf16(1, dY, Wn, tile_cfg=8))
+    # split-K tail with cut-off tiles: M = 2104 -> 11 / 9 / 14 / 10 tile rows x 12 columns
+    M2, N2, K2 = 2104, 3072, 4096
+    A2, W2 = rnd(M2, K2, dtype=BF, seed=36), rnd(N2, K2, dtype=BF, seed=37, scale=0.05)
+    ref2 = A2.float() @ W2.float().t()
+    for rep in range(2):
+        out2 = ops.gemm_bf16(0, A2, W2, tile_cfg=tile)
+        torch.cuda.synchronize()
+        assert_close(out2, ref2, 2 ** -7, 2e-3, f"cut-off split tail tile={tile} rep {rep}")
+
+
+def test_gemm_qkv_rope_cut_off_tiles_bit_identical():
+    """RoPE epilogue on cut-off tiles == the full tile == GEMM + the separate RoPE row kernel (packed rows with a position array)"""
+    from navillm_amd import ops, lib
+    M, H, hd, K = 670, 4, 128, 512
+    d = H * hd
+    x, W = rnd(M, K, dtype=BF, seed=41), rnd(3 * d, K, dtype=BF, seed=42, scale=0.05)
+    pos = (torch.arange(M, dtype=torch.int32) % 211).to(dev())
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    ang = torch.arange(256, dtype=torch.float32)[:, None] * inv[None, :]
+    cos_t = torch.cat([ang.cos(), ang.cos()], 1).to(BF).to(dev())
+    sin_t = torch.cat([ang.sin(), ang.sin()], 1).to(BF).to(dev())
+    plain = ops.gemm_bf16(0, x, W, tile_cfg=8)
+    ops.rope_rows_(plain, cos_t, sin_t, pos, H, hd)
+    L = ops._L()
+    for tme in (4, 5, 6, 7, 8):
+        out = torch.empty((M, 3 * d), dtype=BF, device=dev())
+        rc = L.nv_gemm_bf16_rope_cfg(x.data_ptr(), W.data_ptr(), out.data_ptr(), cos_t.data_ptr(), sin_t.data_ptr(), pos.data_ptr(), M, 3 * d, K,
+                                     K, K, 3 * d, 0, 2 * d, 80 + tme, ops._gemm_ws(x.device), ops._st())
+        lib.check(rc, "nv_gemm_bf16_rope_cfg")
+        torch.cuda.synchronize()
+        assert torch.equal(out, plain), f"RoPE epilogue on TME={tme} tiles differs from GEMM + rope_rows"
 
 
 def test_gemm_bf16_large_llama_shapes():
