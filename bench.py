@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--extras-on-tiny", action="store_true", help="run the extras with --model tiny too (rehearsals)")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-3 (mixed tasks) and config-4 (64-step) extra measurements")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch GEMM event timing")
+    ap.add_argument("--no-other-mode", action="store_true", help="do not measure the other training mode (kernel traces of one mode)")
     ap.add_argument("--mode", default=os.environ.get("NAVILLM_BENCH_MODE", "prefix_reuse"), choices=["prefix_reuse", "recompute"],
                     help="how the training step treats the prompt's static prefix (instruction + template, ~530 of ~650 tokens): "
                          "prefix_reuse (default) = forward once per episode, K/V reused by every step, one deferred prefix backward "
@@ -630,7 +631,7 @@ def main():
     phase(f"timed region done: {dt:.2f} s")
     # ---- the OTHER training mode, same process, same model (reported under `other_mode`, never `value`)
     other = None
-    if not a.no_extras or a.model != "tiny":
+    if (not a.no_extras or a.model != "tiny") and not a.no_other_mode:
         other_mode = "recompute" if a.mode == "prefix_reuse" else "prefix_reuse"
         try:
             o_steps = 2 * STEPS_PER_EPISODE

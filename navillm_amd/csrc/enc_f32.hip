@@ -273,14 +273,31 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const float* __r
     }
 }
 
-// out[c] (+)= sum_p part[p,c]
+// out[c] (+)= sum_p part[p,c].  One block = 64 columns x 4 row lanes, 8 independent partial sums per thread (the first version
+// walked the P rows of a column in ONE dependent chain: 36 us for 288 rows -- 33 launches per nav step, 7 ms per episode).
 __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int d,
                                                          long stride, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= d) return;
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += part[(long)p * stride + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < d) {
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* q = part + c;
+        int p = ty;
+        for (; p + 28 < P; p += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += q[(long)(p + 4 * u) * stride];
+        }
+        for (; p < P; p += 4) a[0] += q[(long)p * stride];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < d) {
+        s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        out[c] = accumulate ? out[c] + s : s;
+    }
 }
 
 // ---------------------------------------------------------------- multi-head self-attention core
@@ -585,15 +602,15 @@ int nv_layernorm_bwd_f32(const float* dy, const float* x, const float* w, const 
     float* dbp = dgp + (size_t)128 * d;
     hipStream_t st = (hipStream_t)stream;
     NV_LAUNCH(layernorm_bwd_kernel<4>, dim3(P), dim3(256), 0, st, dy, x, w, mean, rstd, dx, dgp, dbp, M, d);
-    NV_LAUNCH(colsum_f32_kernel, dim3((d + 255) / 256), dim3(256), 0, st, dgp, gw, P, d, (long)d, accumulate);
-    NV_LAUNCH(colsum_f32_kernel, dim3((d + 255) / 256), dim3(256), 0, st, dbp, gb, P, d, (long)d, accumulate);
+    NV_LAUNCH(colsum_f32_kernel, dim3((d + 63) / 64), dim3(256), 0, st, dgp, gw, P, d, (long)d, accumulate);
+    NV_LAUNCH(colsum_f32_kernel, dim3((d + 63) / 64), dim3(256), 0, st, dbp, gb, P, d, (long)d, accumulate);
     return nv_check_launch();
 }
 
 // out[c] (+)= sum_m x[m,c]   (bias gradients)
 int nv_colsum_f32(const float* x, float* out, int M, int d, int ld, int accumulate, void* stream) {
     if (!x || !out) return NV_ERR_ARG;
-    NV_LAUNCH(colsum_f32_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, out, M, d, (long)ld,
+    NV_LAUNCH(colsum_f32_kernel, dim3((d + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, out, M, d, (long)ld,
                        accumulate);
     return nv_check_launch();
 }

@@ -48,13 +48,10 @@ struct GemmArgs {
     int col_strips;         // 1: walk column strips of 8 tiles (XCDs partition B), 0: row groups (XCDs partition A)
     // split-K tail (see launch()): blocks >= full_blocks are K-slices of the last, partial round of tiles
     int full_blocks, rem, split;
-    int kcut;               // split == 2 only: K-tiles of slice 0 (the rest is slice 1); 0 = equal slices
     int c_nt;               // C-tile store mode (store_c)
-    int slab_sc1;           // split-K hand-off through write-through (sc1) slab stores / loads instead of release + acquire fences
-    int tail_first;         // > 0: the first `tail_first` items are the tail K-slices (padded to a multiple of 8 with no-op items),
-                            // the full tiles follow: the slab hand-off + reduction of the split tiles then overlaps the full tiles
+    int band_reduce;        // split-K hand-off: 1 = every slice reduces one row band of its tile (default), 0 = the last arriver reduces all
     float* slabs;           // [rem*split][BM*BN] fp32 partials
-    unsigned* counters;     // [rem] arrival tickets, zero between launches
+    unsigned* counters;     // [2][512] arrival / departure tickets per tail tile, zero between launches
     int debug;              // NV_GEMM_DEBUG (measurement only): bit0 skip the C stores, bit1 skip the K loop, bit2 record clocks
     int items, persist;     // work items of the launch (tiles + tail K-slices); persistent-block mode on/off
     // EPI_ROPE (packed q|k|v projection): rotate the q and k columns (n < rope_cols) as they are written; position of row
@@ -266,23 +263,30 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM_EFF - 1) / BM_EFF;
     int tile_b = item, ks = 0, nsplit = 1, tail_u = 0;
-    if (p.tail_first) {                      // uniform per block
-        if (item < p.tail_first) {
-            if (item >= p.rem * p.split) return;          // padding item (keeps blockIdx % 8 == XCD aligned with the tile order)
-            ks = item / p.rem;
-            tail_u = item % p.rem;
-            tile_b = p.full_blocks + tail_u;
-            nsplit = p.split;
-        } else {
-            tile_b = item - p.tail_first;
-        }
-    } else if (tile_b >= p.full_blocks) {
+    if (tile_b >= p.full_blocks) {
+        // K-slices of the last, partial round.  Tail item q -> XCD x = q % 8 (block b runs on XCD b % 8; full_blocks % 8 == 0 is not
+        // needed for correctness) and position idx = q / 8 inside that XCD's run; the run holds the XCD's contiguous chunk of tail
+        // tiles, ALL slices of a tile next to each other (idx = tile * split + slice).  So the slices of a tile are dispatched
+        // within 8 * split consecutive blocks -- the band reduction below makes them wait for one another, and at most one tile per
+        // XCD can be partly dispatched at any time -- and the same-slice blocks an XCD runs side by side work on neighbouring tiles
+        // at the same K range (shared operand panels in that XCD's L2).
         const int q = tile_b - p.full_blocks;
-        ks = q / p.rem;
-        tail_u = q % p.rem;
+        const int x = q & 7, idx = q >> 3;                             // full_blocks % 256 == 0: x IS this block's XCD
+        const int per = p.rem >> 3, extra = p.rem & 7;                 // tail tiles of XCD x: per (+1 for x < extra)
+        const int mine_tiles = per + (x < extra ? 1 : 0);
+        if (idx >= mine_tiles * p.split) return;                       // padding item (the tail is padded to whole groups of 8)
+        ks = idx % p.split;
+        tail_u = 8 * (idx / p.split) + x;                              // the tile whose un-split block id would ALSO land on XCD x: xcd_remap
+                                                                       // below then continues that XCD's contiguous chunk of tiles
         tile_b = p.full_blocks + tail_u;
         nsplit = p.split;
     }
+    // block-uniform by construction; say so (the integer divisions above run on the vector ALU, and with the bounded spin + trap
+    // further down hipcc otherwise loses track and hands VGPRs to the "s" operands of the DMA asm)
+    ks = __builtin_amdgcn_readfirstlane(ks);
+    tail_u = __builtin_amdgcn_readfirstlane(tail_u);
+    tile_b = __builtin_amdgcn_readfirstlane(tile_b);
+    nsplit = __builtin_amdgcn_readfirstlane(nsplit);
     const int t = xcd_remap(tile_b, tiles_m * tiles_n);
     int tm, tn;
     if (p.col_strips) {
@@ -314,9 +318,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT_all = (p.K + BKT - 1) / BKT;
-    const bool uneven = nsplit == 2 && p.kcut > 0;
-    const int kt0 = uneven ? (ks ? p.kcut : 0) : (int)(((long)KT_all * ks) / nsplit);
-    const int KT = (p.debug & 2) ? 0 : (uneven ? (ks ? KT_all - p.kcut : p.kcut) : (int)(((long)KT_all * (ks + 1)) / nsplit) - kt0);   // this block's K-tiles: kt0 .. kt0+KT-1
+    const int kt0 = (int)(((long)KT_all * ks) / nsplit);
+    const int KT = (p.debug & 2) ? 0 : (int)(((long)KT_all * (ks + 1)) / nsplit) - kt0;   // this block's K-tiles: kt0 .. kt0+KT-1
     auto stage = [&](int kt_local, int buf) {
         const int kt = kt0 + kt_local;
         // LDS layout: [A|B] per stage, except for the interleaved loop (PIPE 4): [A0][A1][B0][B1], so that the
@@ -507,28 +510,71 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     }
     }
 
-    // ---- split-K tail: publish the fp32 partial, take a ticket, the last arriver reduces -------------
-    // Placement-independent hand-off (cdna_hip_programming.md §6 G16 counter form): plain slab stores ->
-    // every wave drains -> barrier -> ONE lane: agent-scope release, drain again (asm: the compiler drops
-    // the post-wbl2 wait), relaxed agent ticket.  Reducer: ONE lane agent-scope acquire -> barrier ->
-    // plain loads.  The slab image is the accumulator register image (lane-linear 16-B stores).
+    // ---- split-K tail: every slice publishes its fp32 partial and reduces ONE ROW BAND of the tile --------------------------
+    // Placement-independent hand-off in the write-through form (cdna_hip_programming.md §6 G16 R1): sc1 slab stores go to memory
+    // past the XCD's L2 (no release fence = no buffer_wbl2 of an L2 full of dirty C tiles, no acquire invalidate), every wave
+    // drains its stores, one lane counts the slice in (relaxed agent-scope atomic) and reads are sc1 loads.  The slab image is the
+    // accumulator register image (lane-linear 16-B accesses).
+    // Round 3: the reduction is spread over the tile's slices.  Before, the LAST slice to arrive read all `nsplit` slabs (256 KiB
+    // each at the ~65 GB/s one CU gets from remote memory: 12-20 us with 3-5 slices) while the other slices' CUs had left.  Now
+    // slice s owns the fragment rows j in [TMU*s/n, TMU*(s+1)/n) of every wave -- a contiguous band of tile rows, thanks to the
+    // interleaved wave rows -- stores its whole partial, waits until all n
+    // slices are in (they sit within 8*n consecutive blocks of the dispatch order, see above; the spin is bounded and traps rather
+    // than hangs) and sums its band over the slices IN SLICE ORDER 0..n-1 (fp32 addition is not associative: an arrival-order sum
+    // made results depend on block timing, tests/test_round2_gpu.py::test_full_vicuna_7b_training_step_invariants), then runs the
+    // epilogue for its band only.  Per slice: one slab written, one slab's worth read (n bands of 1/n), all CUs of the round busy.
+    int j_lo = 0, j_hi = TMU;                              // fragment rows (per wave) this block finishes and stores
     if (nsplit > 1) {
         constexpr int SLAB = BM * BN;
         LDS_PTR(unsigned) flag = (LDS_PTR(unsigned))smem;
-        if (p.slab_sc1) {
-            // Write-through form of the same hand-off (cdna_hip_programming.md §6 G16 R1): sc1 slab stores go to memory past the
-            // XCD's L2, so no release fence (= no buffer_wbl2 of an L2 full of dirty C tiles) and no acquire invalidate; every
-            // wave drains its stores, one lane takes the ticket, the reducer reads all slabs with sc1 loads.
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.slabs, 0, 0x7fffffff, 0x00020000);
-            const int mine = (tail_u * p.split + ks) * SLAB * 4;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.slabs, 0, 0x7fffffff, 0x00020000);
+        const bool band = IL && p.band_reduce;
+        if (band) { j_lo = (TMU * ks) / nsplit; j_hi = (TMU * (ks + 1)) / nsplit; }
+        const int mine = (tail_u * p.split + ks) * SLAB * 4;
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TMU; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
+            for (int j = 0; j < TMU; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rs,
                                                            mine + ((((wave * TN + i) * TM + j) * 64 + lane) * 16), 0, 16);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (band) {
+            if (tid == 0) {
+                __hip_atomic_fetch_add(p.counters + tail_u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (j_hi > j_lo) {
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(p.counters + tail_u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nsplit) {
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1u << 22)) __builtin_trap();      // ~seconds: a partner slice never ran -- fail loudly, never hang the GPU
+                    }
+                }
+            }
             __syncthreads();
+            if (j_hi > j_lo) {
+                for (int o = 0; o < nsplit; ++o) {             // slice order (deterministic sum), own slab included: same lane, same address
+                    const int part = (tail_u * p.split + o) * SLAB * 4;
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+#pragma unroll
+                        for (int j = 0; j < TMU; ++j) {
+                            if (j < j_lo || j >= j_hi) continue;
+                            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, part + ((((wave * TN + i) * TM + j) * 64 + lane) * 16), 0, 16));
+                            acc[i][j] = (o == 0) ? v : acc[i][j] + v;
+                        }
+                }
+            }
+            // count out; the last slice to leave zeroes both words for the next launch (everyone has seen `nsplit` by then)
+            if (tid == 0) {
+                const unsigned gone = __hip_atomic_fetch_add(p.counters + 512 + tail_u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (gone == (unsigned)(nsplit - 1)) {
+                    __hip_atomic_store(p.counters + tail_u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.counters + 512 + tail_u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (j_hi <= j_lo) return;                          // more slices than fragment rows: this one owns no band
+        } else {
+            // the round-2 form (NV_GEMM_BAND_REDUCE=0, and the 128x128 / non-interleaved tiles): the last arriver reduces every slab
             if (tid == 0) *flag = __hip_atomic_fetch_add(p.counters + tail_u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             const unsigned ticket = *flag;
@@ -544,42 +590,6 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
                         acc[i][j] = (o == 0) ? v : acc[i][j] + v;
                     }
             }
-        } else {
-        float* mine = p.slabs + (size_t)(tail_u * p.split + ks) * SLAB;
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int j = 0; j < TMU; ++j)
-                *(f32x4*)(mine + (size_t)(((wave * TN + i) * TM + j) * 64 + lane) * 4) = acc[i][j];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            *flag = __hip_atomic_fetch_add(p.counters + tail_u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        const unsigned ticket = *flag;
-        if (ticket != (unsigned)(nsplit - 1)) return;
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(p.counters + tail_u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        }
-        __syncthreads();
-        // Sum the slices in SLICE ORDER 0,1,..,nsplit-1 whichever block arrived last (its own partial is re-read from its
-        // slab: same lane, same address it just stored): fp32 addition is not associative, and an arrival-order sum made the
-        // result depend on block timing -- last-bit flips of the bf16 outputs that a 32-layer model amplifies to visible
-        // run-to-run differences (tests/test_round2_gpu.py::test_full_vicuna_7b_training_step_invariants).
-        for (int o = 0; o < nsplit; ++o) {
-            const float* part = p.slabs + (size_t)(tail_u * p.split + o) * SLAB;
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int j = 0; j < TMU; ++j) {
-                    const f32x4 v = *(const f32x4*)(part + (size_t)(((wave * TN + i) * TM + j) * 64 + lane) * 4);
-                    acc[i][j] = (o == 0) ? v : acc[i][j] + v;
-                }
-        }
         }
     }
 
@@ -600,6 +610,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         __syncthreads();                                  // every wave is done with the operand stages
 #pragma unroll
         for (int j = 0; j < TMU; ++j) {
+            if (j < j_lo || j >= j_hi) continue;              // (split-K band reduction: only this block's band is final)
             const int ml = IL ? (j * WGM + wm) * 16 + mi : wm * WTM + j * 16 + mi;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
@@ -620,11 +631,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         __syncthreads();
         constexpr int SLOTS = BN / 8;                     // 16-B slots per C row
         constexpr int ROWS_PER_PASS = NT / SLOTS;
+        static_assert(!IL || (WGM * 16) % ROWS_PER_PASS == 0, "a band of fragment rows must be whole store passes");
         const int c16 = tid % SLOTS, r_in = tid / SLOTS;
         const int n = n0 + c16 * 8;
         if (n < p.N) {
+            // rows of the band: fragment rows [j_lo*WGM, j_hi*WGM) of the tile (interleaved wave rows) = a contiguous row range
+            const int pass_lo = IL ? (j_lo * WGM * 16) / ROWS_PER_PASS : 0, pass_hi = IL ? (j_hi * WGM * 16) / ROWS_PER_PASS : BM_EFF / ROWS_PER_PASS;
 #pragma unroll 4
-            for (int pass = 0; pass < BM_EFF / ROWS_PER_PASS; ++pass) {
+            for (int pass = pass_lo; pass < pass_hi; ++pass) {
                 const int ml = pass * ROWS_PER_PASS + r_in, m = m0 + ml;
                 if (m >= p.M) break;
                 u32x4 t = *(LDS_PTR(u32x4))(smem + ml * (BN * 2) + ((c16 ^ (ml & 15)) << 4));
@@ -685,6 +699,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     }
 #pragma unroll
     for (int j = 0; j < TMU; ++j) {
+        if (j < j_lo || j >= j_hi) continue;
         const int m = m0 + (IL ? (j * WGM + wm) * 16 + mi : wm * WTM + j * 16 + mi);
         if (m >= p.M) continue;
 #pragma unroll
@@ -723,8 +738,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
 inline int tail_split(int rem, int KT) {
     constexpr int CUS = 256;
     if (rem <= 0 || rem > CUS / 2) return 1;
-    static const int max_split = [] { const char* e = getenv("NV_GEMM_MAXSPLIT"); return e ? atoi(e) : 6; }();
-    static const int min_slice = [] { const char* e = getenv("NV_GEMM_MINSLICE"); return e ? atoi(e) : 20; }();
+    static const int max_split_env = [] { const char* e = getenv("NV_GEMM_MAXSPLIT"); return e ? atoi(e) : 0; }();
+    static const int min_slice_env = [] { const char* e = getenv("NV_GEMM_MINSLICE"); return e ? atoi(e) : 0; }();
+    // a handful of tail tiles (M = 670, N = 22016: 258 tiles -> 2) may be cut finer: few slabs in flight, and the round they
+    // occupy is otherwise empty (round 3, same probe: 136 -> 126 us); a 48-tile tail is not (o_proj at M = 4760: 137 -> 144 us)
+    const int max_split = max_split_env ? max_split_env : (rem <= 16 ? 8 : 6);
+    const int min_slice = min_slice_env ? min_slice_env : (rem <= 16 ? 8 : 20);
     int split = CUS / rem;
     if (split > max_split) split = max_split;
     if (split > KT / min_slice) split = KT / min_slice;
@@ -737,14 +756,16 @@ inline int tail_split(int rem, int KT) {
 // shrinks a little with the fraction of CUs it occupies, or as split-K slices (slower K-steps: the slices of a tile share no
 // operand panels) plus the slab hand-off.  The constants are a least-squares fit (tools/fit_tme_model.py) to the durations
 // tools/gemm_tme_probe.py measured on MI355X for the four Linear shapes of Vicuna-7B at M = 500 .. 5134, forward (NT) and dgrad
-// (NN) layouts, TME = 4 .. 8 (profiles/r03_gemm_tme_probe.txt): rms error 7 % / 6 %.  What the fit says about the kernel: a
-// K-step costs 1.03 / 1.13 / 1.25 / 1.43 / 1.56 us at TME = 4 .. 8 -- half the MFMAs take two thirds of the time (the barrier,
+// (NN) layouts, TME = 4 .. 8 (profiles/r03_gemm_tme_probe_v2_band_reduce.txt): rms error 7 % / 6 %.  What the fit says about the
+// kernel: a K-step costs 1.03 / 1.15 / 1.21 / 1.38 / 1.46 us at TME = 4 .. 8 -- half the MFMAs take 70 % of the time (the barrier,
 // the B-tile DMA and the fragment reads of B do not shrink with the tile), so a cut-off tile only pays where it removes a
-// mostly-empty round or a mostly-padding tile row.
+// mostly-empty round or a mostly-padding tile row (few-hundred-row GEMMs: M = 670, N = 12288: 91 vs 100 us; M = 670, N = 11008
+// dgrad: 77 vs 91 us).  With the band-distributed split-K reduction the hand-off term fell from ~15 us per slice to ~10 and the
+// full tile is the planner's choice for nearly every training-step shape again.
 struct TmeModel { double tk[5], oh0, c0, fix0, fix1, kfrac; };
 inline const TmeModel& tme_model(bool b_kmaj) {
-    static const TmeModel nt{{1.032, 1.130, 1.250, 1.426, 1.559}, 0.0, 0.965, -30.2, 14.7, 1.331};
-    static const TmeModel nn{{1.047, 1.128, 1.238, 1.419, 1.618}, 0.0, 0.850, -19.4, 12.3, 1.255};
+    static const TmeModel nt{{1.029, 1.146, 1.212, 1.375, 1.455}, 0.0, 0.944, -22.1, 10.5, 1.343};
+    static const TmeModel nn{{1.038, 1.139, 1.197, 1.353, 1.461}, 0.0, 0.872, -14.3, 8.9, 1.279};
     return b_kmaj ? nt : nn;
 }
 inline double est_us_256(int M, int N, int K, int tme, bool can_split, bool b_kmaj) {
@@ -816,9 +837,9 @@ void gemm_bf16_kernel(GemmArgs p) {
         gemm_tile<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI, PIPE, TME>(p, item, first, smem);
     }
     // NV_GEMM_DEBUG bit 2 (measurement): block 0 leaves its core-clock cycles and 100 MHz wall ticks in the workspace
-    // (bytes 2048..2063) -> average shader clock of the launch = 0.1 GHz * cycles / ticks
+    // (bytes 4080..4095) -> average shader clock of the launch = 0.1 GHz * cycles / ticks
     if ((p.debug & 4) && blockIdx.x == 0 && threadIdx.x == 0 && p.counters) {
-        unsigned long long* o = (unsigned long long*)((char*)p.counters + 2048);
+        unsigned long long* o = (unsigned long long*)((char*)p.counters + 4080);
         o[0] = __builtin_readcyclecounter() - c0;
         o[1] = wall_clock64() - w0;
     }
@@ -837,7 +858,7 @@ int launch(const GemmArgs& p, hipStream_t st) {
     }
     const int tiles = ((p.M + BM_EFF - 1) / BM_EFF) * ((p.N + BN - 1) / BN);
     GemmArgs q = p;
-    q.full_blocks = tiles; q.rem = 1; q.split = 1; q.kcut = 0; q.tail_first = 0;
+    q.full_blocks = tiles; q.rem = 1; q.split = 1;
     // Split-K tail: with one 256x256 block per CU, T tiles run in ceil(T/256) rounds and the last round is
     // often nearly empty (M=5152,N=4096: 336 tiles = 2 rounds for 1.31 rounds of work).  The tiles of that
     // partial round are cut into `split` K-slices so the round is ~full and 1/split as long.
@@ -847,10 +868,12 @@ int launch(const GemmArgs& p, hipStream_t st) {
         const int split = tail_split(rem, KT);
         if (split >= 2) { q.full_blocks = tiles - rem; q.rem = rem; q.split = split; }
     }
-    const int ntail = q.split > 1 ? q.rem * q.split : 0;
-    q.items = q.full_blocks + (q.tail_first ? q.tail_first : ntail);
-    // persistent blocks for the interleaved kernel (its prologue/epilogue are the per-tile fixed cost worth hiding)
-    const int grid = (PIPE == 4 && p.persist && q.items > CUS) ? CUS : q.items;
+    // tail items: per XCD (item % 8) the slices of its chunk of tail tiles, padded to whole groups of 8 (see gemm_tile)
+    const int ntail = q.split > 1 ? 8 * ((q.rem + 7) / 8) * q.split : 0;
+    q.items = q.full_blocks + ntail;
+    // persistent blocks for the interleaved kernel (measurement knob NV_GEMM_PERSIST; never with a split tail: its slices wait for
+    // one another and must all be resident)
+    const int grid = (PIPE == 4 && p.persist && ntail == 0 && q.items > CUS) ? CUS : q.items;
     NV_LAUNCH(kern, dim3(grid), dim3(WGM * WGN * 64), LDS, st, q);
     return nv_check_launch();
 }
@@ -943,7 +966,7 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.counters = (unsigned*)workspace;
     p.slabs = workspace ? (float*)((char*)workspace + 4096) : nullptr;
-    p.full_blocks = 0; p.rem = 1; p.split = 1; p.kcut = 0; p.tail_first = 0;
+    p.full_blocks = 0; p.rem = 1; p.split = 1;
     p.rope_sin = (const bf16_t*)rope_sin; p.rope_S = rope_S; p.rope_cols = rope_cols; p.rope_pos = rope_pos;
     {
         // tuning / measurement knobs, read once per process
@@ -953,8 +976,8 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
         static const int env_persist = [] { const char* e = getenv("NV_GEMM_PERSIST"); return e ? atoi(e) : 0; }();
         p.debug = env_debug;
         p.persist = env_persist;
-        static const int env_sc1 = [] { const char* e = getenv("NV_GEMM_SLAB_SC1"); return e ? atoi(e) : 1; }();   // A/B: +0.7 % on the training step
-        p.slab_sc1 = env_sc1;
+        static const int env_band = [] { const char* e = getenv("NV_GEMM_BAND_REDUCE"); return e ? atoi(e) : 1; }();
+        p.band_reduce = env_band;
         static const int env_cst = [] { const char* e = getenv("NV_GEMM_C_STORE"); return e ? atoi(e) : 1; }();   // nt: +0.3 % on the step (ABAB: 43.40 / 43.50 / 43.41 / 43.57)
         p.c_nt = env_cst;
         p.group_m = env_group < 1 ? 1 : env_group;

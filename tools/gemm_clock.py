@@ -22,5 +22,5 @@ for data in ("randn", "zeros"):
             ops.gemm_bf16(layout, a, b, out=C)
         e1.record(); torch.cuda.synchronize()
         ws = list(ops._gemm_ws_cache.values())[0]
-        ck = ws[2048:2064].view(torch.int64).tolist()
+        ck = ws[4080:4096].view(torch.int64).tolist()
         print(f"{data}: {2.0*M*N*K/(e0.elapsed_time(e1)/20*1e-3)/1e12:7.1f} TF, block 0: {ck[0]} cycles / {ck[1]} ticks -> shader clock {0.1*ck[0]/max(ck[1],1):.2f} GHz")

@@ -16,6 +16,10 @@ def main():
         n = name.replace("(anonymous namespace)::", "")
         m = re.match(r"(void )?([\w:]+)(<[^(]*>)?", n)
         key = (m.group(2) + (m.group(3) or "")) if ("gemm_bf16" in n or "gemv_stream" in n) else m.group(2)
+        if key.startswith("at::native::"):            # torch glue kernels: keep the functor + dtype so that fills / copies / adds stay apart
+            f = re.search(r"(FillFunctor<[^>]*>|CUDAFunctor_add<[^>]*>|MulFunctor<[^>]*>|direct_copy_kernel_cuda|masked_fill|CatArrayBatchedCopy|"
+                          r"scatter_gather|reduce_kernel|index_[a-z_]+|bernoulli|uniform|normal|random)", n)
+            key = key.replace("at::native::", "torch::") + ("[" + f.group(1) + "]" if f else "")
         a = agg[key[:110]]
         d = (e - s) / 1e3
         a[0] += 1
