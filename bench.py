@@ -588,17 +588,24 @@ def main():
         return one_step
 
     def run_mode(mode, steps, warmup, prewarm, sync_ranks):
-        """`prewarm` untimed setup steps + `warmup` untimed steps, then `steps` timed ones bracketed by barrier + synchronize on both
-        sides -> (seconds (max over ranks), GemmTimer, last loss)"""
+        """untimed setup steps, then `warmup` untimed steps, then `steps` timed ones bracketed by barrier + synchronize on both sides
+        -> (seconds (max over ranks), GemmTimer, last loss).
+        Episodes are 6 steps long and end with per-episode work (prefix mode: the prefix's backward + one weight-gradient GEMM per
+        weight; both modes: clip + AdamW), so where a 20-step window falls relative to the episodes matters: it can hold 3 or 4
+        episode starts and 3 or 4 episode ends, the long-run average being 3 1/3 of each.  The TIMED REGION ALWAYS STARTS AT AN
+        EPISODE BOUNDARY: the setup phase runs `prewarm` steps plus as many more (< 6) as it takes for setup + warmup to be whole
+        episodes.  With K = 20 the window then holds 4 episode starts and 3 episode ends -- of the four possible alignments the
+        one closest to the long-run average (per-episode work counted: 0.96 of its long-run share; the alignment that follows
+        from counting steps from 0 would count 1.20 of it)."""
         one_step = make_step(mode)
         model.episode_abort()
         ep.reset()
-        for i in range(prewarm):        # setup, not part of the protocol's W/K accounting
+        setup = prewarm + (-(prewarm + warmup)) % STEPS_PER_EPISODE
+        for i in range(setup):          # setup, not part of the protocol's W/K accounting
             one_step(i)
-        model.episode_abort()
-        ep.reset()
-        for i in range(warmup):
+        for i in range(setup, setup + warmup):
             one_step(i)
+        base = setup + warmup           # a multiple of 6: step `base` opens an episode
         tm = GemmTimer()
         if not a.no_profile:
             tm.install(ops)
@@ -608,8 +615,8 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         loss = None
-        for i in range(warmup, warmup + steps):
-            tm.active = (i - warmup) % GemmTimer.SAMPLE_EVERY == 0
+        for i in range(base, base + steps):
+            tm.active = (i - base) % GemmTimer.SAMPLE_EVERY == 0
             loss = one_step(i)
         torch.cuda.synchronize()
         if world > 1 and sync_ranks:
@@ -694,6 +701,10 @@ def main():
                                    f"clip+AdamW every {STEPS_PER_EPISODE} steps)",
                        "global_batch": a.batch * world, "seq_len": seq_len_main,
                        "parallelism": f"dp{world}", "loss": float(loss.detach()) if loss is not None else None,
+                       "timed_window": "starts at an episode boundary (setup + warmup = whole 6-step episodes): %d episode starts and %d "
+                                       "episode ends (clip + AdamW%s) inside the %d timed steps" % (
+                                           (a.steps + STEPS_PER_EPISODE - 1) // STEPS_PER_EPISODE, a.steps // STEPS_PER_EPISODE,
+                                           "; prefix backward + per-weight wgrad GEMMs" if a.mode == "prefix_reuse" else "", a.steps),
                        "training_mode": a.mode,
                        "training_mode_what": MODE_WHAT[a.mode]},
         }

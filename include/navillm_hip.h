@@ -152,6 +152,12 @@ int nv_attn_fwd_hfround_bf16(const void* qkv, void* out, float* lse2, const int*
  *   workspace = nv_attn_bwd_workspace_bytes(B, S_stride, H) */
 int nv_attn_bwd_strided_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
                              void* workspace, int B, int S, int S_stride, int H, int head_dim, int q_row_min, void* stream);
+/*   the same with the K/V gradients of each sample's first prefix_len[b] key rows accumulated in fp32 into kv_acc [B*S_stride,
+ *   2*H*head_dim] straight from the MFMA accumulators (first != 0: stored) instead of written to dqkv -- the fused form of
+ *   nv_kv_grad_accum_f32 / nv_kv_grad_set_f32 */
+int nv_attn_bwd_strided_kvacc_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
+                                   void* workspace, float* kv_acc, const int* prefix_len, int first, int B, int S, int S_stride, int H,
+                                   int head_dim, int q_row_min, void* stream);
 int nv_attn_bwd_varlen_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* cu, const int* pos0,
                             void* dqkv, void* workspace, const void* rope_cos, const void* rope_sin, int B, int S_max, long rows,
                             int H, int head_dim, int q_row_min, void* stream);

@@ -129,6 +129,9 @@ struct AttnArgs {
     float scale2;          // head_dim^-0.5 * log2(e)
     float scale;           // head_dim^-0.5
     const bf16_t* rope_cos; const bf16_t* rope_sin;   // backward only, optional: apply RoPE^T to dQ/dK as they are written
+    float* kvacc;          // backward over a K/V cache, optional (navillm_amd/episode.py): fp32 [rows, 2*H*HD] accumulator of the gradients the
+    const int* kvacc_len;  // steps of an episode send into the cached PREFIX rows: key rows < kvacc_len[b] of sample b add (kvacc_first:
+    int kvacc_first;       // store) their dK | dV there straight from the fp32 MFMA accumulators and write no bf16 row
     const int* dyn;        // forward over a K/V cache, optional: {S, q_row_min} read from DEVICE memory (a decode step replayed from a
                            // hipGraph: the launch arguments are frozen, the lengths are not); the grid then covers the capacity
 };
@@ -612,9 +615,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         cur = cur == 2 ? 0 : cur + 1;
     }
     }
+    const int acc_len = p.kvacc ? p.kvacc_len[b] : 0;
 #pragma unroll
     for (int jk = 0; jk < KW; ++jk)
         if (key[jk] < S) {
+            if (key[jk] < acc_len) {
+                // a cached prefix row: its K/V gradient is summed over the episode's steps in fp32 (what nv_kv_grad_accum_f32 did from
+                // the bf16 row in a second pass: 342 MB per layer and step at 7B/B=8); same scaling as the bf16 store, no rounding
+                float* ak = p.kvacc + (sq.row0 + key[jk]) * (2L * p.H * HD) + h * HD + g * 4;
+                float* av = ak + p.H * HD;
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    f32x4 k4 = dk[jk][dt] * p.scale, v4 = dv[jk][dt];
+                    if (!p.kvacc_first) { k4 += *(const f32x4*)(ak + dt * 16); v4 += *(const f32x4*)(av + dt * 16); }
+                    *(f32x4*)(ak + dt * 16) = k4;
+                    *(f32x4*)(av + dt * 16) = v4;
+                }
+                continue;
+            }
             bf16_t* kp = p.dqkv + (sq.row0 + key[jk]) * ld + p.H * HD + h * HD + g * 4;
             bf16_t* vp = p.dqkv + (sq.row0 + key[jk]) * ld + 2 * p.H * HD + h * HD + g * 4;
             store_grad_row(kp, dk[jk], p.scale, p.rope_cos ? p.rope_cos + (long)(key[jk] + sq.pos0) * HD + g * 4 : nullptr,
@@ -864,7 +882,8 @@ size_t nv_attn_bwd_workspace_bytes(int B, int S, int H) { return (size_t)B * S *
 
 static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
                          void* workspace, int B, int S, int H, int head_dim, int q_row_min, const void* rope_cos,
-                         const void* rope_sin, void* stream, const int* cu = nullptr, long rows = -1, int Sst = 0) {
+                         const void* rope_sin, void* stream, const int* cu = nullptr, long rows = -1, int Sst = 0, float* kvacc = nullptr,
+                         const int* kvacc_len = nullptr, int kvacc_first = 0) {
     if (!qkv || !out || !dout || !lse2 || !kv_start || !dqkv || !workspace) return NV_ERR_ARG;
     if (head_dim != HD || (q_row_min >= 0 && (q_row_min & 127)) || q_row_min < (cu ? -1 : 0) || (S > 0 && q_row_min >= S)) return NV_ERR_SHAPE;
     if ((rope_cos == nullptr) != (rope_sin == nullptr)) return NV_ERR_ARG;
@@ -894,6 +913,7 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
     p.kv_start = kv_start; p.cu = cu; p.B = B; p.S = S; p.Sst = Sst; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
     p.rope_cos = (const bf16_t*)rope_cos; p.rope_sin = (const bf16_t*)rope_sin;
+    p.kvacc = kvacc; p.kvacc_len = kvacc_len; p.kvacc_first = kvacc_first;
     // with q_row_min > 0 only those query rows carry gradient: dK/dV still cover every key, dQ rows below
     // q_row_min are NOT written (the caller zero-fills them)
     if (variant == 1) {
@@ -929,6 +949,17 @@ int nv_attn_bwd_strided_bf16(const void* qkv, const void* out, const void* dout,
     if (S_stride < S) return NV_ERR_SHAPE;
     return attn_bwd_impl(qkv, out, dout, lse2, kv_start, dqkv, workspace, B, S, H, head_dim, q_row_min, nullptr, nullptr, stream, nullptr,
                          -1, S_stride);
+}
+
+// The same with the gradients of each sample's first prefix_len[b] key rows (a cached prompt prefix) accumulated in fp32 into
+// kv_acc [B*S_stride, 2*H*head_dim] (`first` != 0: stored) instead of written to dqkv as bf16: replaces nv_kv_grad_accum_f32 /
+// nv_kv_grad_set_f32 over those rows.  dqkv's K/V columns of the prefix rows are left untouched.
+int nv_attn_bwd_strided_kvacc_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
+                                   void* workspace, float* kv_acc, const int* prefix_len, int first, int B, int S, int S_stride, int H,
+                                   int head_dim, int q_row_min, void* stream) {
+    if (S_stride < S || !kv_acc || !prefix_len) return NV_ERR_SHAPE;
+    return attn_bwd_impl(qkv, out, dout, lse2, kv_start, dqkv, workspace, B, S, H, head_dim, q_row_min, nullptr, nullptr, stream, nullptr,
+                         -1, S_stride, kv_acc, prefix_len, first);
 }
 
 // backward over packed rows (see nv_attn_fwd_varlen_bf16); rope_cos/rope_sin optional (both or neither); `rows` = cu[B]

@@ -94,6 +94,7 @@ class PrefixEpisode:
         self._wcache = {}
         self.stats = {"prefix_rows": 0, "suffix_rows": []}
         self.defer_wgrad = os.environ.get("NAVILLM_EPISODE_DEFER_WGRAD", "1") != "0"
+        self.fuse_kvacc = os.environ.get("NAVILLM_EPISODE_FUSE_KVACC", "1") != "0"
         self._E, self._ecap, self._cursor, self._last_rows = None, 0, 0, 0
 
     # ------------------------------------------------------------------ helpers
@@ -163,7 +164,7 @@ class PrefixEpisode:
         pos = np.concatenate([np.arange(n, dtype=np.int32) for n in lens])
         crow = np.concatenate([b * cap + np.arange(n, dtype=np.int32) for b, n in enumerate(lens)])
         dev = m.device
-        ids_d, pos_d, crow_d, cu_d = (ops.h2d(torch.from_numpy(a), dev) for a in (ids, pos, crow, cu))
+        ids_d, pos_d, crow_d, cu_d, lens_d = (ops.h2d(torch.from_numpy(a), dev) for a in (ids, pos, crow, cu, lens))
         vix = torch.full((Mp,), -1, dtype=I32, device=dev)
         zero_pos0 = torch.zeros((B,), dtype=I32, device=dev)
         Lmax = int(lens.max())
@@ -199,7 +200,7 @@ class PrefixEpisode:
             layers.append(dict(x=x, n1=n1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x1=x1, n2=n2, rstd2=rstd2, gu=gu, h=h))
             x = x2                                     # (dkv_acc needs no zero-fill: the first step SETS the prefix rows)
         self.prefix = dict(ids=[list(p) for p in prefix_ids], ids_np=ids, lens=lens, cu=cu_d, pos=pos_d, crow=crow_d, pos0=zero_pos0,
-                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0, kv_steps=0, defer=defer)
+                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0, kv_steps=0, defer=defer, lens_dev=lens_d)
         self.stats = {"prefix_rows": Mp, "suffix_rows": []}
 
     # ------------------------------------------------------------------ one step: suffix rows over the cached prefix
@@ -329,12 +330,16 @@ class PrefixEpisode:
             # attention backward on the cache layout: dO is zero everywhere except this step's rows (written, used, zeroed again:
             # a full-buffer fill per layer was 3 % of the episode)
             ops.scatter_rows_bf16_(dattn, step["crow"], self.dout_full)
+            # (round 3: the K/V gradients this step sends into the cached prefix rows go straight from the kernel's fp32 accumulators
+            # into dkv_acc -- no bf16 round trip through dqkv_full and no second pass over 4 272 x 8192 values per layer)
             ops.attn_bwd_strided(self.cache[i], self.attn_buf[i], self.dout_full, self.lse[i], self.kv0, B, Lmax, cap, H, hd, self.dqkv_full,
-                                 q_row_min=qmin)
+                                 q_row_min=qmin, kv_acc=self.dkv_acc[i] if self.fuse_kvacc else None, prefix_len_i32=self.prefix["lens_dev"],
+                                 first=first)
             ops.scatter_rows_bf16_(zeros_md, step["crow"], self.dout_full)
             dqkv = ops.gather_rows_bf16(self.dqkv_full, step["crow"], out=E["dqkv"][rows] if defer else None)
             ops.rope_rows_t_(dqkv, m.rope_cos, m.rope_sin, step["pos"], H, hd)
-            ops.kv_grad_accum(self.dqkv_full, self.dkv_acc[i], self.prefix["crow"], first=first)   # what this step sends into the prefix's K/V
+            if not self.fuse_kvacc:
+                ops.kv_grad_accum(self.dqkv_full, self.dkv_acc[i], self.prefix["crow"], first=first)   # what this step sends into the prefix's K/V
             dn1 = ops.gemm_bf16(ops.NN, dqkv, Wqkv, out=self._buf("dn1", (M, d)))
             if not defer:
                 ops.gemm_bf16(ops.TN, dqkv, a["n1"], out=gqkv, epilogue=ops.EPI_ACCUM)

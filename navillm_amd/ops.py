@@ -283,9 +283,16 @@ def attn_bwd_varlen(qkv, out, dout, lse2, cu_i32, pos0_i32, B, S_max, H, hd, dqk
     return dqkv
 
 
-def attn_bwd_strided(qkv, out, dout, lse2, kv_start_i32, B, S, S_stride, H, hd, dqkv, q_row_min=0):
-    """backward over the K/V-cache layout (see nv_attn_bwd_strided_bf16); gradients stay in the rotated frame"""
+def attn_bwd_strided(qkv, out, dout, lse2, kv_start_i32, B, S, S_stride, H, hd, dqkv, q_row_min=0, kv_acc=None, prefix_len_i32=None, first=False):
+    """backward over the K/V-cache layout (see nv_attn_bwd_strided_bf16); gradients stay in the rotated frame.
+    kv_acc / prefix_len_i32: the K/V gradients of each sample's cached prefix rows go into the fp32 accumulator (first: stored)"""
     ws = _workspace(_L().nv_attn_bwd_workspace_bytes(B, S_stride, H), qkv.device, "attn_strided")
+    if kv_acc is not None:
+        rc = _L().nv_attn_bwd_strided_kvacc_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(),
+                                                 dqkv.data_ptr(), ws.data_ptr(), kv_acc.data_ptr(), prefix_len_i32.data_ptr(), 1 if first else 0,
+                                                 B, S, S_stride, H, hd, q_row_min, _st())
+        _lib.check(rc, "nv_attn_bwd_strided_kvacc_bf16")
+        return dqkv
     rc = _L().nv_attn_bwd_strided_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse2.data_ptr(), kv_start_i32.data_ptr(),
                                        dqkv.data_ptr(), ws.data_ptr(), B, S, S_stride, H, hd, q_row_min, _st())
     _lib.check(rc, "nv_attn_bwd_strided_bf16")
