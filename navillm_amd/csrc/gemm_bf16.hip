@@ -241,7 +241,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     constexpr int NT = WGM * WGN * 64;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr bool IL = (PIPE == 4);                       // interleaved fragment rows
+    constexpr bool IL = (PIPE == 4 || PIPE == 6);          // interleaved fragment rows (hand-scheduled loops)
     constexpr int TMU = IL ? TME : TM;                     // fragment rows per wave in use
     constexpr int BM_EFF = IL ? WGM * TME * 16 : BM;       // rows of C this tile covers
     static_assert(TME >= 1 && TME <= TM && (IL || TME == TM), "TME < TM needs the interleaved loop");
@@ -347,7 +347,177 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         }
     };
 
-    if constexpr (PIPE >= 1) {
+    if constexpr (PIPE == 6) {
+        // ---- THREE LDS stages for the cut-off tiles (TME = 4, 5: 128 / 160 x 256) ------------------------------------------------
+        // Why: a K-tile of a cut-off tile takes ~0.6-0.7 us of MFMA time, and the two-stage loop below issues the DMA of tile kt+2
+        // only one iteration before tile kt+1 is needed -- shorter than an L2-missing load takes on the few-hundred-row GEMMs these
+        // tiles exist for, whose weight panels are shared by 4-5 tiles at most (rocprofv3 --pmc, M = 670, N = 12288, TME 5: waves
+        // parked 52 % of their cycles, MFMA pipe 37 % busy, 2.7 TB/s from the fabric; profiles/r03_gemm_smallm_pmc.txt).  A 128 /
+        // 160-row A image is 16 / 20 KiB, so three stages of (A + 32 KiB B) fit the 160 KiB LDS and the DMA of tile kt+3 goes out
+        // TWO iterations ahead.  Same phase structure as the two-stage loop (one barrier per K-tile, fragments double-buffered,
+        // every non-MFMA instruction slotted between MFMAs), but the loop is unrolled over the three stages so that the stage is a
+        // compile-time immediate of every ds_read and of every M0 write (no address toggling), and the wait in front of the barrier
+        // is a counted one: tile kt+2 may still be in flight.
+        static_assert(A_KMAJ && BKT == 64 && TN == 4 && NT == 512 && BN == 256 && TME >= 4 && TME <= 5, "three-stage loop: cut-off tiles, K-major A");
+        constexpr int A_STG = BM_EFF * BKT * 2;                 // 16 / 20 KiB
+        constexpr int B_STG = B_BYTES;                          // 32 KiB
+        constexpr int B_REG = 3 * A_STG;                        // the B stages follow the three A stages
+        constexpr int DUMMY = B_REG + 3 * B_STG;                // 4 KiB: where the unused half of a half piece lands
+        static_assert(DUMMY + 4096 <= 160 * 1024, "LDS budget");
+        constexpr int A_PCS = (BM_EFF + 63) / 64;               // DMA pieces (64 rows each) of an A stage: 2, or 2 + a half
+        constexpr bool HALF = (BM_EFF % 64) != 0;
+        constexpr int LT = A_PCS + 4;                           // DMA instructions per wave and K-tile
+        constexpr int NB = B_KMAJ ? 2 : TN;
+        FragAddr<BM, true, TM, WGM> fa_;
+        FragAddr<BN, B_KMAJ, TN> fb_;
+        fa_.init(wm * 16, lane);
+        fb_.init(wn * WTN, lane);
+        uint32_t offA[2], offBlo[NB], offBhi[NB];               // B: stages 0/1 as immediates on `lo`, stage 2 on `hi` (16-bit ds offsets)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { offA[q] = smem_addr + fa_.off[q]; asm volatile("" : "+v"(offA[q])); }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            offBlo[q] = smem_addr + B_REG + fb_.off[q];
+            offBhi[q] = offBlo[q] + 2 * B_STG;
+            asm volatile("" : "+v"(offBlo[q]));
+            asm volatile("" : "+v"(offBhi[q]));
+        }
+        if (smem_addr != 0) __builtin_trap();                   // the immediates below assume the dynamic LDS block starts at 0
+        auto ldA = [&](auto SC, auto JC, auto KC) -> bf16x8 {
+            constexpr int st = decltype(SC)::value, j = decltype(JC)::value, kk = decltype(KC)::value;
+            return *(LDS_PTR(bf16x8))(uintptr_t)(offA[kk] + (st * A_STG + j * 2048 * WGM));
+        };
+        auto ldB = [&](auto SC, auto IC, auto KC) -> bf16x8 {
+            constexpr int st = decltype(SC)::value, i = decltype(IC)::value, kk = decltype(KC)::value;
+            constexpr int so = st < 2 ? st * B_STG : 0;
+            if constexpr (B_KMAJ) {
+                const uint32_t b = st < 2 ? offBlo[kk] : offBhi[kk];
+                return *(LDS_PTR(bf16x8))(uintptr_t)(b + (so + i * 2048));
+            } else {
+                const uint32_t q = (st < 2 ? offBlo[i] : offBhi[i]) + (so + kk * (32 * BN * 2));
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(uintptr_t)q);
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LDS_PTR(s16x4))(uintptr_t)(q + 4 * BN * 2));
+                s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                return __builtin_bit_cast(bf16x8, v);
+            }
+        };
+        // DMA addressing (as in the two-stage loop): one per-lane source offset per operand, a scalar per piece, K advance in the
+        // descriptors; destination M0 = this wave's 1 KiB slice + an immediate.  The half piece (rows 128..159 of a 160-row tile):
+        // waves 0-3 carry it, waves 4-7 load the next 32 rows into the dummy area (keeps the per-wave load count uniform).
+        uint32_t pva = piece_voff<BM, true, NT, BKT>(m0, 0, p.lda, tid, 0);
+        uint32_t pvb = piece_voff<BN, B_KMAJ, NT, BKT>(n0, 0, p.ldb, tid, 0);
+        asm volatile("" : "+v"(pva));
+        asm volatile("" : "+v"(pvb));
+        const uint32_t a_piece = (uint32_t)((NT / 64) * (1024 / (BKT * 2)) * 2) * (uint32_t)p.lda;
+        const uint32_t b_piece = (uint32_t)((B_KMAJ ? (NT / 64) * (1024 / (BKT * 2)) : (NT / 64) * (1024 / (BN * 2))) * 2) * (uint32_t)p.ldb;
+        const uint32_t wv = __builtin_amdgcn_readfirstlane(wave);
+        const uint32_t m0base = wv * 1024;
+        uint32_t m0half[3];
+#pragma unroll
+        for (int st = 0; st < 3; ++st) m0half[st] = wv < 4 ? st * A_STG + 2 * 8192 + wv * 1024 : DUMMY + (wv - 4) * 1024;
+        const uint32_t a_step = BKT * 2;
+        const uint32_t b_step = B_KMAJ ? BKT * 2 : (uint32_t)(BKT * 2) * (uint32_t)p.ldb;
+        uint64_t a_base = (uint64_t)p.A + (uint64_t)a_step * kt0, b_base = (uint64_t)p.B + (uint64_t)b_step * kt0;
+        uint32_t a_left = p.a_bytes - a_step * (uint32_t)kt0, b_left = p.b_bytes - b_step * (uint32_t)kt0;
+        auto piece = [&](auto SC, auto CC, const u32x4& da, const u32x4& db) {      // DMA instruction c (0..LT-1) of a tile into stage st
+            constexpr int st = decltype(SC)::value, c = decltype(CC)::value;
+            if constexpr (c < A_PCS) {
+                if constexpr (HALF && c == A_PCS - 1) set_m0_imm<0>(m0half[st]);
+                else set_m0_imm<st * A_STG + c * 8192>(m0base);
+                dma16_m0set(da, pva, a_piece * c);
+            } else {
+                set_m0_imm<B_REG + st * B_STG + (c - A_PCS) * 8192>(m0base);
+                dma16_m0set(db, pvb, b_piece * (c - A_PCS));
+            }
+        };
+        auto advance = [&]() { a_base += a_step; a_left -= a_step; b_base += b_step; b_left -= b_step; };
+        // prologue: tiles 0, 1, 2 into stages 0, 1, 2
+        static_for<3>([&](auto SC) {
+            constexpr int st = decltype(SC)::value;
+            if (st < KT) {
+                const u32x4 da = make_desc((const void*)a_base, a_left), db = make_desc((const void*)b_base, b_left);
+                static_for<LT>([&](auto CC) { piece(SC, CC, da, db); });
+                advance();
+            }
+        });
+        if (KT >= 3) wait_vmcnt<2 * LT>(); else if (KT == 2) wait_vmcnt<LT>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        using std::integral_constant;
+        static_for<TME>([&](auto JC) { fa0[decltype(JC)::value] = ldA(integral_constant<int, 0>{}, JC, integral_constant<int, 0>{}); });
+        static_for<TN>([&](auto IC) { fb0[decltype(IC)::value] = ldB(integral_constant<int, 0>{}, IC, integral_constant<int, 0>{}); });
+        constexpr int TOT = TN * TME;                           // MFMAs per phase: 16 / 20, in 8 groups of 2-3
+        constexpr int NRD = TME + TN;                           // fragment reads per phase: 8 / 9
+        // one iteration = K-tile kt living in stage ST.  in3: tile kt+3 exists (DMA it into ST); nx: tile kt+1 exists (read its k-step
+        // 0 fragments); w2: tile kt+2 exists, i.e. is still in flight at the barrier (counted wait)
+        auto body = [&](auto STC, bool in3, bool nx, bool w2) {
+            constexpr int ST = decltype(STC)::value, SN = (ST + 1) % 3;
+            using K0 = integral_constant<int, 0>;
+            using K1 = integral_constant<int, 1>;
+            static_for<8>([&](auto GC) {                        // phase 1: MFMAs of k-step 0, reads of k-step 1 (stage ST)
+                constexpr int gq = decltype(GC)::value;
+                static_for<NRD>([&](auto RC) {                  // read r goes out in group r * 6 / NRD: all reads in the first 6 groups
+                    constexpr int r = decltype(RC)::value;
+                    if constexpr (r * 6 / NRD == gq) {
+                        if constexpr (r < TME) fa1[r] = ldA(STC, RC, K1{});
+                        else fb1[r - TME] = ldB(STC, integral_constant<int, r - TME>{}, K1{});
+                    }
+                });
+                static_for<TOT>([&](auto NC) {
+                    constexpr int n = decltype(NC)::value;
+                    if constexpr (n * 8 / TOT == gq) {
+                        constexpr int i = n / TME, j = n % TME;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[i], fa0[j], acc[i][j], 0, 0, 0);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (w2) wait_vmcnt<LT>(); else wait_vmcnt<0>();     // tile kt+1 has landed (this wave's share); kt+2 may be in flight
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 da = make_desc((const void*)a_base, a_left), db = make_desc((const void*)b_base, b_left);
+            static_for<8>([&](auto GC) {                        // phase 2: MFMAs of k-step 1, tile kt+1's k-step 0 reads, DMA of tile kt+3
+                constexpr int gq = decltype(GC)::value;
+                if (nx) {
+                    static_for<NRD>([&](auto RC) {
+                        constexpr int r = decltype(RC)::value;
+                        if constexpr (r * 6 / NRD == gq) {
+                            if constexpr (r < TME) fa0[r] = ldA(integral_constant<int, SN>{}, RC, K0{});
+                            else fb0[r - TME] = ldB(integral_constant<int, SN>{}, integral_constant<int, r - TME>{}, K0{});
+                        }
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<TOT>([&](auto NC) {
+                    constexpr int n = decltype(NC)::value;
+                    if constexpr (n * 8 / TOT == gq) {
+                        constexpr int i = n / TME, j = n % TME;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb1[i], fa1[j], acc[i][j], 0, 0, 0);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                if (in3) {
+                    if constexpr (gq < LT) piece(STC, GC, da, db);      // one DMA piece per group (LT <= 7 < 8 groups)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (in3) advance();
+        };
+        int kt = 0;
+        for (; kt + 5 < KT; kt += 3) {                          // all three tiles kt, kt+1, kt+2 have a tile three ahead
+            body(integral_constant<int, 0>{}, true, true, true);
+            body(integral_constant<int, 1>{}, true, true, true);
+            body(integral_constant<int, 2>{}, true, true, true);
+        }
+        for (; kt < KT; ++kt) {                                 // the last (up to five) tiles; kt % 3 is still the stage
+            const bool in3 = kt + 3 < KT, nx = kt + 1 < KT, w2 = kt + 2 < KT;
+            const int st = kt % 3;
+            if (st == 0) body(integral_constant<int, 0>{}, in3, nx, w2);
+            else if (st == 1) body(integral_constant<int, 1>{}, in3, nx, w2);
+            else body(integral_constant<int, 2>{}, in3, nx, w2);
+        }
+    } else if constexpr (PIPE >= 1) {
                 // ---- software-pipelined main loop (2 LDS stages, BK=64 = 2 k-steps of 32) ----------------------
         // Fragment registers are double-buffered: the ds_reads of k-step 1 are in flight under the MFMAs of
         // k-step 0, and the ds_reads of the NEXT tile's k-step 0 under the MFMAs of k-step 1.  One barrier
@@ -756,16 +926,16 @@ inline int tail_split(int rem, int KT) {
 // shrinks a little with the fraction of CUs it occupies, or as split-K slices (slower K-steps: the slices of a tile share no
 // operand panels) plus the slab hand-off.  The constants are a least-squares fit (tools/fit_tme_model.py) to the durations
 // tools/gemm_tme_probe.py measured on MI355X for the four Linear shapes of Vicuna-7B at M = 500 .. 5134, forward (NT) and dgrad
-// (NN) layouts, TME = 4 .. 8 (profiles/r03_gemm_tme_probe_v2_band_reduce.txt): rms error 7 % / 6 %.  What the fit says about the
-// kernel: a K-step costs 1.03 / 1.15 / 1.21 / 1.38 / 1.46 us at TME = 4 .. 8 -- half the MFMAs take 70 % of the time (the barrier,
-// the B-tile DMA and the fragment reads of B do not shrink with the tile), so a cut-off tile only pays where it removes a
-// mostly-empty round or a mostly-padding tile row (few-hundred-row GEMMs: M = 670, N = 12288: 91 vs 100 us; M = 670, N = 11008
-// dgrad: 77 vs 91 us).  With the band-distributed split-K reduction the hand-off term fell from ~15 us per slice to ~10 and the
-// full tile is the planner's choice for nearly every training-step shape again.
+// (NN) layouts, TME = 4 .. 8 (profiles/r03_gemm_tme_probe_v3_three_stage.txt): rms error 7-8 %.  What the fit says about the
+// kernel: a K-step of the two-stage loop costs ~0.6 us + 0.11 us per fragment row (1.38 / 1.48 us at TME = 7 / 8: the barrier, the
+// B-tile DMA and the B fragment reads do not shrink with the tile), so its cut-off tiles only pay where they remove a mostly-empty
+// round or a mostly-padding tile row; the three-stage loop of TME = 4 / 5 runs a K-step in 0.83 / 1.08 us (two-stage: 1.03 / 1.15),
+// i.e. the 128-row tile is within 13 % of the full tile's time per flop.  With the band-distributed split-K reduction the
+// hand-off term fell from ~15 us per slice to ~4.
 struct TmeModel { double tk[5], oh0, c0, fix0, fix1, kfrac; };
 inline const TmeModel& tme_model(bool b_kmaj) {
-    static const TmeModel nt{{1.029, 1.146, 1.212, 1.375, 1.455}, 0.0, 0.944, -22.1, 10.5, 1.343};
-    static const TmeModel nn{{1.038, 1.139, 1.197, 1.353, 1.461}, 0.0, 0.872, -14.3, 8.9, 1.279};
+    static const TmeModel nt{{0.835, 1.080, 1.229, 1.380, 1.480}, 1.74, 0.799, -2.4, 3.8, 1.393};
+    static const TmeModel nn{{0.834, 1.081, 1.247, 1.409, 1.523}, 0.0, 0.734, 5.1, 3.5, 1.219};
     return b_kmaj ? nt : nn;
 }
 inline double est_us_256(int M, int N, int K, int tme, bool can_split, bool b_kmaj) {
@@ -847,8 +1017,9 @@ void gemm_bf16_kernel(GemmArgs p) {
 
 template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE = 0, int TME = BM / WGM / 16>
 int launch(const GemmArgs& p, hipStream_t st) {
-    constexpr int LDS = NSTAGE * (BM + BN) * BKT * 2;
-    constexpr int BM_EFF = (PIPE == 4) ? WGM * TME * 16 : BM;
+    constexpr int BM_EFF = (PIPE == 4 || PIPE == 6) ? WGM * TME * 16 : BM;
+    // the three-stage loop of the cut-off tiles: 3 x (A image of BM_EFF rows + B image) + a 4 KiB dummy landing area
+    constexpr int LDS = (PIPE == 6) ? 3 * (BM_EFF + BN) * BKT * 2 + 4096 : NSTAGE * (BM + BN) * BKT * 2;
     auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI, PIPE, TME>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -884,8 +1055,14 @@ template <bool A_KMAJ, bool B_KMAJ, int EPI>
 constexpr bool tme_instances = (A_KMAJ && B_KMAJ && (EPI == EPI_STORE || EPI == EPI_RESID || EPI == EPI_ROPE)) || (A_KMAJ && !B_KMAJ && EPI == EPI_STORE);
 
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
-int launch_tme(const GemmArgs& p, int tme, hipStream_t st) {
+int launch_tme(const GemmArgs& p, int tme, hipStream_t st, bool two_stage = false) {
     if constexpr (tme_instances<A_KMAJ, B_KMAJ, EPI>) {
+        // TME 4 and 5 run the three-stage loop (NV_GEMM_3STAGE=0 or tile_cfg 94 / 95: the two-stage one, for A/B measurements)
+        static const int three = [] { const char* e = getenv("NV_GEMM_3STAGE"); return e ? atoi(e) : 1; }();
+        if (three && !two_stage) {
+            if (tme == 4) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 6, 4>(p, st);
+            if (tme == 5) return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 6, 5>(p, st);
+        }
         switch (tme) {
             case 4: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4, 4>(p, st);
             case 5: return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4, 5>(p, st);
@@ -914,6 +1091,7 @@ int dispatch_tile(const GemmArgs& p, int tile_cfg, hipStream_t st) {
     if (tile_cfg == 1) return launch<128, 128, 2, 2, 64, 2, A_KMAJ, B_KMAJ, EPI>(p, st);
     if (tile_cfg == 8) return launch_tme<A_KMAJ, B_KMAJ, EPI>(p, 8, st);
     if (tile_cfg >= 84 && tile_cfg <= 88) return launch_tme<A_KMAJ, B_KMAJ, EPI>(p, tile_cfg - 80, st);
+    if (tile_cfg == 94 || tile_cfg == 95) return launch_tme<A_KMAJ, B_KMAJ, EPI>(p, tile_cfg - 90, st, true);   // two-stage loop (measurement)
     return NV_ERR_ARG;
 }
 

@@ -37,12 +37,13 @@ def assert_close(got, ref, rtol, atol_scale, what):
 
 
 # ------------------------------------------------------------------------------ bf16 GEMM
-@pytest.mark.parametrize("tile", [0, 1, 8, 84, 85, 86, 87])
+@pytest.mark.parametrize("tile", [0, 1, 8, 84, 85, 86, 87, 94, 95])
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 200, 192), (77, 520, 64), (1000, 384, 448), (670, 1024, 320)])
 def test_gemm_bf16_layouts(layout, tile, M, N, K):
     """tile: 0 = planned, 1 = 128x128, 8 = 256x256, 84..87 = the 256-wide tile cut off after 4..7 fragment rows per wave
-    (128 / 160 / 192 / 224 x 256; layouts without a cut-off instance run the full tile)"""
+    (128 / 160 / 192 / 224 x 256; 84 / 85 run the three-stage loop, 94 / 95 the same tiles on the two-stage loop; layouts without
+    a cut-off instance run the full tile)"""
     from navillm_amd import ops
     if layout == 2:
         Kc = K + 37          # wgrad: ragged contraction length
@@ -107,7 +108,7 @@ def test_gemm_bf16_splitk_tail(layout, M, N, K):
     assert (out.float() - out2.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("tile", [84, 85, 86, 87])
+@pytest.mark.parametrize("tile", [84, 85, 86, 87, 94, 95])
 def test_gemm_bf16_cut_off_tiles_epilogues_and_split_tail(tile):
     """the cut-off tiles (TME = 4..7 fragment rows per wave) through every epilogue they are instantiated for -- store, residual,
     RoPE (vs the separate row kernel, bit for bit) -- on shapes with ragged M / N edges, and on a shape whose tile count leaves a
@@ -135,6 +136,13 @@ def test_gemm_bf16_cut_off_tiles_epilogues_and_split_tail(tile):
         out2 = ops.gemm_bf16(0, A2, W2, tile_cfg=tile)
         torch.cuda.synchronize()
         assert_close(out2, ref2, 2 ** -7, 2e-3, f"cut-off split tail tile={tile} rep {rep}")
+    # short and odd K-tile counts (the three-stage loop's prologue / remainder paths: KT = 1, 2, 3, 4, 5, 7)
+    for K3 in (64, 128, 192, 256, 320, 448):
+        A3, W3 = rnd(300, K3, dtype=BF, seed=38), rnd(520, K3, dtype=BF, seed=39, scale=0.05)
+        out3 = ops.gemm_bf16(0, A3, W3, tile_cfg=tile)
+        assert torch.equal(out3, ops.gemm_bf16(0, A3, W3, tile_cfg=8)), f"tile={tile} K={K3}"
+        dY3, Wn3 = rnd(300, K3, dtype=BF, seed=40), rnd(K3, 520, dtype=BF, seed=41, scale=0.05)
+        assert torch.equal(ops.gemm_bf16(1, dY3, Wn3, tile_cfg=tile), ops.gemm_bf16(1, dY3, Wn3, tile_cfg=8)), f"dgrad tile={tile} K={K3}"
 
 
 def test_gemm_qkv_rope_cut_off_tiles_bit_identical():

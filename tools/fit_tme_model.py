@@ -6,10 +6,11 @@ import numpy as np
 from scipy.optimize import least_squares
 
 
-def tail_split(rem, KT, max_split=6, min_slice=20):
-    """gemm_bf16.hip: tail_split() as it was when the probe ran (round 3 later lets tails of <= 16 tiles split 8 ways)"""
+def tail_split(rem, KT):
+    """gemm_bf16.hip: tail_split()"""
     if rem <= 0 or rem > 128:
         return 1
+    max_split, min_slice = (8, 8) if rem <= 16 else (6, 20)
     s = min(256 // rem, max_split, KT // min_slice, 512 // rem)
     return s if s >= 2 else 1
 

@@ -1,5 +1,5 @@
 """GPU probe for the cut-off tiles of the 256-wide GEMM kernel (TME = 4..8 fragment rows per wave = 128..256 x 256 tiles):
-duration of forward (NT) and dgrad (NN) GEMMs per TME on (a) the few-hundred-row shapes of K/V-reuse / suffix steps and (b) the
+duration of forward (NT) and dgrad (NN) GEMMs per TME (84 / 85: three-stage loop, 94 / 95: the same tiles on the two-stage loop) on (a) the few-hundred-row shapes of K/V-reuse / suffix steps and (b) the
 dense training shapes, next to the planner's choice (tile_cfg 0) and its estimate.  -> profiles/r03_gemm_tme_probe.txt
 Usage: python tools/gemm_tme_probe.py [quick]"""
 import os
@@ -23,7 +23,7 @@ for M in Ms:
         for lay, A, B in ((0, X, W), (1, dY, W)):
             line = f"M={M:5d} {name:8s} {'NT' if lay == 0 else 'NN'} N={N if lay == 0 else K:6d} K={K if lay == 0 else N:6d}:"
             best = None
-            for tile in (1, 84, 85, 86, 87, 88, 0):
+            for tile in (1, 94, 95, 84, 85, 86, 87, 88, 0):
                 t = bench([lambda i=i: ops.gemm_bf16(lay, A[i], B[i], tile_cfg=tile) for i in range(3)], iters=12)
                 line += f"  {tile if tile else 'plan'}: {t * 1e6:6.1f}us"
                 if tile not in (0,) and (best is None or t < best[1]):
