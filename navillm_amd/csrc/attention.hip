@@ -447,12 +447,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 // rows = B*S (padded layout) or cu[B] (packed layout: the sample of a row is found by walking cu, B is small)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ out,
                                                             float* __restrict__ dsum, const int* __restrict__ cu, long rows, int B,
-                                                            int S, int H) {
+                                                            int S, int H, int q_lo, int nq) {
     const int sub = threadIdx.x & 15;
     const long item = (long)blockIdx.x * 16 + (threadIdx.x >> 4);   // (row, head)
     const bool live = item < rows * H;
-    const long row = live ? item / H : 0;
+    long row = live ? item / H : 0;
     const int h = live ? (int)(item % H) : 0;
+    int bb = 0, s_ = 0;
+    if (cu) {
+        while (bb + 1 < B && row >= cu[bb + 1]) ++bb;
+        s_ = (int)(row - cu[bb]);
+    } else {
+        // padded / K/V-cache layout: only the query rows [q_lo, q_lo + nq) of every sample carry gradient (round 3: a suffix step of
+        // navillm_amd/episode.py differentiates ~130 of the cache's 1024 rows per sample; the other rows' dsum is never read)
+        bb = (int)(row / nq); s_ = q_lo + (int)(row % nq);
+        row = (long)bb * S + s_;
+    }
     const u32x4 av = *(const u32x4*)(dout + row * (H * HD) + h * HD + sub * 8);
     const u32x4 ov = *(const u32x4*)(out + row * (H * HD) + h * HD + sub * 8);
     float v = 0.f;
@@ -462,17 +472,7 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __rest
              __uint_as_float(av[q] & 0xffff0000u) * __uint_as_float(ov[q] & 0xffff0000u);
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if (live && sub == 0) {
-        int bb, s;
-        if (cu) {
-            bb = 0;
-            while (bb + 1 < B && row >= cu[bb + 1]) ++bb;
-            s = (int)(row - cu[bb]);
-        } else {
-            bb = (int)(row / S); s = (int)(row % S);
-        }
-        dsum[((long)bb * H + h) * S + s] = v;
-    }
+    if (live && sub == 0) dsum[((long)bb * H + h) * S + s_] = v;
 }
 
 // =========================================================================== backward dK, dV
@@ -903,11 +903,13 @@ static int attn_bwd_impl(const void* qkv, const void* out, const void* dout, con
     hipStream_t st = (hipStream_t)stream;
     float* dsum = (float*)workspace;
     if (Sst <= 0) Sst = S;
-    if (rows < 0) rows = (long)B * Sst;
+    // padded / strided (K/V-cache) layout: dsum is indexed like lse2, [B, H, Sst]; only the query rows [q_row_min, S) of a sample are
+    // read by the kernels below
+    const int q_lo = cu ? 0 : q_row_min, nq = cu ? 0 : S - q_row_min;
+    if (rows < 0) rows = (long)B * nq;
     const long items = rows * H;
-    // strided (K/V-cache) layout: dsum is indexed like lse2, [B, H, Sst]; the rows between a sample's length and Sst carry dO = 0
     NV_LAUNCH(attn_bwd_prep_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, (const bf16_t*)dout,
-                       (const bf16_t*)out, dsum, cu, rows, B, cu ? S : Sst, H);
+                       (const bf16_t*)out, dsum, cu, rows, B, cu ? S : Sst, H, q_lo, nq);
     AttnArgs p{};
     p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.lse2 = (float*)lse2; p.dsum = dsum; p.dqkv = (bf16_t*)dqkv;
     p.kv_start = kv_start; p.cu = cu; p.B = B; p.S = S; p.Sst = Sst; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
