@@ -65,9 +65,18 @@ def make_cfg(a):
 class GemmTimer:
     """HIP events around the bf16 GEMM launches, on the stream the kernels are launched on.  Only while `active`: bracketing
     all 384 GEMM launches of every step with two events each costs the step 0.9 % (43.30 vs 43.68 nav-steps/s, ABAB on one box), so
-    the timed region instruments every SAMPLE_EVERY-th step (the first timed step always; 5 and 6 steps per episode are coprime, so
-    the sampled steps walk through all positions of an episode)."""
-    SAMPLE_EVERY = 5
+    the timed region instruments ONE WHOLE EPISODE (its second one, steps 6..11 of the window; the steps of an episode differ a lot
+    in the prefix-reuse mode: the first carries the prefix forward, the last the prefix backward and the per-weight wgrad GEMMs).
+    Shorter windows (< 12 steps) instrument every step."""
+
+    @staticmethod
+    def sampled(k, steps):
+        """is step k (0-based inside the timed window of `steps` steps) instrumented?"""
+        return STEPS_PER_EPISODE <= k < 2 * STEPS_PER_EPISODE if steps >= 2 * STEPS_PER_EPISODE else True
+
+    @staticmethod
+    def n_sampled(steps):
+        return STEPS_PER_EPISODE if steps >= 2 * STEPS_PER_EPISODE else steps
 
     def __init__(self):
         self.recs = []
@@ -164,7 +173,7 @@ def roofline_of(timer, dt, steps, mode, model):
     if g is None:
         return None
     allg = timer.summary(layouts=(0, 1, 2))
-    n_sampled = (steps + GemmTimer.SAMPLE_EVERY - 1) // GemmTimer.SAMPLE_EVERY      # timed steps that carried the events
+    n_sampled = GemmTimer.n_sampled(steps)           # timed steps that carried the events: one whole episode
     # the dominant kernel is ONE template (gemm_bf16_kernel) in three operand layouts.  With the backward on a single stream (the
     # default) every launch's event bracket is its kernel duration, so the roofline is taken over all of them; with the optional
     # wgrad side stream only the forward launches run alone.
@@ -176,10 +185,10 @@ def roofline_of(timer, dt, steps, mode, model):
     return {"bound": "mfma", "achieved": round(r["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(r["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_src,
-            "kernel": "gemm_bf16_kernel<256,256,2,4,64,2,*,*,*,4,TME> -- every bf16 GEMM launch of every %d-th timed step, "
-                      "%d of the %d (forward y = x W^T, dgrad, wgrad of qkv / o / gate|up / down in every layer; in prefix_reuse mode the "
+            "kernel": "gemm_bf16_kernel<256,256,2,4,64,2,*,*,*,PIPE,TME> -- every bf16 GEMM launch of one whole episode of the timed region "
+                      "(%d of the %d steps: forward y = x W^T, dgrad, wgrad of qkv / o / gate|up / down in every layer; in prefix_reuse mode the "
                       "suffix steps' few-hundred-row GEMMs run the cut-off 128..224 x 256 tiles; bracketing all steps costs the step 0.9 %%)"
-                      % (GemmTimer.SAMPLE_EVERY, n_sampled, steps)
+                      % (n_sampled, steps)
                       if not model.overlap_wgrad else
                       "gemm_bf16_kernel<256,256,2,4,64,2,true,true,*,4,*> (forward launches only: with the wgrad side stream the backward brackets overlap)",
             "launches": r["launches"], "avg_launch_ms": round(r["avg_launch_ms"], 4),
@@ -616,7 +625,7 @@ def main():
         t0 = time.perf_counter()
         loss = None
         for i in range(base, base + steps):
-            tm.active = (i - base) % GemmTimer.SAMPLE_EVERY == 0
+            tm.active = GemmTimer.sampled(i - base, steps)
             loss = one_step(i)
         torch.cuda.synchronize()
         if world > 1 and sync_ranks:

@@ -431,7 +431,7 @@ def test_clip_and_adamw_vs_reference_fixture_g8():
     """the HIP clip + AdamW against fixture G8 DIRECTLY -- three steps of torch's own
     `clip_grad_norm_(params, 40.)` + `torch.optim.AdamW` on two bf16 tensors and one fp32 tensor (train.py:86-89,
     tools/optims.py:43-45), clipping active at every step (norms 45 / 4520 / 45).  The fused clip keeps the global norm in
-    fp32 where torch rounds each per-tensor norm to the gradient dtype first: the total norm must agree to 0.2 %; the clip
+    fp32 where torch rounds each per-tensor norm to the gradient dtype first: the total norm must agree to 0.5 % (measured 0.26 %); the clip
     coefficient then differs in its last digits, which flips the bf16 rounding of a moment here and there, so a few per cent of the
     bf16 parameters may differ from torch's -- by at most 2 % of the update (an AdamW update is ~lr = 1e-3 whatever the gradient;
     torch's bf16 sequence rounds five times on the way -- lerp, mul, addcmul, sqrt / div / add, addcdiv -- 2^-9 to 2^-8 relative each, and
@@ -455,7 +455,7 @@ def test_clip_and_adamw_vs_reference_fixture_g8():
         coef = ops.clip_coef(gs, 40.0)
         torch.cuda.synchronize()
         want_norm = float(z["norms"][s_])
-        assert abs(coef[0].item() - want_norm) <= 2e-3 * want_norm, (s_, coef[0].item(), want_norm)
+        assert abs(coef[0].item() - want_norm) <= 5e-3 * want_norm, (s_, coef[0].item(), want_norm)   # torch: per-tensor norms rounded to bf16 (2^-8) first
         for i in range(3):
             ops.adamw_(ps[i], gs[i], ms[i], vs[i], s_ + 1, 1e-3, clip=coef)
         torch.cuda.synchronize()
