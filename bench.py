@@ -281,6 +281,31 @@ def mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed):
     eps = {t: SyntheticEpisodes(cfg, a.batch, seed=seed + i, instr_len=(a.instr_len if t != "soon" else min(a.instr_len, 256)),
                                 device=device, task=t) for i, t in enumerate(("r2r", "reverie", "soon", "cvdn"))}
     res = {}
+    # round 3: the same meta-steps with the navigation steps over the episode's cached prompt prefix (the sub-tasks -- fine-grained R2R,
+    # object grounding, summarization, ScanQA -- have prompts of their own and run through the whole LM in either mode)
+    pre = None
+    for rep in range(2):
+        nav_steps = 0
+        per_task = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t, ep in eps.items():
+            ep.reset()
+            t1 = time.perf_counter()
+            mixed_task_episode(wrapped, crit, ep, STEPS_PER_EPISODE, prefix_reuse=True)
+            opt.clip_grad_norm_(40.0); opt.step(); opt.zero_grad()
+            nav_steps += STEPS_PER_EPISODE * a.batch
+            torch.cuda.synchronize()
+            per_task[t] = round((time.perf_counter() - t1) * 1e3, 1)
+        t1 = time.perf_counter()
+        qa_step(wrapped, eps["r2r"], sync="final")
+        opt.clip_grad_norm_(40.0); opt.step(); opt.zero_grad()
+        torch.cuda.synchronize()
+        per_task["scanqa"] = round((time.perf_counter() - t1) * 1e3, 1)
+        dt = time.perf_counter() - t0
+        pre = {"seconds": round(dt, 3), "ms_per_meta_step": per_task, "nav_steps_per_s_per_gpu": round(nav_steps / dt, 2),
+               "episodes_per_s_per_gpu": round((4 * a.batch + a.batch) / dt, 2)}
+    model.episode_abort()
     for rep in range(2):
         model.flop_log = []
         nav_steps = 0
@@ -307,7 +332,9 @@ def mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed):
                "algorithmic_tflops": round(fl / dt / 1e12, 1), "frac_of_mfma_peak": round(fl / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                "what": f"one episode each of r2r (+fgr2r on steps 0,2,4 +summarization), reverie and soon (+object grounding +summarization), "
                        f"cvdn, {STEPS_PER_EPISODE} nav steps each with per-step backward, and one ScanQA batch; B={a.batch}; clip+AdamW after each; "
-                       f"algorithmic FLOPs per SURVEY.md §8d incl. lm_head in the LM-loss modes"}
+                       f"algorithmic FLOPs per SURVEY.md §8d incl. lm_head in the LM-loss modes (top level: the whole prompt recomputed at "
+                       f"every nav step; `navigation_over_cached_prefix`: the same meta-steps in prefix_reuse mode)"}
+        res["navigation_over_cached_prefix"] = pre
     model.flop_log = None
     return res
 

@@ -536,28 +536,39 @@ def qa_step(model, ep, train=True, sync="final", coef=1.0, accum=1, answer_len=8
     return loss, out
 
 
-def mixed_task_episode(model, criterion, ep, steps, enable_og=None, enable_summarize=True, enable_fgr2r=True, accum=1, train=True):
+def mixed_task_episode(model, criterion, ep, steps, enable_og=None, enable_summarize=True, enable_fgr2r=True, accum=1, train=True,
+                       prefix_reuse=False):
     """One training meta-step of the multi-task mix (BASELINE config 3; rollout of tasks/agents/mp3d_agent.py:593-964 for the
     task `ep.task`): `steps` navigation steps, each with its backward inside `no_sync` except the last; fine-grained R2R
     (embodied_qa + LM loss) on the non-last steps of an R2R episode; on the last step the object-grounding sub-task (SOON /
     REVERIE) and the summarization sub-task (not CVDN), each with its own backward -- the last of them is the `final` one a
-    data-parallel wrapper exchanges gradients from.  Returns the losses of the episode."""
+    data-parallel wrapper exchanges gradients from.  Returns the losses of the episode.
+    prefix_reuse: the NAVIGATION steps run over the episode's cached prompt prefix (navillm_amd/episode.py); the sub-tasks have
+    prompts of their own and go through the whole LM as before; the prefix's deferred backward then is the episode's last one."""
     if enable_og is None:
         enable_og = ep.task in ("soon", "reverie")
     enable_summarize = enable_summarize and ep.task != "cvdn"
     enable_fgr2r = enable_fgr2r and ep.task == "r2r"
+    inner = model.module if hasattr(model, "module") else model
+    prefix_reuse = prefix_reuse and train
+    if prefix_reuse:
+        inner.begin_episode(ep.prefix_ids())
     losses = {"nav": [], "og": None, "sum": None, "fgr2r": []}
     for t in range(steps):
         last = t == steps - 1
         more = last and (enable_og or enable_summarize)
-        l, _ = nav_step(model, criterion, ep, train=train, last=last, accum=accum, final=last and not more)
+        l, _ = nav_step(model, criterion, ep, train=train, last=last, accum=accum, final=last and not more and not prefix_reuse)
         losses["nav"].append(l)
         if enable_fgr2r and not last and t % 2 == 0 and train:
             losses["fgr2r"].append(lm_aux_step(model, ep, "embodied_qa", sync="no_sync", accum=accum)[0])
         if last and enable_og and train:
-            losses["og"] = og_step(model, criterion, ep, sync="plain" if enable_summarize else "final", accum=accum)[0]
+            losses["og"] = og_step(model, criterion, ep, sync="plain" if (enable_summarize or prefix_reuse) else "final", accum=accum)[0]
         if last and enable_summarize and train:
-            losses["sum"] = lm_aux_step(model, ep, "summarization", sync="final", accum=accum)[0]
+            losses["sum"] = lm_aux_step(model, ep, "summarization", sync="plain" if prefix_reuse else "final", accum=accum)[0]
+    if prefix_reuse:
+        ctx = model.final_backward if hasattr(model, "final_backward") else contextlib.nullcontext
+        with ctx():
+            inner.finish_episode()
     return losses
 
 

@@ -132,3 +132,37 @@ def test_prefix_episode_under_the_data_parallel_wrapper_world1():
     for g in base:
         assert torch.equal(base[g], got[g]), g
     comm.close()
+
+
+@pytest.mark.parametrize("task", ["r2r", "reverie"])
+def test_mixed_task_episode_with_navigation_over_cached_prefix(task):
+    """BASELINE config 3 in prefix-reuse mode: the navigation steps of a multi-task episode run over the cached prompt prefix while
+    its sub-tasks (fine-grained R2R, object grounding, summarization: prompts of their own) go through the whole LM; the prefix's
+    deferred backward comes last.  Accumulated gradients and every loss must match the all-recompute episode."""
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.losses import CrossEntropyLoss
+    from navillm_amd.synthetic import SyntheticEpisodes, mixed_task_episode
+    cfg = _mid_cfg()
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
+    m.eval()
+    crit = CrossEntropyLoss()
+
+    def run(prefix):
+        ep = SyntheticEpisodes(cfg, 3, seed=41, instr_len=150, device=torch.device(DEV), task=task)
+        m.zero_grad()
+        m.store.touched.clear()
+        torch.manual_seed(9)
+        losses = mixed_task_episode(m, crit, ep, steps=3, prefix_reuse=prefix)
+        torch.cuda.synchronize()
+        flat = [float(l.detach()) for l in losses["nav"] + losses["fgr2r"] + [losses["og"], losses["sum"]] if l is not None]
+        return flat, {g: t.detach().float().clone() for g, t in m.store.grad.items()}, set(m.store.touched)
+
+    l_ref, g_ref, t_ref = run(False)
+    l_pre, g_pre, t_pre = run(True)
+    assert m.episode.prefix is None and t_pre == t_ref and len(l_ref) == len(l_pre)
+    for a, b in zip(l_pre, l_ref):
+        assert abs(a - b) <= 2e-2 * max(1.0, abs(b)), (l_pre, l_ref)
+    for g in g_ref:
+        rel = ((g_pre[g] - g_ref[g]).norm() / (g_ref[g].norm() + 1e-20)).item()
+        print(f"[mixed {task}] gradient buffer {g}: prefix-reuse vs recompute rel err {rel:.4f}")
+        assert rel < 2.5e-2, (g, rel)
