@@ -32,6 +32,16 @@ per-layer episode buffers behind the prefix's rows (131 KB per token row and lay
 and `finish()` runs ONE weight-gradient GEMM per weight over all ~8 300 rows of the episode -- fp32 accumulation across the
 whole episode and a single bf16 rounding, where the per-step form (and the reference's autograd) round after every step.
 
+Round 3b: the WHOLE backward of the suffix steps is deferred too (`NAVILLM_EPISODE_DEFER=all`, the default; `wgrad` = only the
+weight gradients as above, `none` = everything step by step).  A step's `backward()` then only records the gradient of its B
+output rows; `finish()` walks the layers ONCE for every token row of the episode -- prefix rows and all steps' blocks side by
+side, ~8 300 rows -- so the four dgrad GEMMs per layer and the row kernels run at large-M efficiency instead of six times at
+M ~ 670 (the attention backward stays per step: each step's rows are put back into the K/V cache and differentiated over the
+cache layout, the prefix's own causal attention separately), and each step's visual-token gradient is then sent into that
+step's scene-encoder / fusion graph, which was kept alive (the step's forward hands the LM a detached copy).  Nothing reads
+`.grad` between the steps of an episode -- `optimizer.step()` only runs after it (train.py:86-89) -- so the result is the same
+sum of gradients.  What is kept per token row and layer: x, n1, qkv, attn, x1, n2, gu, h (131 KB at 7B) + the per-step lse.
+
 This is an OPTIONAL mode (`NavModel.begin_episode`): the default training path, `bench.py`'s `value` included, recomputes the
 full prompt at every step like the reference.
 """
@@ -61,16 +71,21 @@ def prefix_ids_from_prompts(tokenizer, prompts):
 
 
 class _SuffixLM(torch.autograd.Function):
-    """the step's suffix rows through the decoder over the cached prefix -> final-norm hidden state of each sample's last token"""
+    """the step's suffix rows through the decoder over the cached prefix -> final-norm hidden state of each sample's last token.
+    mode "all": `vis_all` arrives detached (the live tensor, with its encoder / fusion graph, waits in step["vis_live"]), the backward
+    only records dH; finish() does the rest."""
 
     @staticmethod
     def forward(ctx, vis_all, anchor, ep, step):
-        Hs, saved = ep._step_forward(step, vis_all)
+        Hs, saved = ep._step_forward(step, vis_all if step.get("vis_live") is None else step["vis_live"].detach())
         ctx.ep, ctx.saved, ctx.has_vis = ep, saved, vis_all is not None
         return Hs
 
     @staticmethod
     def backward(ctx, dH):
+        if ctx.saved.get("batched"):
+            ctx.saved["dH"] = dH.contiguous().clone()
+            return None, None, None, None
         dvis = ctx.ep._step_backward(ctx.saved, dH.contiguous())
         return (dvis if ctx.has_vis else None), None, None, None
 
@@ -83,7 +98,7 @@ class PrefixEpisode:
         dev = model.device
         rows = batch_size * capacity
         self.cache = [torch.zeros((rows + 1, 3 * d), dtype=BF16, device=dev) for _ in range(L)]   # + a junk row for padding rows
-        self.attn_buf = [torch.zeros((rows, d), dtype=BF16, device=dev) for _ in range(L)]
+        self.attn_buf = [torch.zeros((rows + 1, d), dtype=BF16, device=dev) for _ in range(L)]      # (+ junk row: steps are scattered back in finish())
         self.lse = [torch.zeros((batch_size, H, capacity), dtype=F32, device=dev) for _ in range(L)]
         self.dkv_acc = [torch.zeros((rows, 2 * d), dtype=F32, device=dev) for _ in range(L)]
         self.dout_full = torch.zeros((rows + 1, d), dtype=BF16, device=dev)
@@ -93,9 +108,15 @@ class PrefixEpisode:
         self._slab = {}
         self._wcache = {}
         self.stats = {"prefix_rows": 0, "suffix_rows": []}
-        self.defer_wgrad = os.environ.get("NAVILLM_EPISODE_DEFER_WGRAD", "1") != "0"
+        mode = os.environ.get("NAVILLM_EPISODE_DEFER", "all")
+        if os.environ.get("NAVILLM_EPISODE_DEFER_WGRAD", "1") == "0":
+            mode = "none"
+        assert mode in ("all", "wgrad", "none"), mode
+        self.mode = mode
+        self.defer_wgrad = mode != "none"
+        self.lse_s = []                                       # mode "all": per step, per layer lse [B, H, cap] (1 MB each at B = 8)
         self.fuse_kvacc = os.environ.get("NAVILLM_EPISODE_FUSE_KVACC", "1") != "0"
-        self._E, self._ecap, self._cursor, self._last_rows = None, 0, 0, 0
+        self._E, self._E32, self._ecap, self._cursor, self._last_rows = None, None, 0, 0, 0
 
     # ------------------------------------------------------------------ helpers
     def _buf(self, tag, shape, dtype=BF16):
@@ -108,28 +129,41 @@ class PrefixEpisode:
         return t[:n].view(*shape)
 
     _EWIDTH = {"n1": (1, 0), "attn": (1, 0), "n2": (1, 0), "h": (0, 1), "dqkv": (3, 0), "dx1": (1, 0), "dgu": (0, 2), "dxo": (1, 0)}
+    # mode "all": forward activations only (the gradients of a layer are produced and consumed inside finish()'s layer iteration)
+    _EWIDTH_ALL = {"x": (1, 0), "n1": (1, 0), "qkv": (3, 0), "attn": (1, 0), "x1": (1, 0), "n2": (1, 0), "gu": (0, 2), "h": (0, 1)}
 
     def _ensure_rows(self, rows):
-        """per-layer episode buffers [capacity, width]: the Linear inputs (n1, attn, n2, h) and output gradients (dqkv, dx1, dgu,
-        dxo = gradient of the layer's output) of every token row the episode has pushed through the decoder so far -- prefix rows
-        first, then each step's block.  Grow-only; growing mid-episode copies the rows already written (first episodes only)."""
+        """per-layer episode buffers [capacity, width] for every token row the episode has pushed through the decoder so far --
+        prefix rows first, then each step's block.  mode "wgrad": the Linear inputs (n1, attn, n2, h) and output gradients (dqkv, dx1,
+        dgu, dxo); mode "all": every forward activation the backward needs (+ the two fp32 rstd vectors).  Grow-only; growing
+        mid-episode copies the rows already written (first episodes only)."""
         if self._E is not None and rows <= self._ecap:
             return
         cfg, dev = self.m.cfg, self.m.device
         d, ff = cfg.hidden_size, cfg.intermediate_size
+        widths = self._EWIDTH_ALL if self.mode == "all" else self._EWIDTH
         cap = int(rows * (1.5 if self._cursor else 1.1)) + 64      # growing mid-episode copies: do it rarely
-        new = []
+        new, new32 = [], []
         for i in range(cfg.num_layers):
-            bufs = {}
-            for name, (cd, cf) in self._EWIDTH.items():
+            bufs, b32 = {}, {}
+            for name, (cd, cf) in widths.items():
                 t = torch.empty((cap, cd * d + cf * ff), dtype=BF16, device=dev)
                 if self._E is not None and self._cursor:
                     t[: self._cursor].copy_(self._E[i][name][: self._cursor])
                 bufs[name] = t
+            if self.mode == "all":
+                for name in ("r1", "r2"):
+                    t = torch.empty((cap,), dtype=F32, device=dev)
+                    if self._E32 is not None and self._cursor:
+                        t[: self._cursor].copy_(self._E32[i][name][: self._cursor])
+                    b32[name] = t
             new.append(bufs)
+            new32.append(b32)
             if self._E is not None:
                 self._E[i] = None                      # release layer by layer: never two full copies resident
-        self._E, self._ecap = new, cap
+                if self._E32 is not None:
+                    self._E32[i] = None
+        self._E, self._E32, self._ecap = new, new32, cap
 
     def _weights(self, i):
         """(Wqkv, Wo, Wgu, Wd, w1, w2, their six gradient views) of layer i: views of the flat store, built once"""
@@ -169,13 +203,15 @@ class PrefixEpisode:
         zero_pos0 = torch.zeros((B,), dtype=I32, device=dev)
         Lmax = int(lens.max())
         d, ff = cfg.hidden_size, cfg.intermediate_size
-        x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_d, vix, None, out=self._buf("pE", (Mp, d)))
         layers = []
         defer = self.defer_wgrad
+        allm = self.mode == "all"
         if defer:
             self._cursor = 0
             self._ensure_rows(Mp + max(self._last_rows, Mp))     # first episode: assume the steps add about as many rows as the prefix has
             self._cursor = Mp
+        x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_d, vix, None,
+                          out=self._E[0]["x"][:Mp] if allm else self._buf("pE", (Mp, d)))
         for i in range(L):
             Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
             # kept until finish(): grow-only slabs, so prefixes of varying length do not churn the allocator; the four Linear
@@ -185,6 +221,10 @@ class PrefixEpisode:
             def t(name, width, dt=BF16, E=E, i=i):
                 if E is not None and name in E:
                     return E[name][:Mp]
+                if allm and name in ("r1", "r2"):
+                    return self._E32[i][name][:Mp]
+                if allm and name == "x2" and i + 1 < L:
+                    return self._E[i + 1]["x"][:Mp]        # a layer's output IS the next layer's saved input
                 return self._buf(f"p{i}.{name}", (Mp, width) if width else (Mp,), dt)
             n1, rstd1 = ops.rmsnorm_fwd(x, w1, eps, out=t("n1", d), rstd=t("r1", 0, F32))
             qkv = ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, Lmax, 2 * H * hd, out=t("qkv", 3 * d), pos_i32=pos_d)
@@ -200,7 +240,7 @@ class PrefixEpisode:
             layers.append(dict(x=x, n1=n1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x1=x1, n2=n2, rstd2=rstd2, gu=gu, h=h))
             x = x2                                     # (dkv_acc needs no zero-fill: the first step SETS the prefix rows)
         self.prefix = dict(ids=[list(p) for p in prefix_ids], ids_np=ids, lens=lens, cu=cu_d, pos=pos_d, crow=crow_d, pos0=zero_pos0,
-                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0, kv_steps=0, defer=defer, lens_dev=lens_d)
+                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0, kv_steps=0, defer=defer, lens_dev=lens_d, recs=[])
         self.stats = {"prefix_rows": Mp, "suffix_rows": []}
 
     # ------------------------------------------------------------------ one step: suffix rows over the cached prefix
@@ -249,6 +289,11 @@ class PrefixEpisode:
                     ids_np=ids_new)
         self.stats["suffix_rows"].append(int(sum(n)))
         anchor = self.m._anchor if torch.is_grad_enabled() else None
+        if self.mode == "all" and P["defer"] and torch.is_grad_enabled():
+            # the LM sees a detached copy; the live tensor keeps this step's scene-encoder / fusion graph alive until finish()
+            step["vis_live"] = vis_all
+            step["batched"] = True
+            return _SuffixLM.apply(None, anchor, self, step)
         return _SuffixLM.apply(vis_all, anchor, self, step)
 
     def _step_forward(self, step, vis_all):
@@ -258,11 +303,16 @@ class PrefixEpisode:
         M, Lmax, qmin = step["M"], step["Lmax"], step["qmin"]
         k = self.prefix["steps"]
         defer = self.defer_wgrad and self.prefix["defer"]
+        allm = defer and bool(step.get("batched"))
         r0 = self._cursor
         if defer:
             self._ensure_rows(r0 + M)
             self._cursor = r0 + M
-        x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), step["ids"], step["vix"], vis_all, out=self._buf("E", (M, d)))
+        if allm:
+            while len(self.lse_s) <= k:
+                self.lse_s.append([torch.zeros((B, H, cap), dtype=F32, device=m.device) for _ in range(L)])
+        x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), step["ids"], step["vix"], vis_all,
+                          out=self._E[0]["x"][r0:r0 + M] if allm else self._buf("E", (M, d)))
         layers = []
         for i in range(L):
             Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
@@ -270,13 +320,18 @@ class PrefixEpisode:
 
             def t(name, width, dt=BF16, E=E, i=i):
                 if E is not None and name in E:
-                    return E[name][r0:r0 + M]          # this step's block of the episode buffers: kept for finish()'s weight gradients
+                    return E[name][r0:r0 + M]          # this step's block of the episode buffers: kept for finish()
+                if allm and name in ("r1", "r2"):
+                    return self._E32[i][name][r0:r0 + M]
+                if allm and name == "x2" and i + 1 < L:
+                    return self._E[i + 1]["x"][r0:r0 + M]
                 return self._buf(f"s{i}.{name}", (M, width) if width else (M,), dt)
             n1, rstd1 = ops.rmsnorm_fwd(x, w1, eps, out=t("n1", d), rstd=t("r1", 0, F32))
-            qkv = ops.gemm_bf16(ops.NT, n1, Wqkv, out=self._buf("qkv", (M, 3 * d)))
+            qkv = ops.gemm_bf16(ops.NT, n1, Wqkv, out=E["qkv"][r0:r0 + M] if allm else self._buf("qkv", (M, 3 * d)))
             ops.rope_rows_(qkv, m.rope_cos, m.rope_sin, step["pos"], H, hd)
             ops.scatter_rows_bf16_(qkv, step["crow"], self.cache[i])
-            ops.attn_fwd_strided(self.cache[i], self.kv0, B, Lmax, cap, H, hd, out=self.attn_buf[i], lse2=self.lse[i], q_row_min=qmin)
+            lse_i = self.lse_s[k][i] if allm else self.lse[i]
+            ops.attn_fwd_strided(self.cache[i], self.kv0, B, Lmax, cap, H, hd, out=self.attn_buf[i], lse2=lse_i, q_row_min=qmin)
             attn = t("attn", d)
             ops._lib.check(ops._L().nv_gather_rows_bf16(self.attn_buf[i].data_ptr(), step["grow"].data_ptr(), attn.data_ptr(), M, d, ops._st()),
                            "nv_gather_rows_bf16")
@@ -285,12 +340,16 @@ class PrefixEpisode:
             gu = ops.gemm_bf16(ops.NT, n2, Wgu, out=t("gu", 2 * ff))
             h = ops.swiglu_fwd(gu, out=t("h", ff))
             x2 = ops.gemm_bf16(ops.NT, h, Wd, out=t("x2", d), R=x1, epilogue=ops.EPI_RESID)
-            layers.append(dict(x=x, n1=n1, rstd1=rstd1, attn=attn, x1=x1, n2=n2, rstd2=rstd2, gu=gu, h=h))
+            if not allm:
+                layers.append(dict(x=x, n1=n1, rstd1=rstd1, attn=attn, x1=x1, n2=n2, rstd2=rstd2, gu=gu, h=h))
             x = x2
         x_last = ops.gather_rows_bf16(x, step["last"])
         Hs, rstdf = ops.rmsnorm_fwd(x_last, st.p("lang_model.model.norm.weight"), eps)
         self.prefix["steps"] = k + 1
-        return Hs, dict(step=step, layers=layers, x_last=x_last, rstdf=rstdf, serial=k + 1, r0=r0, defer=defer)
+        saved = dict(step=step, layers=layers, x_last=x_last, rstdf=rstdf, serial=k + 1, r0=r0, defer=defer, batched=allm, k=k, dH=None)
+        if allm:
+            self.prefix["recs"].append(saved)
+        return Hs, saved
 
     def _step_backward(self, saved, dH):
         m, cfg, st = self.m, self.m.cfg, self.m.store
@@ -376,6 +435,8 @@ class PrefixEpisode:
         m, cfg, st = self.m, self.m.cfg, self.m.store
         B, H, hd, L, d = self.B, cfg.num_heads, cfg.head_dim, cfg.num_layers, cfg.hidden_size
         Mp, Lmax = P["Mp"], P["Lmax"]
+        if self.mode == "all" and P["defer"]:
+            return self._finish_batched()
         if P["kv_steps"] == 0:                         # no step ran a backward: nothing to propagate (and dkv_acc holds no data)
             self.prefix = None
             self._cursor = 0
@@ -431,3 +492,90 @@ class PrefixEpisode:
         dp = getattr(m, "_dp", None)
         if dp is not None and dp._exchanging():
             dp._finalize()                         # outside autograd: no engine callback will run the end-of-backward exchange
+
+    def _finish_batched(self):
+        """mode "all": ONE walk down the layers for every token row of the episode (prefix rows [0, Mp), then each step's block)."""
+        P = self.prefix
+        m, cfg, st = self.m, self.m.cfg, self.m.store
+        B, cap, H, hd, L, d, ff = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.num_layers, cfg.hidden_size, cfg.intermediate_size
+        Mp, R = P["Mp"], self._cursor
+        recs = P["recs"]
+        live = [r for r in recs if r["dH"] is not None]
+        self.prefix = None
+        self._last_rows = R - Mp
+        self._cursor = 0
+        if not live:
+            return
+        with torch.no_grad():
+            st.touch_layers()
+            dp0 = getattr(m, "_dp", None)
+            if dp0 is not None:
+                dp0.on_deferred_backward_begin()
+            normw, gnormw = st.p("lang_model.model.norm.weight"), st.g("lang_model.model.norm.weight")
+            dx, other = self._buf("b.dx_a", (R, d)), self._buf("b.dx_b", (R, d))
+            dx1, dattn, dn = self._buf("b.dx1", (R, d)), self._buf("b.dattn", (R, d)), self._buf("b.dn", (R, d))
+            dqkv, dgu, dh = self._buf("b.dqkv", (R, 3 * d)), self._buf("b.dgu", (R, 2 * ff)), self._buf("b.dh", (R, ff))
+            # gradient of the stack's output: the final norm's backward on each step's B last-token rows; zero everywhere else (the
+            # top layer's prefix rows feed nothing, a step without a backward contributes nothing)
+            dx.zero_()
+            for r in live:
+                dx_last = ops.rmsnorm_bwd(r["dH"], r["x_last"], normw, r["rstdf"], gnormw)
+                ops.scatter_rows_bf16_(dx_last, r["step"]["last"], dx[r["r0"]:r["r0"] + r["step"]["M"]])
+            Mz = max(r["step"]["M"] for r in recs)
+            zeros_md = self._buf("zeros_md", (Mz, d))
+            zeros_md.zero_()
+            Lp_max = P["Lmax"]
+            for i in reversed(range(L)):
+                Wqkv, Wo, Wgu, Wd, w1, w2, gqkv, go, ggu, gd, gw1, gw2 = self._weights(i)
+                E, E32 = self._E[i], self._E32[i]
+                ops.gemm_bf16(ops.NN, dx, Wd, out=dh)
+                ops.gemm_bf16(ops.TN, dx, E["h"][:R], out=gd, epilogue=ops.EPI_ACCUM)
+                ops.swiglu_bwd(E["gu"][:R], dh, out=dgu)
+                ops.gemm_bf16(ops.NN, dgu, Wgu, out=dn)
+                ops.gemm_bf16(ops.TN, dgu, E["n2"][:R], out=ggu, epilogue=ops.EPI_ACCUM)
+                ops.rmsnorm_bwd(dn, E["x1"][:R], w2, E32["r2"][:R], gw2, resid_grad=dx, out=dx1)
+                ops.gemm_bf16(ops.NN, dx1, Wo, out=dattn)
+                ops.gemm_bf16(ops.TN, dx1, E["attn"][:R], out=go, epilogue=ops.EPI_ACCUM)
+                # attention backward.  The prefix rows' own causal attention (packed rows) ...
+                ops.attn_bwd_varlen(E["qkv"][:Mp], E["attn"][:Mp], dattn[:Mp], P["layers"][i]["lse"], P["cu"], P["pos0"], B, Lp_max, H, hd,
+                                    dqkv[:Mp], q_row_min=0, rope=None)
+                # ... and each step's rows over the K/V cache: the step's post-RoPE q|k|v and its attention outputs go back to their
+                # cache rows, dO to the step's rows (zero elsewhere); the gradients the step sends into the cached prefix rows are
+                # summed in fp32 by the kernel itself (first step: stored)
+                for n_, r in enumerate(recs):
+                    sp = r["step"]
+                    rows = slice(r["r0"], r["r0"] + sp["M"])
+                    ops.scatter_rows_bf16_(E["qkv"][rows], sp["crow"], self.cache[i])
+                    ops.scatter_rows_bf16_(E["attn"][rows], sp["crow"], self.attn_buf[i])
+                    ops.scatter_rows_bf16_(dattn[rows], sp["crow"], self.dout_full)
+                    ops.attn_bwd_strided(self.cache[i], self.attn_buf[i], self.dout_full, self.lse_s[r["k"]][i], self.kv0, B, sp["Lmax"], cap,
+                                         H, hd, self.dqkv_full, q_row_min=sp["qmin"], kv_acc=self.dkv_acc[i],
+                                         prefix_len_i32=P["lens_dev"], first=(n_ == 0))
+                    ops.scatter_rows_bf16_(zeros_md[:sp["M"]], sp["crow"], self.dout_full)
+                    ops.gather_rows_bf16(self.dqkv_full, sp["crow"], out=dqkv[rows])
+                    ops.rope_rows_t_(dqkv[rows], m.rope_cos, m.rope_sin, sp["pos"], H, hd)
+                ops.kv_grad_inject(dqkv[:Mp], self.dkv_acc[i], P["crow"])
+                ops.rope_rows_t_(dqkv[:Mp], m.rope_cos, m.rope_sin, P["pos"], H, hd)
+                ops.gemm_bf16(ops.NN, dqkv, Wqkv, out=dn)
+                ops.gemm_bf16(ops.TN, dqkv, E["n1"][:R], out=gqkv, epilogue=ops.EPI_ACCUM)
+                ndx = ops.rmsnorm_bwd(dn, E["x"][:R], w1, E32["r1"][:R], gw1, resid_grad=dx1, out=other)
+                dx, other = ndx, dx
+                m._dp_layer_done(i, [])
+            self._embed_grad(dx[:Mp], P["ids_np"])
+            dvis = []
+            for r in recs:
+                sp = r["step"]
+                blk = dx[r["r0"]:r["r0"] + sp["M"]]
+                dvis.append(ops.vis_grad(blk, sp["vis_rows"]) if sp["vis_rows"].numel() else None)
+                self._embed_grad(blk, sp["ids_np"])
+        # each step's visual-token gradient into that step's scene-encoder / fusion graph (kept alive since the step's forward)
+        for r, g in zip(recs, dvis):
+            v = r["step"].get("vis_live")
+            if g is not None and v is not None and v.requires_grad:
+                with torch.enable_grad():
+                    torch.autograd.backward([v], [g])
+            r["step"]["vis_live"] = None
+        dp = getattr(m, "_dp", None)
+        if dp is not None and dp._exchanging():
+            dp._finalize()                         # outside autograd: no engine callback will run the end-of-backward exchange
+

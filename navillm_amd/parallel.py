@@ -314,6 +314,12 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
         self._queued = True
         torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
 
+    def on_deferred_backward_begin(self):
+        """a backward that runs OUTSIDE the autograd engine (navillm_amd/episode.py: finish_episode): same bookkeeping as
+        on_backward_begin, but no engine callback can be queued -- the caller runs `_finalize()` itself when it is done"""
+        if self.reduce == "step" and not self._final and (self._world() > 1 or self.force_sync):
+            self._pending = True
+
     def on_layer_done(self, i, events=()):
         if not self._exchanging() or not self.overlap:
             return

@@ -36,15 +36,16 @@ def _episode(model, cfg, steps, use_prefix, seed=31, B=3, instr_len=180):
     return logits, grads, (stats if use_prefix else None)
 
 
-@pytest.mark.parametrize("size,defer,fuse", [("mid", "1", "1"), ("mid", "0", "1"), ("mid", "1", "0"), ("7b-width", "1", "1")])
+@pytest.mark.parametrize("size,defer,fuse", [("mid", "all", "1"), ("mid", "wgrad", "1"), ("mid", "none", "1"), ("mid", "wgrad", "0"),
+                                             ("7b-width", "all", "1"), ("7b-width", "wgrad", "1")])
 def test_prefix_episode_matches_per_step_recompute(size, defer, fuse, monkeypatch):
     """mid: d=512, 3 layers; 7b-width: Vicuna-7B's d=4096 / 32 heads / ff=11008 with two layers (multi-tile GEMMs, split-K tails,
-    32 heads in the strided attention backward).  defer: the episode's weight gradients as ONE GEMM per weight over all token rows
-    at finish() (default) or accumulated step by step.  fuse: the prefix rows' K/V gradients accumulated in fp32 by the attention
+    32 heads in the strided attention backward).  defer: "all" (default) = the steps' whole LM backward batched into finish(),
+    "wgrad" = only the weight gradients as ONE GEMM per weight over all token rows at finish(), "none" = everything step by step.  fuse: the prefix rows' K/V gradients accumulated in fp32 by the attention
     backward itself (default) or by the separate nv_kv_grad_accum_f32 pass over the bf16 rows."""
     from navillm_amd.nav_model import NavModel
     from navillm_amd import config as nvcfg
-    monkeypatch.setenv("NAVILLM_EPISODE_DEFER_WGRAD", defer)
+    monkeypatch.setenv("NAVILLM_EPISODE_DEFER", defer)
     monkeypatch.setenv("NAVILLM_EPISODE_FUSE_KVACC", fuse)
     cfg = _mid_cfg() if size == "mid" else nvcfg.vicuna_7b(image_feat_size=768, num_layers=2, base_vocab_size=2000)
     m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
