@@ -15,10 +15,96 @@ dropping gradients, so a parameter is skipped until it receives its FIRST gradie
 `og_head` never moves (nav_model.py:78-80 vs :445), `lm_head` only once an LM-loss mode has run, `obj_projector` only once a
 batch carried objects.  Here gradients live in flat buffers and are never None, so the backward functions report what they
 accumulated into (`FlatStore.touch`), and the update runs over the runs of tensors that have been touched so far, each with
-its own step count.  Optimizer state is in this flat layout: not interchangeable with a reference checkpoint's
-`optimizer` entry (model weights are: `NavModel.load_reference_state_dict`)."""
+its own step count.
+
+Optimizer state lives in this flat layout; `load_state_dict` also accepts the reference checkpoint's `optimizer` entry
+(`torch.optim.AdamW.state_dict()` as written by tools/optims.py:65-78 and read back at :26-29) and `reference_state_dict()`
+writes one, so a run can be resumed on either side (the conversion is `reference_optimizer_to_flat` /
+`flat_to_reference_optimizer` below; pinned by tests/golden/g13_optimizer_bf16.npz)."""
 import torch
 from . import ops
+from .params import param_specs
+
+
+def reference_param_orders(cfg):
+    """Candidate orders of `[n for n, p in model.named_parameters() if p.requires_grad]` (tools/optims.py:43), which is what
+    the integer keys of the reference's optimizer state index.  Module registration order (nav_model.py:33-91,
+    image_embedding.py:11-49) = params.param_specs; inside the Llama MLP it depends on the transformers release the checkpoint
+    was written under: the pinned 4.28 registers gate, down, up (its published modeling_llama.py), current releases gate, up,
+    down (the order tests/golden/make_golden.py::gen_optimizer_state records from the installed one).  The shapes tell the two
+    apart ([ff, d] vs [d, ff]), which is how `reference_optimizer_to_flat` picks."""
+    new = [n for n, _, _ in param_specs(cfg)]
+    old = list(new)
+    for i, n in enumerate(new):
+        if n.endswith("mlp.up_proj.weight") and new[i + 1].endswith("mlp.down_proj.weight"):
+            old[i], old[i + 1] = new[i + 1], new[i]
+    return [new, old]
+
+
+def names_from_model_state_dict(keys, cfg):
+    """the parameter order of the model a checkpoint was written from, read off its `model_state_dict` keys (state_dict() and
+    named_parameters() walk the module tree in the same order; buffers and the DDP `module.` prefix dropped)"""
+    known = {n for n, _, _ in param_specs(cfg)}
+    out = [k[7:] if k.startswith("module.") else k for k in keys]
+    return [k for k in out if k in known]
+
+
+def _step_number(v):
+    return int(v.item()) if torch.is_tensor(v) else int(v)
+
+
+def reference_optimizer_to_flat(store, sd, names=None):
+    """`torch.optim.AdamW.state_dict()` of the reference -> (exp_avg/exp_avg_sq written into store's flat buffers,
+    step_count, born, hyper-parameters).  Parameters without an entry in `sd["state"]` never had a gradient
+    (optimizer.step skips `p.grad is None`) and stay untouched here."""
+    shapes = store.shape_of
+    if len(sd["param_groups"]) != 1:
+        raise ValueError(f"reference optimizer state with {len(sd['param_groups'])} param groups: the reference builds ONE (tools/optims.py:43)")
+    idx = sd["param_groups"][0]["params"]
+    cands = [list(names)] if names is not None else reference_param_orders(store.cfg)
+    order = None
+    for c in cands:
+        if len(c) == len(idx) and all(tuple(sd["state"][k]["exp_avg"].shape) == tuple(shapes[c[j]])
+                                      for j, k in enumerate(idx) if k in sd["state"]):
+            order = c
+            break
+    if order is None:
+        raise ValueError(f"reference optimizer state: {len(idx)} parameters whose shapes fit none of the known parameter orders "
+                         f"({[len(c) for c in cands]} names); pass names=names_from_model_state_dict(ckpt['model_state_dict'], cfg)")
+    store.init_optimizer_state()
+    steps = {}
+    for j, k in enumerate(idx):
+        st = sd["state"].get(k)
+        if st is None:
+            continue
+        n = order[j]
+        steps[n] = _step_number(st["step"])
+        for buf, key in ((store.exp_avg, "exp_avg"), (store.exp_avg_sq, "exp_avg_sq")):
+            v = store._view(buf, n)
+            v.copy_(st[key].to(device=v.device, dtype=v.dtype))
+    step_count = max(steps.values(), default=0)
+    born = {n: step_count - s for n, s in steps.items()}
+    g = sd["param_groups"][0]
+    if g.get("amsgrad", False) or g.get("maximize", False):
+        raise ValueError("reference optimizer state with amsgrad/maximize: the reference never sets them (tools/optims.py:43)")
+    hyper = {k: g[k] for k in ("lr", "betas", "eps", "weight_decay", "initial_lr") if k in g}
+    return step_count, born, hyper
+
+
+def flat_to_reference_optimizer(store, step_count, born, group, names=None):
+    """the inverse: a `torch.optim.AdamW.state_dict()` the reference's `optimizer.load_state_dict` (tools/optims.py:29) accepts"""
+    order = list(names) if names is not None else reference_param_orders(store.cfg)[0]
+    state = {}
+    for j, n in enumerate(order):
+        if n not in born:
+            continue
+        state[j] = {"step": torch.tensor(float(step_count - born[n])),
+                    "exp_avg": store._view(store.exp_avg, n).detach().clone().cpu(),
+                    "exp_avg_sq": store._view(store.exp_avg_sq, n).detach().clone().cpu()}
+    g = {k: v for k, v in group.items() if k != "params"}
+    g.setdefault("amsgrad", False)
+    g["params"] = list(range(len(order)))
+    return {"state": state, "param_groups": [g]}
 
 
 def active_segments(store, born):
@@ -105,10 +191,21 @@ class FlatAdamW(torch.optim.Optimizer):
                 "exp_avg_sq": {g: t.clone() for g, t in self.store.exp_avg_sq.items()},
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
-    def load_state_dict(self, sd):
+    def reference_state_dict(self, names=None):
+        """this optimizer's state as the reference's `optimizer.state_dict()` (per-parameter, indexed in `names` order; default
+        the installed transformers' `named_parameters()` order)"""
+        return flat_to_reference_optimizer(self.store, self.step_count, self.born, self.param_groups[0], names)
+
+    def load_state_dict(self, sd, names=None):
+        if "state" in sd and "param_groups" in sd and "exp_avg" not in sd:
+            # a reference checkpoint's `optimizer` entry (tools/optims.py:26-29 calls exactly this method with it)
+            self.step_count, self.born, hyper = reference_optimizer_to_flat(self.store, sd, names)
+            self.store.touched.update(self.born)
+            self._segs_key = None
+            self.param_groups[0].update(hyper)
+            return
         if "exp_avg" not in sd or not isinstance(sd["exp_avg"], dict) or "lm" not in sd["exp_avg"]:
-            raise ValueError("FlatAdamW.load_state_dict: not a FlatAdamW state (a reference checkpoint's torch.optim.AdamW "
-                             "state is per-parameter and is not interchangeable with the flat layout)")
+            raise ValueError("FlatAdamW.load_state_dict: neither a FlatAdamW state nor a torch.optim.AdamW state_dict")
         self.step_count = sd["step"]
         self.born = dict(sd.get("born", {}))
         self.store.touched.update(self.born)

@@ -26,6 +26,8 @@ Outputs (all small, committed):
                        step, the chosen slot's fuse_embeds appended to the history (mp3d_agent.py:683-778), gradients
                        ACCUMULATED over the steps (train.py:86-89 steps the optimizer only afterwards): per-step logits,
                        losses, history rows and the accumulated parameter gradients
+    g13_optimizer_bf16.npz  (round 3) the `optimizer` entry of a reference checkpoint (torch.optim.AdamW.state_dict(), tools/optims.py:73)
+                       after two optimizer steps (navigation, then object grounding) + the named_parameters() order its keys index
 
 Three shims, all outside the reference tree (the third -- fp32 RoPE
 frequencies, see build_reference -- undoes a transformers 4.28 -> 5.15 drift): the bert-large-uncased
@@ -669,6 +671,69 @@ def gen_episode(prec, seed=11, T_steps=3):
     save(f"g12_episode_{tag}.npz", **arrs, meta=np.array(json.dumps(meta)))
 
 
+def gen_optimizer_state(seed=11):
+    """G13: the `optimizer` entry of a reference checkpoint (tools/optims.py:65-78) after two optimizer steps of the training loop
+    (train.py:86-89: clip_grad_norm_(40) + AdamW.step + zero_grad) on the tiny amp_bf16 model: step 1 after a navigation
+    backward, step 2 after an object-grounding backward, so `obj_pos_embeddings` / `obj_projector` enter the state one step late
+    and `og_head` / `lm_head` never do (no gradient: optimizer.step skips them).  The optimizer is built as tools/optims.py:43
+    builds it.  zero_grad(set_to_none=False) = the pinned torch 1.10's zero_grad."""
+    from tasks.agents.r2r import R2RAgent
+    from tasks.agents.reverie import REVERIEAgent
+    cfg = nvcfg.tiny(precision="amp_bf16")
+    print("[bf16] G13 optimizer state")
+    model = build_reference(cfg, seed)
+    lm = model.lang_model
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert names == [n for n, _, _ in param_specs(cfg)], "params.param_specs is not in named_parameters() order"
+    opt = torch.optim.AdamW([p for n, p in model.named_parameters() if p.requires_grad], lr=3e-5)
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-100, reduction="sum")
+    g = torch.Generator().manual_seed(4242)
+    B, N = 3, 8
+    # optimizer step 1: one navigation step
+    pin, cand_k = pano_inputs(cfg, g, B, N)
+    pano = model("panorama", dict(pin))
+    nin = nav_inputs(cfg, g, pano["pano_embeds"], pano["pano_masks"], cand_k, [0] * B)
+    nin["hist_vis"] = [[] for _ in range(B)]
+    nin["history"] = [[] for _ in range(B)]
+    cand_nums = (nin["gmap_masks"] & ~nin["gmap_visited_masks"]).sum(-1)
+    nin["prompts"] = [R2RAgent.get_navigation_prompt(None, INSTR[b], 0, int(cand_nums[b]), lm.cls_token[0]) for b in range(B)]
+    nin["instruction"] = INSTR
+    torch.manual_seed(6000)
+    nout = model("navigation", nin)
+    (crit(nout["fuse_logits"], torch.tensor(G12_TARGETS[0])) * 0.8 / B).backward()
+    n1 = torch.nn.utils.clip_grad_norm_(model.parameters(), 40.)
+    opt.step()
+    opt.zero_grad(set_to_none=False)
+    # optimizer step 2: one object-grounding step (mp3d_agent.py:788-842)
+    pin_o, _ = pano_inputs(cfg, g, B, N, with_obj=True)
+    po = model("panorama", dict(pin_o))
+    ocn = po["obj_masks"].sum(1) + 1
+    ob = dict(obj_embeds=po["obj_embeds"], obj_masks=po["obj_masks"], obj_loc_fts=po["obj_loc_fts"],
+              hist_vis=[[] for _ in range(B)], history=[[] for _ in range(B)], instruction=INSTR, data_type=["reverie"] * B,
+              prompts=[REVERIEAgent.get_object_grounding_prompt(None, INSTR[b], 0, int(ocn[b]), lm.cls_token[0]) for b in range(B)])
+    oo = model("object_grounding", ob)
+    (crit(oo["obj_logits"], torch.tensor([2, -100, 1])) * 0.5 / B).backward()
+    n2 = torch.nn.utils.clip_grad_norm_(model.parameters(), 40.)
+    opt.step()
+    sd = opt.state_dict()
+    arrs = {}
+    steps = {}
+    for k, st in sd["state"].items():
+        steps[str(k)] = float(st["step"])
+        for key in ("exp_avg", "exp_avg_sq"):
+            # the moments are payload here (G8 pins the arithmetic): big matrices keep their [::3, ::5] sub-block only
+            t = st[key]
+            if t.numel() > 20000:
+                arrs[f"{key}_sub/{k}"] = t[::3, ::5]
+            else:
+                arrs[f"{key}/{k}"] = t
+    grp = {k: (list(v) if isinstance(v, tuple) else v) for k, v in sd["param_groups"][0].items()}
+    meta = dict(names=names, steps=steps, param_group=grp, grad_norms=[float(n1), float(n2)],
+                shapes={str(k): list(st["exp_avg"].shape) for k, st in sd["state"].items()},
+                moment_dtypes={str(k): str(st["exp_avg"].dtype) for k, st in sd["state"].items()})
+    save("g13_optimizer_bf16.npz", **arrs, meta=np.array(json.dumps(meta)))
+
+
 def pad(ts):
     m = max(t.shape[0] for t in ts)
     return torch.stack([torch.cat([t, torch.zeros(m - t.shape[0], *t.shape[1:])], 0) for t in ts], 0)
@@ -803,6 +868,9 @@ def main():
         for prec in ("fp32", "amp_bf16"):
             gen_episode(prec)
         return
+    if "--only-optimizer" in sys.argv:           # add G13 without touching the other fixtures
+        gen_optimizer_state()
+        return
     if "--only-generation" in sys.argv:          # add G9 without touching the other fixtures
         for prec in ("fp32", "amp_bf16"):
             c = nvcfg.tiny(precision=prec)
@@ -821,6 +889,7 @@ def main():
     gen_adamw()
     for prec in ("fp32", "amp_bf16"):
         gen_episode(prec)
+    gen_optimizer_state()
 
 
 if __name__ == "__main__":

@@ -202,8 +202,96 @@ def test_flat_adamw_is_a_torch_optimizer_and_tracks_first_gradients():
     opt2 = FlatAdamW(_ParamModel(cfg), lr=1.0)
     opt2.load_state_dict(sd)
     assert opt2.step_count == 9 and opt2.born == born and abs(opt2.lr - 3e-5) < 1e-12
-    with pytest.raises(ValueError, match="not interchangeable"):
+    with pytest.raises(ValueError, match="neither a FlatAdamW state nor"):
+        opt2.load_state_dict({"step": 3})
+    with pytest.raises(ValueError, match="ONE"):
         opt2.load_state_dict({"state": {}, "param_groups": []})
+
+
+def _g13_reference_optimizer_state():
+    """the `optimizer` entry of a reference checkpoint as torch.load would return it (tests/golden/make_golden.py::gen_optimizer_state;
+    the big matrices' moments are zero outside the stored [::3, ::5] sub-block)"""
+    z = gold("g13_optimizer_bf16.npz")
+    m = meta_of(z)
+    state = {}
+    for k, step in m["steps"].items():
+        dt = torch.bfloat16 if m["moment_dtypes"][k] == "torch.bfloat16" else torch.float32
+        ent = {"step": torch.tensor(step)}
+        for key in ("exp_avg", "exp_avg_sq"):
+            if f"{key}/{k}" in z:
+                t = torch.from_numpy(z[f"{key}/{k}"]).to(dt)
+            else:
+                t = torch.zeros(m["shapes"][k], dtype=dt)
+                t[::3, ::5] = torch.from_numpy(z[f"{key}_sub/{k}"]).to(dt)
+            ent[key] = t
+        state[int(k)] = ent
+    grp = dict(m["param_group"])
+    grp["betas"] = tuple(grp["betas"])
+    return {"state": state, "param_groups": [grp]}, m
+
+
+def test_g13_reference_optimizer_state_loads_and_round_trips():
+    """tools/optims.py:26-29,65-78: a reference checkpoint's `optimizer` entry goes through `optimizer.load_state_dict`; the flat
+    optimizer reads it (per-parameter step counts -> first-gradient origins) and writes one torch's own AdamW accepts."""
+    from navillm_amd.optim import (FlatAdamW, active_segments, reference_param_orders, names_from_model_state_dict,
+                                   reference_optimizer_to_flat)
+    sd, m = _g13_reference_optimizer_state()
+    cfg = tiny_cfg("bf16")
+    new, old = reference_param_orders(cfg)
+    assert m["names"] == new                      # the installed transformers' named_parameters() order, recorded from the reference
+    model = _ParamModel(cfg)
+    opt = FlatAdamW(model, lr=1.0)
+    opt.load_state_dict(sd)                       # exactly what tools/optims.py:29 calls
+    st = model.store
+    assert opt.step_count == 2 and abs(opt.lr - 3e-5) < 1e-15 and opt.param_groups[0]["weight_decay"] == 0.01
+    late = {n for n in new if n.startswith(("obj_pos_embeddings.", "img_embeddings.obj_projector."))}
+    never = {"lang_model.lm_head.weight", "og_head.0.weight", "og_head.0.bias"}
+    assert set(opt.born) == set(new) - never and late and all(opt.born[n] == (1 if n in late else 0) for n in opt.born)
+    assert st.touched >= set(opt.born)
+    for k, ent in sd["state"].items():
+        n = new[k]
+        for key, buf in (("exp_avg", st.exp_avg), ("exp_avg_sq", st.exp_avg_sq)):
+            v = st._view(buf, n)
+            assert v.dtype == ent[key].dtype and torch.equal(v, ent[key]), (n, key)
+    for n in never:
+        assert not st._view(st.exp_avg, n).any()
+    segs = active_segments(st, opt.born)
+    o = st.offsets["obj_pos_embeddings.0.weight"]
+    assert any(s <= o < e and b == 1 for s, e, b in segs["f32"])
+    # ... and back: same keys, steps, tensors; torch.optim.AdamW itself loads it
+    out = opt.reference_state_dict()
+    assert sorted(out["state"]) == sorted(sd["state"]) and out["param_groups"][0]["params"] == list(range(len(new)))
+    for k, ent in sd["state"].items():
+        assert float(out["state"][k]["step"]) == float(ent["step"])
+        assert torch.equal(out["state"][k]["exp_avg"], ent["exp_avg"]) and torch.equal(out["state"][k]["exp_avg_sq"], ent["exp_avg_sq"])
+    ps = [torch.nn.Parameter(torch.zeros(st.shape_of[n], dtype=st._view(st.param, n).dtype)) for n in new]
+    ref_opt = torch.optim.AdamW(ps, lr=1.0)
+    ref_opt.load_state_dict(out)
+    assert ref_opt.param_groups[0]["lr"] == 3e-5 and len(ref_opt.state) == len(sd["state"])
+    assert torch.equal(ref_opt.state[ps[1]]["exp_avg"], sd["state"][1]["exp_avg"])
+    # a checkpoint written under the pinned transformers 4.28 indexes the MLP as gate, down, up: found by shape
+    pos = {n: i for i, n in enumerate(new)}
+    sd_old = {"state": {j: sd["state"][pos[n]] for j, n in enumerate(old) if pos[n] in sd["state"]}, "param_groups": sd["param_groups"]}
+    assert old != new and sd_old["state"][6]["exp_avg"].shape != sd["state"][6]["exp_avg"].shape
+    model2 = _ParamModel(cfg)
+    model2.store.init_optimizer_state()
+    step2, born2, _ = reference_optimizer_to_flat(model2.store, sd_old)
+    assert step2 == 2 and born2 == opt.born
+    assert torch.equal(model2.store.exp_avg["lm"], st.exp_avg["lm"]) and torch.equal(model2.store.exp_avg_sq["f32"], st.exp_avg_sq["f32"])
+    # or the order is read off the checkpoint's own model_state_dict (DDP prefix and buffers dropped)
+    keys = ["module." + n for n in old[:3]] + ["module.lang_model.model.layers.0.self_attn.rotary_emb.inv_freq"] + ["module." + n for n in old[3:]]
+    assert names_from_model_state_dict(keys, cfg) == old
+    step3, born3, _ = reference_optimizer_to_flat(_opt_store(cfg), sd_old, names=old)
+    assert born3 == born2
+    with pytest.raises(ValueError, match="fit none"):
+        reference_optimizer_to_flat(_opt_store(cfg), sd_old, names=new)
+
+
+def _opt_store(cfg):
+    from navillm_amd.flat import FlatStore
+    st = FlatStore(cfg, "cpu")
+    st.init_optimizer_state()
+    return st
 
 
 def test_hf_checkpoint_reader_and_reference_scratch_init(tmp_path):

@@ -469,7 +469,10 @@ def test_clip_and_adamw_vs_reference_fixture_g8():
                 print(f"[g8 step {s_ + 1} tensor {i}] bf16 params: {frac:.2%} of the elements differ from torch's, by at most {worst:.2f} spacings")
                 assert bool((d <= torch.maximum(2.0 * spacing, torch.full_like(d, 2e-2 * 1e-3))).all()) and frac < 0.10, (s_, i, frac, worst)   # measured 1.2 % / 3.2 % / <10 % after steps 1 / 2 / 3: the moments carry the flips forward
             else:
-                assert torch.allclose(got, ref, rtol=1e-5, atol=2e-6), (s_, i, (got - ref).abs().max().item())
+                # the clip coefficient differs from torch's by up to 0.5 % (asserted above: torch rounds each tensor's norm to
+                # bf16 first), which moves an update of size lr by up to lr * 0.5 % = 5e-6 once a clipped and an unclipped
+                # step are mixed in the moments (measured 2.2e-6 after step 2)
+                assert torch.allclose(got, ref, rtol=1e-5, atol=5e-6), (s_, i, (got - ref).abs().max().item())
 
 
 # ------------------------------------------------------------------------------ fp32 encoder kernels
