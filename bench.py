@@ -157,9 +157,10 @@ def gemm_traffic_from_profile():
 MODE_WHAT = {
     "prefix_reuse": "per 6-step episode the prompt's static prefix (task sentence + instruction + history header, ~530 of ~650 tokens) goes "
                     "through the LM forward ONCE (K/V cached per layer); every nav step pushes only its suffix rows (history, candidates, "
-                    "hints, <cls_1>) forward and backward over the cache; one deferred backward through the prefix with the summed K/V "
-                    "gradients and ONE weight-gradient GEMM per weight over all of the episode's token rows close the episode "
-                    "(navillm_amd/episode.py).  Same losses and gradients as the per-step recompute up to bf16 rounding order -- the weights "
+                    "hints, <cls_1>) forward over the cache and its backward() records the gradient of its B output rows; finish_episode() then "
+                    "walks the layers ONCE for every token row of the episode (prefix + all steps' rows: dgrad and ONE weight-gradient GEMM "
+                    "per weight over ~8 300 rows, the attention backward per step over the cache, each step's visual-token gradient sent "
+                    "into that step's scene-encoder graph) (navillm_amd/episode.py).  Same losses and gradients as the per-step recompute up to bf16 rounding order -- the weights "
                     "are frozen inside an episode (train.py:86-89) -- pinned to the reference's own 3-step episode by fixture G12 "
                     "(tests/test_parity_gpu.py::test_g12_episode_accumulated_gradients_vs_reference[prefix_reuse])",
     "recompute": "the whole ~650-token prompt goes through the LM forward and backward at every nav step, as the reference's rollout "
