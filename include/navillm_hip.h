@@ -158,6 +158,16 @@ int nv_attn_bwd_strided_bf16(const void* qkv, const void* out, const void* dout,
 int nv_attn_bwd_strided_kvacc_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* kv_start, void* dqkv,
                                    void* workspace, float* kv_acc, const int* prefix_len, int first, int B, int S, int S_stride, int H,
                                    int head_dim, int q_row_min, void* stream);
+/*   attention backward of ALL T steps of a prefix-reuse episode for one layer, in place on the episode's row buffers
+ *   (navillm_amd/episode.py, mode "all"; the reference runs one full-prompt backward per step, mp3d_agent.py:756): rows [0, Mp) =
+ *   the packed prompt prefixes (cu [B+1]), then T step blocks described by tab (device int32: r0[T] | N[T] | n[T*B]: step t, sample
+ *   b = rows r0[t] + b*N[t] + j, j < n[t*B+b] live, the rest padding); lse_ptrs = T device pointers to the steps' lse2 [B, H, cap]
+ *   (indexed by cache position prefix_len + j).  Writes dqkv rows [Mp, R) (dQ and the steps' own dK|dV, through RoPE^T when the
+ *   tables are given, position = prefix_len + j; padding rows: zeros) and STORES the fp32 sum over the steps of the prefix rows'
+ *   dK|dV in kv_acc [B*cap, 2*H*head_dim] (row b*cap + key).  workspace: (R - Mp) * H floats */
+int nv_attn_bwd_episode_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, void* workspace, const void* lse_ptrs,
+                             const int* cu, const int* tab, float* kv_acc, const void* rope_cos, const void* rope_sin, int T, int B, int H,
+                             int head_dim, int cap, int Mp, long R, int Lp_max, int N_max, void* stream);
 int nv_attn_bwd_varlen_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* cu, const int* pos0,
                             void* dqkv, void* workspace, const void* rope_cos, const void* rope_sin, int B, int S_max, long rows,
                             int H, int head_dim, int q_row_min, void* stream);

@@ -769,6 +769,289 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         }
 }
 
+// =========================================================================== backward of a prefix-reuse EPISODE's steps (round 3)
+// navillm_amd/episode.py, mode "all": at finish_episode() one layer's q|k|v, attention outputs and output gradients of EVERY token row
+// of the episode sit in [R, .] buffers -- the prompt prefixes packed (sample b = rows [cu[b], cu[b+1])), then one block per step
+// (step t = rows r0_t + b*N_t + j, j < n_t[b] live, the rest of the N_t rows padding).  A step's queries see their sample's whole
+// prefix and the step's own earlier rows.  One launch per kernel covers all T steps: the prefix key blocks walk the query tiles of
+// every step and leave the fp32 sum of the K/V gradients in kv_acc (round 3a ran one launch per step, each re-reading and
+// re-writing 139 MB of fp32 accumulator); nothing is scattered into the K/V cache layout and back.  Padding rows get zeros.
+// descriptor whose base / span come from values LOADED in the kernel (wave-uniform, but in vector registers)
+__device__ __forceinline__ u32x4 make_desc_u(const void* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    return u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu)),
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+}
+
+struct EpiArgs {
+    const bf16_t* qkv; const bf16_t* dout; bf16_t* dqkv;
+    const float* dsum;              // [H, R - Mp]: row-sums of dO * O over the steps' rows
+    const float* const* lse;        // [T] device pointers: lse2 [B, H, cap] of each step, indexed by cache position (prefix_len + j)
+    const int* cu;                  // [B + 1]
+    const int* tab;                 // [T] r0 | [T] N | [T * B] n
+    float* kvacc;                   // fp32 [B * cap, 2 * H * HD], row b * cap + key
+    const bf16_t* rope_cos; const bf16_t* rope_sin;
+    int T, B, H, ld, cap, Mp, Rs, nPB, nSB;
+    float scale2, scale;
+};
+
+__global__ __launch_bounds__(256) void epi_bwd_dkv_kernel(EpiArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
+    constexpr int TILE = 32 * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int T = p.T, B = p.B, ld = p.ld, od = p.H * HD;
+    const int lp = p.cu[b + 1] - p.cu[b];
+    const bool pre = (int)blockIdx.y < p.nPB;          // a block of prefix keys (queries: every step) or of one step's own keys
+    int t_beg, t_end, kblk, klen;
+    long krow0;
+    if (pre) {
+        kblk = blockIdx.y * 64; t_beg = 0; t_end = T; krow0 = p.cu[b]; klen = lp;
+    } else {
+        const int y = blockIdx.y - p.nPB;
+        t_beg = y / p.nSB; t_end = t_beg + 1; kblk = (y % p.nSB) * 64;
+        klen = p.tab[T + t_beg]; krow0 = p.tab[t_beg] + (long)b * klen;
+    }
+    if (kblk >= klen) return;
+    const int ki = lane & 15, g = lane >> 4;
+    const int key = kblk + wave * 16 + ki;
+    bf16x8 kf[4], vf[4];
+    {
+        const int kl = key < klen ? key : klen - 1;
+        const bf16_t* kp = p.qkv + (krow0 + kl) * ld + p.H * HD + h * HD + g * 8;
+        const bf16_t* vp = kp + p.H * HD;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            kf[kk] = *(const bf16x8*)(kp + kk * 32);
+            vf[kk] = *(const bf16x8*)(vp + kk * 32);
+        }
+    }
+    f32x4 dv[8], dk[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) { dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    auto nvalid = [&](int t) { return p.tab[2 * T + t * B + b]; };
+    auto norm = [&](int& t, int& q) { while (t < t_end && q * 32 >= nvalid(t)) { ++t; q = 0; } };
+    auto stage = [&](int t, int q, int slot) {
+        const int N = p.tab[T + t], n = nvalid(t);
+        const long row0 = p.tab[t] + (long)b * N;
+        const u32x4 rq = make_desc_u(p.qkv + row0 * ld, (uint32_t)(((long)(n - 1) * ld + 3 * p.H * HD) * 2));
+        const u32x4 rdo = make_desc_u(p.dout + row0 * od, (uint32_t)(((long)(n - 1) * od + od) * 2));
+        stage_rows<32, 256>(rq, smem + slot * 2 * TILE, q * 32, h * HD, ld, tid);
+        stage_rows<32, 256>(rdo, smem + slot * 2 * TILE + TILE, q * 32, h * HD, od, tid);
+    };
+    int t0 = t_beg, q0 = pre ? 0 : kblk / 32;          // a step's own keys: causal, the first query tile is the one holding key kblk
+    norm(t0, q0);
+    if (t0 < t_end) {
+        int t1 = t0, q1 = q0 + 1;
+        norm(t1, q1);
+        int t2 = t1, q2 = q1 + 1;
+        if (t1 < t_end) norm(t2, q2);
+        stage(t0, q0, 0);
+        if (t1 < t_end) { stage(t1, q1, 1); wait_vmcnt<4>(); } else { wait_vmcnt<0>(); }
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        const int wkey_hi = kblk + wave * 16 + 15;
+        while (t0 < t_end) {
+            const bool more = t2 < t_end;
+            if (more) stage(t2, q2, cur >= 1 ? cur - 1 : 2);
+            LDS_PTR(char) sq = smem + cur * 2 * TILE;
+            LDS_PTR(char) sdo = sq + TILE;
+            const int N = p.tab[T + t0], n = nvalid(t0);
+            const long row0 = p.tab[t0] + (long)b * N;
+            const float* lse2 = p.lse[t0] + ((long)b * p.H + h) * p.cap + lp;
+            const float* dsum = p.dsum + (long)h * p.Rs + (row0 - p.Mp);
+            f32x4 s[2], dp[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { s[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bf16x8 qa = frag_rm(sq, j * 16, kk, lane);
+                    const bf16x8 da = frag_rm(sdo, j * 16, kk, lane);
+                    s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[kk], s[j], 0, 0, 0);
+                    dp[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[kk], dp[j], 0, 0, 0);
+                }
+            }
+            float lq[2][4], dq_[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 * 32 + j * 16 + g * 4 + r;
+                    const int qc = q < n ? q : n - 1;
+                    lq[j][r] = lse2[qc];
+                    dq_[j][r] = dsum[qc];
+                }
+            const bool interior = (q0 * 32 + 31 < n) && (pre ? wkey_hi < lp : q0 * 32 >= wkey_hi);
+            f32x4 pv[2], ds[2];
+            if (interior) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pe = fast_exp2(fmaf(s[j][r], p.scale2, -lq[j][r]));
+                        pv[j][r] = pe;
+                        ds[j][r] = pe * (dp[j][r] - dq_[j][r]);
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int q = q0 * 32 + j * 16 + g * 4 + r;
+                        const bool ok = (q < n) && (pre ? key < lp : key <= q);
+                        const float pe = ok ? fast_exp2(fmaf(s[j][r], p.scale2, -lq[j][r])) : 0.f;
+                        pv[j][r] = pe;
+                        ds[j][r] = ok ? pe * (dp[j][r] - dq_[j][r]) : 0.f;
+                    }
+            }
+            const bf16x8 pfrag = pack_frag(pv[0], pv[1]), dsfrag = pack_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const bf16x8 dot_ = frag_tr(sdo, 0, 16, dt * 16, lane);
+                const bf16x8 qt_ = frag_tr(sq, 0, 16, dt * 16, lane);
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_, pfrag, dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsfrag, dk[dt], 0, 0, 0);
+            }
+            if (more) wait_vmcnt<4>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+            t0 = t1; q0 = q1; t1 = t2; q1 = q2;
+            if (more) { ++q2; norm(t2, q2); }
+        }
+    }
+    if (key >= klen) return;
+    if (pre) {
+        float* ak = p.kvacc + ((long)b * p.cap + key) * (2L * p.H * HD) + h * HD + g * 4;
+        float* av = ak + p.H * HD;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+            *(f32x4*)(ak + dt * 16) = dk[dt] * p.scale;
+            *(f32x4*)(av + dt * 16) = dv[dt];
+        }
+        return;
+    }
+    const int pos = lp + key < p.cap ? lp + key : p.cap - 1;
+    bf16_t* kp = p.dqkv + (krow0 + key) * ld + p.H * HD + h * HD + g * 4;
+    store_grad_row(kp, dk, p.scale, p.rope_cos ? p.rope_cos + (long)pos * HD + g * 4 : nullptr,
+                   p.rope_sin ? p.rope_sin + (long)pos * HD + g * 4 : nullptr);
+    store_grad_row(kp + p.H * HD, dv, 1.f, nullptr, nullptr);
+}
+
+// grid (B*H, T * nSB): 64 queries of one step per block (wave w: 16 of them); key tiles of 64: the sample's prefix, then the step's own rows
+__global__ __launch_bounds__(256) void epi_bwd_dq_kernel(EpiArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
+    constexpr int TILE = 64 * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int T = p.T, ld = p.ld, od = p.H * HD;
+    const int t = blockIdx.y / p.nSB, q0 = (blockIdx.y % p.nSB) * 64;
+    const int N = p.tab[T + t], n = p.tab[2 * T + t * p.B + b];
+    if (q0 >= N) return;
+    const long row0 = p.tab[t] + (long)b * N;
+    const int lp = p.cu[b + 1] - p.cu[b];
+    const int qi = lane & 15, g = lane >> 4;
+    const int q = q0 + wave * 16 + qi;
+    f32x4 dq[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q0 < n) {
+        const u32x4 rpre = make_desc_u(p.qkv + (long)p.cu[b] * ld, (uint32_t)(((long)(lp - 1) * ld + 3 * p.H * HD) * 2));
+        const u32x4 rstep = make_desc_u(p.qkv + row0 * ld, (uint32_t)(((long)(n - 1) * ld + 3 * p.H * HD) * 2));
+        const int kcol = p.H * HD + h * HD, vcol = 2 * p.H * HD + h * HD;
+        const int ql = q < n ? q : n - 1;
+        bf16x8 qf[4], dof[4];
+        {
+            const bf16_t* qp = p.qkv + (row0 + ql) * ld + h * HD + g * 8;
+            const bf16_t* dp_ = p.dout + (row0 + ql) * od + h * HD + g * 8;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                qf[kk] = *(const bf16x8*)(qp + kk * 32);
+                dof[kk] = *(const bf16x8*)(dp_ + kk * 32);
+            }
+        }
+        const float my_lse = p.lse[t][((long)b * p.H + h) * p.cap + lp + ql];
+        const float my_ds = p.dsum[(long)h * p.Rs + (row0 - p.Mp) + ql];
+        const int q_hi = q0 + 63 < n - 1 ? q0 + 63 : n - 1;
+        const int npt = (lp + 63) / 64, total = npt + q_hi / 64 + 1;
+        auto stage = [&](int i, int buf) {
+            if (i < npt) {
+                stage_rows<64, 256>(rpre, smem + buf * 2 * TILE, i * 64, kcol, ld, tid);
+                stage_rows<64, 256>(rpre, smem + buf * 2 * TILE + TILE, i * 64, vcol, ld, tid);
+            } else {
+                stage_rows<64, 256>(rstep, smem + buf * 2 * TILE, (i - npt) * 64, kcol, ld, tid);
+                stage_rows<64, 256>(rstep, smem + buf * 2 * TILE + TILE, (i - npt) * 64, vcol, ld, tid);
+            }
+        };
+        stage(0, 0);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        const int wq_lo = q0 + wave * 16, wq_hi = wq_lo + 15;
+        for (int i = 0; i < total; ++i) {
+            if (i + 1 < total) stage(i + 1, cur ^ 1);
+            LDS_PTR(char) sk = smem + cur * 2 * TILE;
+            LDS_PTR(char) sv = sk + TILE;
+            const bool is_pre = i < npt;
+            const int kt = is_pre ? i : i - npt;
+            f32x4 s[4], dp[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { s[a] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[a] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const bf16x8 ka = frag_rm(sk, a * 16, kk, lane);
+                    const bf16x8 va = frag_rm(sv, a * 16, kk, lane);
+                    s[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[kk], s[a], 0, 0, 0);
+                    dp[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[kk], dp[a], 0, 0, 0);
+                }
+            }
+            const bool interior = (wq_hi < n) && (is_pre ? kt * 64 + 63 < lp : kt * 64 + 63 <= wq_lo);
+            if (interior) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pe = fast_exp2(fmaf(s[a][r], p.scale2, -my_lse));
+                        s[a][r] = pe * (dp[a][r] - my_ds);
+                    }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 64 + a * 16 + g * 4 + r;
+                        const bool ok = (q < n) && (is_pre ? key < lp : key <= q);
+                        const float pe = ok ? fast_exp2(fmaf(s[a][r], p.scale2, -my_lse)) : 0.f;
+                        s[a][r] = ok ? pe * (dp[a][r] - my_ds) : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const bf16x8 dsf = pack_frag(s[2 * a], s[2 * a + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 8; ++dt) {
+                    const bf16x8 kt_ = frag_tr(sk, a * 32, a * 32 + 16, dt * 16, lane);
+                    dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsf, dq[dt], 0, 0, 0);
+                }
+            }
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+    }
+    if (q >= N) return;
+    const int pos = lp + q < p.cap ? lp + q : p.cap - 1;
+    bf16_t* qp = p.dqkv + (row0 + q) * ld + h * HD + g * 4;
+    store_grad_row(qp, dq, p.scale, p.rope_cos ? p.rope_cos + (long)pos * HD + g * 4 : nullptr,
+                   p.rope_sin ? p.rope_sin + (long)pos * HD + g * 4 : nullptr);
+}
+
 int set_lds(const void* fn, int bytes) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? NV_OK : NV_ERR_LAUNCH;
 }
@@ -972,5 +1255,42 @@ int nv_attn_bwd_varlen_bf16(const void* qkv, const void* out, const void* dout, 
     return attn_bwd_impl(qkv, out, dout, lse2, pos0, dqkv, workspace, B, S_max, H, head_dim, q_row_min, rope_cos, rope_sin, stream, cu,
                          rows);
 }
+
+// Attention backward of ALL the steps of a prefix-reuse episode for one layer, in place on the episode's row buffers (see EpiArgs):
+// qkv / dqkv [R, 3*H*head_dim], out / dout [R, H*head_dim]; rows [0, Mp) are the packed prompt prefixes (cu [B+1]), then the T step
+// blocks described by tab (device int32: r0[T] | N[T] | n[T*B]); lse_ptrs = T device pointers to the steps' lse2 [B, H, cap].
+// Writes dqkv rows [Mp, R) (dQ and the steps' own dK|dV, through RoPE^T when the tables are given: position = prefix_len + j;
+// padding rows: zeros) and STORES the fp32 sum over the steps of the prefix rows' dK|dV in kv_acc [B*cap, 2*H*head_dim] (row b*cap + key).
+// workspace: (R - Mp) * H floats.  Lp_max / N_max: the longest prefix / the largest N.
+int nv_attn_bwd_episode_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, void* workspace, const void* lse_ptrs,
+                             const int* cu, const int* tab, float* kv_acc, const void* rope_cos, const void* rope_sin, int T, int B, int H,
+                             int head_dim, int cap, int Mp, long R, int Lp_max, int N_max, void* stream) {
+    if (!qkv || !out || !dout || !dqkv || !workspace || !lse_ptrs || !cu || !tab || !kv_acc) return NV_ERR_ARG;
+    if ((rope_cos == nullptr) != (rope_sin == nullptr)) return NV_ERR_ARG;
+    if (head_dim != HD || T < 0 || B <= 0 || H <= 0 || cap <= 0 || Mp < 0 || R < Mp || Lp_max <= 0 || Lp_max > cap || N_max < 0) return NV_ERR_SHAPE;
+    if (T == 0 || R == Mp || N_max == 0) return NV_OK;
+    static bool once = false;
+    if (!once) {
+        if (set_lds((const void*)epi_bwd_dkv_kernel, 49152) || set_lds((const void*)epi_bwd_dq_kernel, 65536)) return NV_ERR_LAUNCH;
+        once = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int od = H * HD;
+    const long Rs = R - Mp;
+    float* dsum = (float*)workspace;
+    NV_LAUNCH(attn_bwd_prep_kernel, dim3((unsigned)((Rs * H + 15) / 16)), dim3(256), 0, st, (const bf16_t*)dout + (long)Mp * od,
+              (const bf16_t*)out + (long)Mp * od, dsum, (const int*)nullptr, Rs, 1, (int)Rs, H, 0, (int)Rs);
+    EpiArgs p{};
+    p.qkv = (const bf16_t*)qkv; p.dout = (const bf16_t*)dout; p.dqkv = (bf16_t*)dqkv; p.dsum = dsum;
+    p.lse = (const float* const*)lse_ptrs; p.cu = cu; p.tab = tab; p.kvacc = kv_acc;
+    p.rope_cos = (const bf16_t*)rope_cos; p.rope_sin = (const bf16_t*)rope_sin;
+    p.T = T; p.B = B; p.H = H; p.ld = 3 * H * HD; p.cap = cap; p.Mp = Mp; p.Rs = (int)Rs;
+    p.nPB = (Lp_max + 63) / 64; p.nSB = (N_max + 63) / 64;
+    p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
+    NV_LAUNCH(epi_bwd_dkv_kernel, dim3(B * H, p.nPB + T * p.nSB), dim3(256), 49152, st, p);
+    NV_LAUNCH(epi_bwd_dq_kernel, dim3(B * H, T * p.nSB), dim3(256), 65536, st, p);
+    return nv_check_launch();
+}
+
 
 }  // extern "C"

@@ -303,7 +303,9 @@ class PrefixEpisode:
         M, Lmax, qmin = step["M"], step["Lmax"], step["qmin"]
         k = self.prefix["steps"]
         defer = self.defer_wgrad and self.prefix["defer"]
-        allm = defer and bool(step.get("batched"))
+        if self.mode == "all" and not step.get("batched"):
+            defer = False                  # a step outside autograd (validation inside an episode): scratch only, the episode buffers hold
+        allm = defer and bool(step.get("batched"))                                        # exactly the rows finish() will walk
         r0 = self._cursor
         if defer:
             self._ensure_rows(r0 + M)
@@ -525,35 +527,46 @@ class PrefixEpisode:
             zeros_md = self._buf("zeros_md", (Mz, d))
             zeros_md.zero_()
             Lp_max = P["Lmax"]
+            self._lens_dev = P["lens_dev"]
+            epi_tab = lse_tab = None
+            if os.environ.get("NAVILLM_EPISODE_ATTN_BWD", "episode") != "steps":
+                # where every step's block sits (r0 | rows per sample | live rows of each sample) and, per layer, where its lse is
+                T = len(recs)
+                tab = np.concatenate([np.array([r["r0"] for r in recs], np.int32), np.array([r["step"]["N"] for r in recs], np.int32),
+                                      np.array([r["step"]["n"] for r in recs], np.int32).reshape(-1)])
+                ptrs = np.array([[self.lse_s[r["k"]][i].data_ptr() for r in recs] for i in range(L)], dtype=np.int64)
+                epi_tab = ops.h2d(torch.from_numpy(tab), m.device)
+                lse_tab = ops.h2d(torch.from_numpy(ptrs), m.device)
+                assert recs[0]["r0"] == Mp and all(a["r0"] + a["step"]["M"] == b_["r0"] for a, b_ in zip(recs, recs[1:])) and \
+                    recs[-1]["r0"] + recs[-1]["step"]["M"] == R, "the steps' blocks must tile rows [Mp, R) of the episode buffers"
             for i in reversed(range(L)):
                 Wqkv, Wo, Wgu, Wd, w1, w2, gqkv, go, ggu, gd, gw1, gw2 = self._weights(i)
                 E, E32 = self._E[i], self._E32[i]
-                ops.gemm_bf16(ops.NN, dx, Wd, out=dh)
-                ops.gemm_bf16(ops.TN, dx, E["h"][:R], out=gd, epilogue=ops.EPI_ACCUM)
-                ops.swiglu_bwd(E["gu"][:R], dh, out=dgu)
-                ops.gemm_bf16(ops.NN, dgu, Wgu, out=dn)
-                ops.gemm_bf16(ops.TN, dgu, E["n2"][:R], out=ggu, epilogue=ops.EPI_ACCUM)
-                ops.rmsnorm_bwd(dn, E["x1"][:R], w2, E32["r2"][:R], gw2, resid_grad=dx, out=dx1)
-                ops.gemm_bf16(ops.NN, dx1, Wo, out=dattn)
-                ops.gemm_bf16(ops.TN, dx1, E["attn"][:R], out=go, epilogue=ops.EPI_ACCUM)
+                # the top layer's prefix rows feed nothing (only their K/V carry gradient): its MLP / o_proj backward covers the steps' rows only
+                lo = Mp if i == L - 1 else 0
+                ops.gemm_bf16(ops.NN, dx[lo:], Wd, out=dh[lo:])
+                ops.gemm_bf16(ops.TN, dx[lo:], E["h"][lo:R], out=gd, epilogue=ops.EPI_ACCUM)
+                ops.swiglu_bwd(E["gu"][lo:R], dh[lo:], out=dgu[lo:])
+                ops.gemm_bf16(ops.NN, dgu[lo:], Wgu, out=dn[lo:])
+                ops.gemm_bf16(ops.TN, dgu[lo:], E["n2"][lo:R], out=ggu, epilogue=ops.EPI_ACCUM)
+                ops.rmsnorm_bwd(dn[lo:], E["x1"][lo:R], w2, E32["r2"][lo:R], gw2, resid_grad=dx[lo:], out=dx1[lo:])
+                ops.gemm_bf16(ops.NN, dx1[lo:], Wo, out=dattn[lo:])
+                ops.gemm_bf16(ops.TN, dx1[lo:], E["attn"][lo:R], out=go, epilogue=ops.EPI_ACCUM)
                 # attention backward.  The prefix rows' own causal attention (packed rows) ...
-                ops.attn_bwd_varlen(E["qkv"][:Mp], E["attn"][:Mp], dattn[:Mp], P["layers"][i]["lse"], P["cu"], P["pos0"], B, Lp_max, H, hd,
-                                    dqkv[:Mp], q_row_min=0, rope=None)
-                # ... and each step's rows over the K/V cache: the step's post-RoPE q|k|v and its attention outputs go back to their
-                # cache rows, dO to the step's rows (zero elsewhere); the gradients the step sends into the cached prefix rows are
-                # summed in fp32 by the kernel itself (first step: stored)
-                for n_, r in enumerate(recs):
-                    sp = r["step"]
-                    rows = slice(r["r0"], r["r0"] + sp["M"])
-                    ops.scatter_rows_bf16_(E["qkv"][rows], sp["crow"], self.cache[i])
-                    ops.scatter_rows_bf16_(E["attn"][rows], sp["crow"], self.attn_buf[i])
-                    ops.scatter_rows_bf16_(dattn[rows], sp["crow"], self.dout_full)
-                    ops.attn_bwd_strided(self.cache[i], self.attn_buf[i], self.dout_full, self.lse_s[r["k"]][i], self.kv0, B, sp["Lmax"], cap,
-                                         H, hd, self.dqkv_full, q_row_min=sp["qmin"], kv_acc=self.dkv_acc[i],
-                                         prefix_len_i32=P["lens_dev"], first=(n_ == 0))
-                    ops.scatter_rows_bf16_(zeros_md[:sp["M"]], sp["crow"], self.dout_full)
-                    ops.gather_rows_bf16(self.dqkv_full, sp["crow"], out=dqkv[rows])
-                    ops.rope_rows_t_(dqkv[rows], m.rope_cos, m.rope_sin, sp["pos"], H, hd)
+                if lo == 0:
+                    ops.attn_bwd_varlen(E["qkv"][:Mp], E["attn"][:Mp], dattn[:Mp], P["layers"][i]["lse"], P["cu"], P["pos0"], B, Lp_max, H, hd,
+                                        dqkv[:Mp], q_row_min=0, rope=None)
+                else:
+                    dqkv[:Mp].zero_()
+                    dx1[:Mp].zero_()
+                # ... and every step's rows over their sample's prefix and the step's own earlier rows
+                if epi_tab is not None:
+                    # ONE launch per kernel for all the steps, reading the episode buffers in place: the prefix key blocks walk every
+                    # step's queries and STORE the fp32 sum in dkv_acc; dQ and the steps' own dK|dV land in dqkv through RoPE^T
+                    ops.attn_bwd_episode(E["qkv"][:R], E["attn"][:R], dattn, dqkv, lse_tab[i], P["cu"], epi_tab, self.dkv_acc[i], len(recs), B, H, hd,
+                                         cap, Mp, Lp_max, Mz // B, rope=(m.rope_cos, m.rope_sin))
+                else:
+                    self._attn_bwd_by_step(i, recs, E, dattn, dqkv, zeros_md)
                 ops.kv_grad_inject(dqkv[:Mp], self.dkv_acc[i], P["crow"])
                 ops.rope_rows_t_(dqkv[:Mp], m.rope_cos, m.rope_sin, P["pos"], H, hd)
                 ops.gemm_bf16(ops.NN, dqkv, Wqkv, out=dn)
@@ -579,3 +592,21 @@ class PrefixEpisode:
         if dp is not None and dp._exchanging():
             dp._finalize()                         # outside autograd: no engine callback will run the end-of-backward exchange
 
+    def _attn_bwd_by_step(self, i, recs, E, dattn, dqkv, zeros_md):
+        """round 3a form (NAVILLM_EPISODE_ATTN_BWD=steps): one strided backward per step over the K/V cache: the step's post-RoPE q|k|v
+        and its attention outputs go back to their cache rows, dO to the step's rows (zero elsewhere); the gradients the step sends
+        into the cached prefix rows are summed in fp32 by the kernel itself (first step: stored)"""
+        m, cfg = self.m, self.m.cfg
+        B, cap, H, hd = self.B, self.cap, cfg.num_heads, cfg.head_dim
+        for n_, r in enumerate(recs):
+            sp = r["step"]
+            rows = slice(r["r0"], r["r0"] + sp["M"])
+            ops.scatter_rows_bf16_(E["qkv"][rows], sp["crow"], self.cache[i])
+            ops.scatter_rows_bf16_(E["attn"][rows], sp["crow"], self.attn_buf[i])
+            ops.scatter_rows_bf16_(dattn[rows], sp["crow"], self.dout_full)
+            ops.attn_bwd_strided(self.cache[i], self.attn_buf[i], self.dout_full, self.lse_s[r["k"]][i], self.kv0, B, sp["Lmax"], cap,
+                                 H, hd, self.dqkv_full, q_row_min=sp["qmin"], kv_acc=self.dkv_acc[i],
+                                 prefix_len_i32=self._lens_dev, first=(n_ == 0))
+            ops.scatter_rows_bf16_(zeros_md[:sp["M"]], sp["crow"], self.dout_full)
+            ops.gather_rows_bf16(self.dqkv_full, sp["crow"], out=dqkv[rows])
+            ops.rope_rows_t_(dqkv[rows], m.rope_cos, m.rope_sin, sp["pos"], H, hd)

@@ -36,8 +36,9 @@ def _episode(model, cfg, steps, use_prefix, seed=31, B=3, instr_len=180):
     return logits, grads, (stats if use_prefix else None)
 
 
-@pytest.mark.parametrize("size,defer,fuse", [("mid", "all", "1"), ("mid", "wgrad", "1"), ("mid", "none", "1"), ("mid", "wgrad", "0"),
-                                             ("7b-width", "all", "1"), ("7b-width", "wgrad", "1")])
+@pytest.mark.parametrize("size,defer,fuse", [("mid", "all", "1"), ("mid", "all-steps", "1"), ("mid", "wgrad", "1"), ("mid", "none", "1"),
+                                             ("mid", "wgrad", "0"), ("7b-width", "all", "1"), ("7b-width", "all-steps", "1"),
+                                             ("7b-width", "wgrad", "1")])
 def test_prefix_episode_matches_per_step_recompute(size, defer, fuse, monkeypatch):
     """mid: d=512, 3 layers; 7b-width: Vicuna-7B's d=4096 / 32 heads / ff=11008 with two layers (multi-tile GEMMs, split-K tails,
     32 heads in the strided attention backward).  defer: "all" (default) = the steps' whole LM backward batched into finish(),
@@ -45,6 +46,9 @@ def test_prefix_episode_matches_per_step_recompute(size, defer, fuse, monkeypatc
     backward itself (default) or by the separate nv_kv_grad_accum_f32 pass over the bf16 rows."""
     from navillm_amd.nav_model import NavModel
     from navillm_amd import config as nvcfg
+    # "all-steps": mode "all" with one strided attention backward per step (round 3a) instead of nv_attn_bwd_episode_bf16
+    monkeypatch.setenv("NAVILLM_EPISODE_ATTN_BWD", "steps" if defer == "all-steps" else "episode")
+    defer = defer.split("-")[0]
     monkeypatch.setenv("NAVILLM_EPISODE_DEFER", defer)
     monkeypatch.setenv("NAVILLM_EPISODE_FUSE_KVACC", fuse)
     cfg = _mid_cfg() if size == "mid" else nvcfg.vicuna_7b(image_feat_size=768, num_layers=2, base_vocab_size=2000)
@@ -84,6 +88,106 @@ def test_prefix_episode_matches_per_step_recompute(size, defer, fuse, monkeypatc
     rows_ref = steps * sum(180 - 23 * b + 90 for b in range(3))
     print(f"[episode] token rows through the LM: prefix {stats['prefix_rows']} once + suffixes {stats['suffix_rows']} (recompute: ~{rows_ref})")
     assert stats["prefix_rows"] + sum(stats["suffix_rows"]) < 0.6 * rows_ref
+
+
+@pytest.mark.parametrize("H,lens,ns", [(4, [70, 131, 64], [[5, 9, 1], [40, 70, 65], [17, 3, 30]]),
+                                       (2, [1, 300], [[129, 2]]),
+                                       (32, [530, 512, 541, 499, 520, 533, 507, 528], [[95, 101, 88, 110, 97, 104, 92, 99]] * 2)])
+def test_attn_bwd_episode_kernel_vs_one_strided_backward_per_step(H, lens, ns):
+    """nv_attn_bwd_episode_bf16 (all the steps of an episode in one launch per kernel, reading the episode's row buffers in place) against
+    the round-3a sequence it replaces: per step scatter into the K/V cache layout -> nv_attn_bwd_strided_kvacc_bf16 -> gather -> RoPE^T.
+    Same bf16-rounded probabilities in both; the key tiles are cut at different places, so sums differ in the last bits."""
+    from navillm_amd import ops
+    dev = torch.device(DEV)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    B, hd, cap, T = len(lens), 128, 512 if max(lens) < 400 else 1024, len(ns)
+    d = H * hd
+    BF, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+    cu = np.zeros(B + 1, np.int32); cu[1:] = np.cumsum(lens)
+    Mp = int(cu[-1])
+    Ns = [max(n) for n in ns]
+    r0s, R = [], Mp
+    for N in Ns:
+        r0s.append(R); R += B * N
+    qkv = (torch.randn(R, 3 * d, generator=g) * 0.8).to(BF).to(dev)
+    dout = torch.zeros(R, d, dtype=BF, device=dev)
+    attn = torch.zeros(R, d, dtype=BF, device=dev)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(cap).float(), inv)
+    emb = torch.cat([fr, fr], -1)
+    cos, sin = emb.cos().to(BF).to(dev).contiguous(), emb.sin().to(BF).to(dev).contiguous()
+    cache = torch.zeros(B * cap + 1, 3 * d, dtype=BF, device=dev)
+    attn_buf = torch.zeros(B * cap + 1, d, dtype=BF, device=dev)
+    dout_full = torch.zeros(B * cap + 1, d, dtype=BF, device=dev)
+    dqkv_full = torch.zeros(B * cap + 1, 3 * d, dtype=BF, device=dev)
+    kv0 = torch.zeros(B, dtype=I32, device=dev)
+    lens_dev = torch.tensor(lens, dtype=I32, device=dev)
+    pcrow = torch.tensor(np.concatenate([b * cap + np.arange(n) for b, n in enumerate(lens)]), dtype=I32, device=dev)
+    ops.scatter_rows_bf16_(qkv[:Mp], pcrow, cache)
+    lses, crows, poss = [], [], []
+    junk = B * cap
+    for t in range(T):
+        N, M = Ns[t], B * Ns[t]
+        crow = np.full(M, junk, np.int32); pos = np.zeros(M, np.int32)
+        for b in range(B):
+            ar = np.arange(lens[b], lens[b] + ns[t][b], dtype=np.int32)
+            crow[b * N:b * N + ns[t][b]] = b * cap + ar
+            pos[b * N:b * N + ns[t][b]] = ar
+        crow_d, pos_d = torch.tensor(crow, dtype=I32, device=dev), torch.tensor(pos, dtype=I32, device=dev)
+        crows.append(crow_d); poss.append(pos_d)
+        rows = slice(r0s[t], r0s[t] + M)
+        live = torch.tensor(crow != junk, device=dev)
+        dout[rows] = torch.where(live[:, None], (torch.randn(M, d, generator=g) * 0.5).to(BF).to(dev), torch.zeros((), dtype=BF, device=dev))
+        # forward of step t over the cache: its attention outputs and lse (the next step overwrites the same cache rows, as in the episode)
+        ops.scatter_rows_bf16_(qkv[rows], crow_d, cache)
+        lse = torch.zeros(B, H, cap, dtype=F32, device=dev)
+        Lmax = max(lens[b] + ns[t][b] for b in range(B))
+        qmin = (min(lens) // 128) * 128
+        ops.attn_fwd_strided(cache, kv0, B, Lmax, cap, H, hd, out=attn_buf, lse2=lse, q_row_min=qmin)
+        grow = torch.tensor(np.where(crow == junk, 0, crow), dtype=I32, device=dev)
+        ops.gather_rows_bf16(attn_buf, grow, out=attn[rows])
+        lses.append(lse)
+    # ---- reference sequence
+    acc_ref = torch.full((B * cap, 2 * d), float("nan"), dtype=F32, device=dev)
+    dqkv_ref = torch.zeros(R, 3 * d, dtype=BF, device=dev)
+    for t in range(T):
+        N, M = Ns[t], B * Ns[t]
+        rows = slice(r0s[t], r0s[t] + M)
+        Lmax = max(lens[b] + ns[t][b] for b in range(B))
+        ops.scatter_rows_bf16_(qkv[rows], crows[t], cache)
+        ops.scatter_rows_bf16_(attn[rows], crows[t], attn_buf)
+        ops.scatter_rows_bf16_(dout[rows], crows[t], dout_full)
+        ops.attn_bwd_strided(cache, attn_buf, dout_full, lses[t], kv0, B, Lmax, cap, H, hd, dqkv_full, q_row_min=(min(lens) // 128) * 128,
+                             kv_acc=acc_ref, prefix_len_i32=lens_dev, first=(t == 0))
+        ops.scatter_rows_bf16_(torch.zeros(M, d, dtype=BF, device=dev), crows[t], dout_full)
+        ops.gather_rows_bf16(dqkv_full, crows[t], out=dqkv_ref[rows])
+        ops.rope_rows_t_(dqkv_ref[rows], cos, sin, poss[t], H, hd)
+    # ---- one call
+    acc = torch.full((B * cap, 2 * d), float("nan"), dtype=F32, device=dev)
+    dqkv = torch.full((R, 3 * d), float("nan"), dtype=BF, device=dev)
+    tab = torch.tensor(np.concatenate([np.array(r0s, np.int32), np.array(Ns, np.int32), np.array(ns, np.int32).reshape(-1)]), dtype=I32, device=dev)
+    ptrs = torch.tensor([l.data_ptr() for l in lses], dtype=torch.int64, device=dev)
+    ops.attn_bwd_episode(qkv, attn, dout, dqkv, ptrs, torch.tensor(cu, dtype=I32, device=dev), tab, acc, T, B, H, hd, cap, Mp, max(lens), max(Ns),
+                         rope=(cos, sin))
+    torch.cuda.synchronize()
+    assert torch.isnan(dqkv[:Mp].float()).all()                       # the prefix rows of dqkv are not this kernel's
+    got, ref = dqkv[Mp:].float(), dqkv_ref[Mp:].float()
+    assert torch.isfinite(got).all()
+    for t in range(T):                                               # padding rows: zeros
+        N = Ns[t]
+        for b in range(B):
+            assert not got[r0s[t] - Mp + b * N + ns[t][b]: r0s[t] - Mp + (b + 1) * N].any()
+    for name, c0 in (("dq", 0), ("dk", d), ("dv", 2 * d)):
+        a, r = got[:, c0:c0 + d], ref[:, c0:c0 + d]
+        rel = ((a - r).norm() / r.norm()).item()
+        worst = ((a - r).abs().max() / r.abs().max()).item()
+        print(f"[attn_bwd_episode H={H}] {name}: rel {rel:.2e}, max |diff| / max |ref| {worst:.2e}")
+        assert rel < 4e-3 and worst < 2e-2, (name, rel, worst)
+    for b in range(B):
+        a, r = acc[b * cap:b * cap + lens[b]], acc_ref[b * cap:b * cap + lens[b]]
+        assert torch.isfinite(a).all() and torch.isnan(acc[b * cap + lens[b]:(b + 1) * cap]).all()     # only the prefix rows are written
+        rel = ((a - r).norm() / r.norm()).item()
+        assert rel < 1e-4, (b, rel)
 
 
 def test_prefix_episode_rejects_foreign_prompts_and_wrong_use():
