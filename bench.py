@@ -453,7 +453,7 @@ def fp8_13b_extra(a, device, seed):
                    "greedy decoding of 24 tokens at B=8 (prefill included; device-side loop replayed from a hipGraph); decode steps stream "
                    "the fp8 codes (gemv_stream.hip); prefill / K/V-reuse GEMMs read either the de-quantised operands kept resident "
                    "(fp8_codes_plus_resident_bf16: 38 GB of weights) or one shared bf16 scratch panel filled per GEMM (fp8_weight_only: "
-                   "12.7 GB, a 3 B/weight pre-pass)")
+                   "12.7 GB, a 3 B/weight pre-pass; overlapping it with the previous GEMM on a side stream was measured and loses 1-4 %)")
     del m
     torch.cuda.empty_cache()
     return out
@@ -604,11 +604,11 @@ def main():
     def make_step(mode):
         prefix = mode == "prefix_reuse"
 
-        def one_step(i):
-            """iteration i of the rollout loop (tasks/agents/mp3d_agent.py:660) for the rank's B episodes; every 6th one ends the
-            episodes: (prefix mode: the prefix's single backward,) clip(40) + AdamW + zero_grad (train.py:86-89)"""
+        def one_step(i, end=False):
+            """iteration i of the rollout loop (tasks/agents/mp3d_agent.py:660) for the rank's B episodes; every 6th one (or `end`)
+            ends the episodes: (prefix mode: the episode's deferred backward,) clip(40) + AdamW + zero_grad (train.py:86-89)"""
             pos = i % STEPS_PER_EPISODE
-            last = pos == STEPS_PER_EPISODE - 1
+            last = pos == STEPS_PER_EPISODE - 1 or end
             if prefix and pos == 0:
                 model.begin_episode(ep.prefix_ids())          # static prompt prefix: forward once, K/V cached per layer
             loss, logits = nav_step(wrapped, crit, ep, train=True, last=last, final=last and not prefix)
@@ -627,13 +627,15 @@ def main():
     def run_mode(mode, steps, warmup, prewarm, sync_ranks):
         """untimed setup steps, then `warmup` untimed steps, then `steps` timed ones bracketed by barrier + synchronize on both sides
         -> (seconds (max over ranks), GemmTimer, last loss).
-        Episodes are 6 steps long and end with per-episode work (prefix mode: the prefix's backward + one weight-gradient GEMM per
-        weight; both modes: clip + AdamW), so where a 20-step window falls relative to the episodes matters: it can hold 3 or 4
-        episode starts and 3 or 4 episode ends, the long-run average being 3 1/3 of each.  The TIMED REGION ALWAYS STARTS AT AN
-        EPISODE BOUNDARY: the setup phase runs `prewarm` steps plus as many more (< 6) as it takes for setup + warmup to be whole
-        episodes.  With K = 20 the window then holds 4 episode starts and 3 episode ends -- of the four possible alignments the
-        one closest to the long-run average (per-episode work counted: 0.96 of its long-run share; the alignment that follows
-        from counting steps from 0 would count 1.20 of it)."""
+        Episodes are 6 steps long; they open with per-episode work (prefix mode: the prefix forward) and END with most of it (prefix
+        mode: the backward of EVERY token row of the episode, deferred to finish_episode(); both modes: clip + AdamW).  Every timed
+        step's work must lie inside the timed region, so (1) the region always STARTS at an episode boundary -- the setup phase runs
+        `prewarm` steps plus as many more (< 6) as it takes for setup + warmup to be whole episodes -- and (2) the LAST timed step
+        always ENDS its episode: with K = 20 the window holds episodes of 6, 6, 6 and 2 steps, each complete (begin, steps, deferred
+        backward, optimizer step).  The short last episode spreads its prefix and its optimizer step over 2 steps instead of 6, so the
+        K = 20 figure is BELOW the steady-state rate of 6-step episodes (`whole_episodes` in the JSON line: 18 steps = 3 whole
+        episodes, measured right after); a window that merely stopped after 20 steps would leave the backward of the last two steps
+        outside the timed region."""
         one_step = make_step(mode)
         model.episode_abort()
         ep.reset()
@@ -654,7 +656,7 @@ def main():
         loss = None
         for i in range(base, base + steps):
             tm.active = GemmTimer.sampled(i - base, steps)
-            loss = one_step(i)
+            loss = one_step(i, end=(i == base + steps - 1))
         torch.cuda.synchronize()
         if world > 1 and sync_ranks:
             dist.barrier()
@@ -673,6 +675,18 @@ def main():
     main_stats = dict(model.episode.stats) if (a.mode == "prefix_reuse" and model.episode is not None) else None
 
     phase(f"timed region done: {dt:.2f} s")
+    # ---- the same mode over WHOLE 6-step episodes (steady state; reported aside, never `value`): the K-step window above ends with a
+    # short episode whenever K is not a multiple of 6
+    whole = None
+    if a.steps % STEPS_PER_EPISODE and (not a.no_extras or a.model != "tiny") and not a.no_other_mode:
+        try:
+            w_steps = 3 * STEPS_PER_EPISODE
+            w_dt, _, _ = run_mode(a.mode, w_steps, 0, 0, world > 1)
+            whole = {"steps": w_steps, "episodes": 3, "ms_per_step": round(w_dt / w_steps * 1e3, 2),
+                     "nav_steps_per_s": round(a.batch * world * w_steps / w_dt, 2),
+                     "what": "the headline mode over 3 whole 6-step episodes, same process and model, right after the timed region"}
+        except Exception as e:
+            whole = {"error": f"{type(e).__name__}: {e}"}
     # ---- the OTHER training mode, same process, same model (reported under `other_mode`, never `value`)
     other = None
     if (not a.no_extras or a.model != "tiny") and not a.no_other_mode:
@@ -738,16 +752,21 @@ def main():
                                    f"clip+AdamW every {STEPS_PER_EPISODE} steps)",
                        "global_batch": a.batch * world, "seq_len": seq_len_main,
                        "parallelism": f"dp{world}", "loss": float(loss.detach()) if loss is not None else None,
-                       "timed_window": "starts at an episode boundary (setup + warmup = whole 6-step episodes): %d episode starts and %d "
-                                       "episode ends (clip + AdamW%s) inside the %d timed steps" % (
-                                           (a.steps + STEPS_PER_EPISODE - 1) // STEPS_PER_EPISODE, a.steps // STEPS_PER_EPISODE,
-                                           "; prefix backward + per-weight wgrad GEMMs" if a.mode == "prefix_reuse" else "", a.steps),
+                       "timed_window": "starts at an episode boundary (setup + warmup = whole 6-step episodes) and the last timed step ends "
+                                       "its episode: %d complete episodes (%s steps) inside the %d timed steps, each with its begin, its %s"
+                                       "clip + AdamW -- no timed step's work is left outside the window%s" % (
+                                           (a.steps + STEPS_PER_EPISODE - 1) // STEPS_PER_EPISODE,
+                                           " + ".join(["6"] * (a.steps // STEPS_PER_EPISODE) + ([str(a.steps % STEPS_PER_EPISODE)] if a.steps % STEPS_PER_EPISODE else [])),
+                                           a.steps, "deferred backward (finish_episode) and " if a.mode == "prefix_reuse" else "",
+                                           "; the short last episode makes this figure conservative, see whole_episodes" if a.steps % STEPS_PER_EPISODE else ""),
                        "training_mode": a.mode,
                        "training_mode_what": MODE_WHAT[a.mode]},
         }
         if main_stats is not None:
             line["config"]["token_rows_last_episode"] = {"prefix_once": int(main_stats["prefix_rows"]),
                                                          "suffix_per_step": [int(x) for x in main_stats["suffix_rows"]]}
+        if whole is not None:
+            line["whole_episodes"] = whole
         if other is not None:
             line["other_mode"] = other
         if REHEARSAL:

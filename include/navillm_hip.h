@@ -268,6 +268,9 @@ int nv_decoder_set_weight(nv_decoder* p, int layer, int kind, const void* w, con
 int nv_decoder_set_layer(nv_decoder* p, int layer, const void* input_norm, const void* post_attn_norm, void* kv_cache);
 int nv_decoder_set_shared(nv_decoder* p, const void* rope_cos, const void* rope_sin, const void* final_norm, void* gemm_workspace,
                           void* fp8_scratch);
+/*   weight-only fp8 without resident bf16 operands: two bf16 panels (each >= the largest operand) + a side stream; nv_decoder_extend
+ *   then de-quantises the NEXT Linear's operand on the side stream while the current GEMM runs (steps of > 16 rows) */
+int nv_decoder_set_fp8_overlap(nv_decoder* p, void* panel_a, void* panel_b, void* side_stream);
 size_t nv_decoder_workspace_bytes(const nv_decoder* p, int max_rows);
 /*   x_in [M,d] new-row embeddings; pos/crow/grow [M] (position, cache row written, cache row read back); kv0 [B] zeros; attn_buf
  *   [B*cap,d]; lse [B,H,cap]; last [B] -> hs_out [B,d] final-norm hidden states of those block rows; hs_all optional [M,d] */

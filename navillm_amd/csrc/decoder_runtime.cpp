@@ -16,6 +16,8 @@
 #include <new>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "../../include/navillm_hip.h"
 
 namespace {
@@ -39,6 +41,11 @@ struct nv_decoder {
     const void *rope_cos = nullptr, *rope_sin = nullptr, *final_norm = nullptr;
     void* gemm_ws = nullptr;        // zero-filled split-K workspace of nv_gemm_bf16_ws (may be NULL)
     void* fp8_scratch = nullptr;    // bf16 panel for de-quantised operands (needed when a layer carries codes)
+    // weight-only fp8, memory-lean AND overlapped (round 3): two panels; the NEXT Linear's operand is de-quantised on a side stream
+    // while the current GEMM runs (the GEMM is MFMA-bound and leaves most of the HBM bandwidth idle; the pre-pass is pure bandwidth)
+    void* panel[2] = {nullptr, nullptr};
+    hipStream_t side = nullptr;
+    hipEvent_t ev_entry = nullptr, ev_dq[2] = {nullptr, nullptr}, ev_use[2] = {nullptr, nullptr};
 };
 
 extern "C" {
@@ -52,7 +59,30 @@ nv_decoder* nv_decoder_create(int L, int d, int H, int head_dim, int ff, float e
     return p;
 }
 
-void nv_decoder_destroy(nv_decoder* p) { delete p; }
+void nv_decoder_destroy(nv_decoder* p) {
+    if (!p) return;
+    if (p->ev_entry) (void)hipEventDestroy(p->ev_entry);
+    for (int k = 0; k < 2; ++k) {
+        if (p->ev_dq[k]) (void)hipEventDestroy(p->ev_dq[k]);
+        if (p->ev_use[k]) (void)hipEventDestroy(p->ev_use[k]);
+    }
+    delete p;
+}
+
+// weight-only fp8 without resident bf16 operands: give the decoder two bf16 panels (each as large as the largest operand) and a
+// side stream, and nv_decoder_extend de-quantises the next Linear's operand there while the current GEMM runs on the caller's
+// stream (steps of more than 16 rows; the few-row steps read the codes directly).  Everything the call enqueues is ordered
+// after the caller's earlier work on `stream` and completes in `stream` order, as without the side stream.
+int nv_decoder_set_fp8_overlap(nv_decoder* p, void* panel_a, void* panel_b, void* side_stream) {
+    if (!p || !panel_a || !panel_b || panel_a == panel_b || !side_stream) return NV_ERR_ARG;
+    if (!p->ev_entry) {
+        hipEvent_t* evs[5] = {&p->ev_entry, &p->ev_dq[0], &p->ev_dq[1], &p->ev_use[0], &p->ev_use[1]};
+        for (hipEvent_t* e : evs)
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return NV_ERR_LAUNCH;
+    }
+    p->panel[0] = panel_a; p->panel[1] = panel_b; p->side = (hipStream_t)side_stream;
+    return NV_OK;
+}
 
 // weights of layer i.  kind: 0 qkv, 1 o, 2 gate|up, 3 down.  Either `w` (bf16 [N,K]) or `codes` + `scales` (weight-only fp8).
 int nv_decoder_set_weight(nv_decoder* p, int i, int kind, const void* w, const void* codes, const float* scales) {
@@ -99,6 +129,42 @@ static int linear(const nv_decoder* p, const Layer& ly, int kind, const void* x,
     return nv_gemm_bf16_ws(0, x, ly.w[kind], out, R, M, N, K, K, K, N, N, epi, 0, p->gemm_ws, stream);
 }
 
+namespace {
+
+// the Linears of a step in execution order: k = 4 * layer + kind
+struct Fp8Pipe {
+    const nv_decoder* p;
+    hipStream_t main;
+    bool on;
+    int dims[4][2];          // N, K of each kind
+
+    int prefetch(int k) const {          // side stream: operand k -> panel k & 1, once the GEMM that last read that panel is done
+        if (k >= 4 * p->L) return NV_OK;
+        const Layer& ly = p->layers[k >> 2];
+        const int kind = k & 3, pn = k & 1;
+        if (!ly.q[kind] || ly.w[kind]) return NV_OK;
+        if (k >= 2 && hipStreamWaitEvent(p->side, p->ev_use[pn], 0) != hipSuccess) return NV_ERR_LAUNCH;
+        const int N = dims[kind][0], K = dims[kind][1];
+        int rc = nv_fp8_dequant_rows(ly.q[kind], ly.s[kind], p->panel[pn], N, K, K, K, (void*)p->side);
+        if (rc) return rc;
+        return hipEventRecord(p->ev_dq[pn], p->side) == hipSuccess ? NV_OK : NV_ERR_LAUNCH;
+    }
+    // main stream: GEMM k on its panel (de-quantised by prefetch(k)), then the operand after next starts
+    int linear(int k, const void* x, void* out, const void* R, int M) const {
+        const Layer& ly = p->layers[k >> 2];
+        const int kind = k & 3, pn = k & 1, N = dims[kind][0], K = dims[kind][1];
+        const int epi = R ? 2 : 0;
+        if (!ly.q[kind] || ly.w[kind]) return NV_ERR_ARG;
+        if (hipStreamWaitEvent(main, p->ev_dq[pn], 0) != hipSuccess) return NV_ERR_LAUNCH;
+        int rc = nv_gemm_bf16_ws(0, x, p->panel[pn], out, R, M, N, K, K, K, N, N, epi, 0, p->gemm_ws, (void*)main);
+        if (rc) return rc;
+        if (hipEventRecord(p->ev_use[pn], main) != hipSuccess) return NV_ERR_LAUNCH;
+        return prefetch(k + 2);
+    }
+};
+
+}  // namespace
+
 // One incremental step over the K/V cache (navillm_amd/kvcache.py::KVCacheLM.extend is the host side):
 //   x        [M, d] bf16   embeddings of the new rows, any order (the host packs them sample after sample); M == B is taken to mean
 //                          ONE new row per sample, row r = sample r (the decode step)
@@ -136,6 +202,24 @@ int nv_decoder_extend(const nv_decoder* p, const void* x_in, const int* pos, con
     // one new row per sample (M == B: row r is sample r): the streaming decode attention, output rows compact in `attn`
     const bool dec_attn = !(knob2 && atoi(knob2) == 0) && M == B;
     const bool fused = !(knob && atoi(knob) == 0) && M <= 16 && (d % 128) == 0 && (ff % 128) == 0;
+    // weight-only fp8 with the de-quantisation overlapped (see nv_decoder_set_fp8_overlap): every layer must carry codes only
+    Fp8Pipe pipe{p, (hipStream_t)stream, false, {{3 * (int)d, (int)d}, {(int)d, (int)d}, {2 * (int)ff, (int)d}, {(int)d, (int)ff}}};
+    if (p->side && M > 16 && !dyn) {
+        pipe.on = true;
+        for (int i = 0; i < p->L && pipe.on; ++i)
+            for (int k = 0; k < 4; ++k)
+                if (!p->layers[i].q[k] || p->layers[i].w[k]) pipe.on = false;
+    }
+    if (pipe.on) {
+        // the side stream starts after everything already enqueued on the caller's stream (earlier users of the panels included)
+        if (hipEventRecord(p->ev_entry, pipe.main) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_entry, 0) != hipSuccess)
+            return NV_ERR_LAUNCH;
+        NV_TRY(pipe.prefetch(0));
+        NV_TRY(pipe.prefetch(1));
+    }
+    auto lin = [&](const Layer& ly, int i, int kind, const void* xin, void* out, const void* R, int N, int K) {
+        return pipe.on ? pipe.linear(4 * i + kind, xin, out, R, M) : linear(p, ly, kind, xin, out, R, M, N, K, stream);
+    };
     for (int i = 0; i < p->L; ++i) {
         const Layer& ly = p->layers[i];
         if (!ly.norm1 || !ly.norm2 || !ly.kv) return NV_ERR_ARG;
@@ -157,7 +241,7 @@ int nv_decoder_extend(const nv_decoder* p, const void* x_in, const int* pos, con
             continue;
         }
         NV_TRY(nv_rmsnorm_fwd_bf16(x, ly.norm1, n, rstd, M, (int)d, p->eps, stream));
-        NV_TRY(linear(p, ly, 0, n, qkv, nullptr, M, 3 * (int)d, (int)d, stream));
+        NV_TRY(lin(ly, i, 0, n, qkv, nullptr, 3 * (int)d, (int)d));
         if (knob && atoi(knob) == 0) {                                 // the literal two-launch sequence (parity reference)
             NV_TRY(nv_rope_rows_bf16(qkv, p->rope_cos, p->rope_sin, pos, M, p->H, p->hd, 3 * (int)d, stream));
             NV_TRY(nv_scatter_rows_bf16(qkv, crow, ly.kv, M, 3 * (int)d, stream));
@@ -171,11 +255,11 @@ int nv_decoder_extend(const nv_decoder* p, const void* x_in, const int* pos, con
             else NV_TRY(nv_attn_fwd_strided_bf16(ly.kv, attn_buf, lse, kv0, B, Lmax, cap, p->H, p->hd, q_row_min, stream));
             NV_TRY(nv_gather_rows_bf16(attn_buf, grow, attn, M, (int)d, stream));
         }
-        NV_TRY(linear(p, ly, 1, attn, x1, x, M, (int)d, (int)d, stream));                    // x1 = x + o_proj(attn)
+        NV_TRY(lin(ly, i, 1, attn, x1, x, (int)d, (int)d));                                  // x1 = x + o_proj(attn)
         NV_TRY(nv_rmsnorm_fwd_bf16(x1, ly.norm2, n, rstd, M, (int)d, p->eps, stream));
-        NV_TRY(linear(p, ly, 2, n, gu, nullptr, M, 2 * (int)ff, (int)d, stream));
+        NV_TRY(lin(ly, i, 2, n, gu, nullptr, 2 * (int)ff, (int)d));
         NV_TRY(nv_swiglu_fwd_bf16(gu, h, M, (int)ff, stream));
-        NV_TRY(linear(p, ly, 3, h, x2, x1, M, (int)d, (int)ff, stream));                     // x2 = x1 + down(h)
+        NV_TRY(lin(ly, i, 3, h, x2, x1, (int)d, (int)ff));                                   // x2 = x1 + down(h)
         x = x2;
     }
     if (hs_all) NV_TRY(nv_rmsnorm_fwd_bf16(x, p->final_norm, hs_all, rstd, M, (int)d, p->eps, stream));

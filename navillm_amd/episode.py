@@ -143,6 +143,14 @@ class PrefixEpisode:
         d, ff = cfg.hidden_size, cfg.intermediate_size
         widths = self._EWIDTH_ALL if self.mode == "all" else self._EWIDTH
         cap = int(rows * (1.5 if self._cursor else 1.1)) + 64      # growing mid-episode copies: do it rarely
+        if not self._rows_fit(cap):
+            cap = rows + 64                                        # no head room then
+            if not self._rows_fit(cap):
+                raise RuntimeError(
+                    f"prefix-reuse training: the episode buffers for {rows} token rows need {self._row_bytes() * cap / 2**30:.0f} GiB "
+                    f"({self._row_bytes() // 1024} KiB per row over {cfg.num_layers} layers) and do not fit the free device memory; run long "
+                    "episodes with NAVILLM_EPISODE_DEFER=none (every step backpropagates at once, nothing is kept) or finish the "
+                    "episode earlier")
         new, new32 = [], []
         for i in range(cfg.num_layers):
             bufs, b32 = {}, {}
@@ -164,6 +172,23 @@ class PrefixEpisode:
                 if self._E32 is not None:
                     self._E32[i] = None
         self._E, self._E32, self._ecap = new, new32, cap
+
+    def _row_bytes(self):
+        cfg = self.m.cfg
+        widths = self._EWIDTH_ALL if self.mode == "all" else self._EWIDTH
+        per = sum(cd * cfg.hidden_size + cf * cfg.intermediate_size for cd, cf in widths.values()) * 2 + (8 if self.mode == "all" else 0)
+        return per * cfg.num_layers
+
+    def _rows_fit(self, cap):
+        """would episode buffers of `cap` rows fit?  (what is held now is released layer by layer while the new ones are built)"""
+        if self.m.device.type != "cuda":
+            return True
+        free, _ = torch.cuda.mem_get_info(self.m.device)
+        cfg = self.m.cfg
+        held = self._row_bytes() * self._ecap if self._E is not None else 0
+        one_layer = self._row_bytes() // cfg.num_layers * cap
+        reserve = 2 << 30                                       # the batched backward's [R, .] scratch, allocator slack
+        return self._row_bytes() * cap - held + one_layer + reserve <= free + torch.cuda.memory_reserved(self.m.device) - torch.cuda.memory_allocated(self.m.device)
 
     def _weights(self, i):
         """(Wqkv, Wo, Wgu, Wd, w1, w2, their six gradient views) of layer i: views of the flat store, built once"""

@@ -7,11 +7,16 @@ enabled raises.
 
 Arithmetic: every GEMM multiplies with the de-quantised weight bf16(s[n] * q[n,k]) -- "the reference run on de-quantised
 weights", the semantics tests/golden/g11_fp8_*.npz pin:
-  * prefill / K/V-reuse steps (M > 16 rows): `nv_fp8_dequant_rows` writes the operand into ONE bf16 scratch panel (reused by every
-    GEMM of the stream, 141 MB at 13B) in front of the bf16 MFMA GEMM.  HBM-bound pre-pass of 3 B per weight: 5-12 % of the GEMM
-    it feeds at B = 4..8 (DESIGN.md §4 has the measurement);
+  * prefill / K/V-reuse steps (M > 16 rows): `nv_fp8_dequant_rows` writes the operand into a bf16 panel in front of the bf16 MFMA
+    GEMM: an HBM-bound pre-pass of 3 B per weight, 5-12 % of the GEMM it feeds at B = 4..8.  Round 3 built and measured the obvious overlap -- the pre-pass of the NEXT Linear on a side stream into the
+    other of two panels while the current GEMM runs (`NAVILLM_FP8_OVERLAP=1`; the native K/V-cache layer loop does the same,
+    nv_decoder_set_fp8_overlap) -- and it LOSES 1-4 % at 13B / B = 8 (profiles/r03_fp8_overlap_ab.txt: the GEMM's LDS-DMA stream and the
+    pre-pass share the same CUs and the same HBM queues; the GEMM slows down by more than the pre-pass costs in line).  It stays as an
+    opt-in knob, bit-identical and tested; the default is the in-line pre-pass;
   * decode steps (M <= 16): `nv_gemv_fp8w` streams the codes themselves -- half the bytes per generated token.
 """
+import os
+
 import torch
 
 from . import lib as _lib
@@ -77,6 +82,10 @@ class Fp8DecoderWeights:
                     self.resident.append(mats)
         n_max = max(q.shape[0] * q.shape[1] for q in self.codes[0].values())
         self._scratch = None if resident_bf16 else torch.empty((n_max,), dtype=BF16, device=model.device)
+        # the overlapped pre-pass: two panels, a side stream, "operand ready" / "panel free" events; built on first use
+        self.overlap = (not resident_bf16) and os.environ.get("NAVILLM_FP8_OVERLAP", "0") == "1"
+        self._n_max, self._device, self._L = n_max, model.device, cfg.num_layers
+        self._panels = None
         self.bytes = sum(q.numel() + s.numel() * 4 for c, sc in zip(self.codes, self.scales) for q, s in zip(c.values(), sc.values()))
 
     def weight(self, i, kind):
@@ -86,8 +95,54 @@ class Fp8DecoderWeights:
         q, s = self.codes[i][kind], self.scales[i][kind]
         return dequantize_rows(q, s, out=self._scratch[:q.numel()].view(q.shape))
 
+    def pipe(self):
+        """(panel a, panel b, side stream) of the overlapped pre-pass, shared with the native layer loop (navillm_amd/kvcache.py)"""
+        if self._panels is None:
+            self._panels = [torch.empty((self._n_max,), dtype=BF16, device=self._device) for _ in range(2)]
+            self._side = torch.cuda.Stream(device=self._device)
+            self._ev_dq = [torch.cuda.Event() for _ in range(2)]
+            self._ev_use = [torch.cuda.Event() for _ in range(2)]
+            self._ready = [None, None]
+        return self._panels[0], self._panels[1], self._side
+
+    def invalidate(self):
+        """someone else (the native layer loop) wrote the panels"""
+        if self._panels is not None:
+            self._ready = [None, None]
+
+    def _dequant_on_side(self, key, pn):
+        q, s = self.codes[key[0]][key[1]], self.scales[key[0]][key[1]]
+        with torch.cuda.stream(self._side):
+            dequantize_rows(q, s, out=self._panels[pn][:q.numel()].view(q.shape))
+            self._ev_dq[pn].record(self._side)
+        self._ready[pn] = key
+
+    def _next(self, i, kind):
+        k = KINDS.index(kind) + 1
+        return (i, KINDS[k]) if k < 4 else ((i + 1) % self._L, KINDS[0])
+
     def linear(self, x, i, kind, out=None, R=None, epilogue=ops.EPI_STORE):
         q, s = self.codes[i][kind], self.scales[i][kind]
         if x.shape[0] <= 16 and epilogue in (ops.EPI_STORE, ops.EPI_RESID) and q.shape[1] % 64 == 0:
             return gemv_fp8w(x, q, s, out=out, R=R, epilogue=epilogue)
-        return ops.gemm_bf16(ops.NT, x, self.weight(i, kind), out=out, R=R, epilogue=epilogue)
+        if not self.overlap or self.resident is not None:
+            return ops.gemm_bf16(ops.NT, x, self.weight(i, kind), out=out, R=R, epilogue=epilogue)
+        self.pipe()
+        main = torch.cuda.current_stream(self._device)
+        key = (i, kind)
+        if key in self._ready:
+            pn = self._ready.index(key)
+        else:
+            # not prefetched (first Linear, or the Linears are not visited in layer order): after everything enqueued so far
+            pn = 0 if self._ready[0] is None else 1 if self._ready[1] is None else getattr(self, "_last_pn", 1) ^ 1
+            self._side.wait_stream(main)
+            self._dequant_on_side(key, pn)
+        main.wait_event(self._ev_dq[pn])
+        y = ops.gemm_bf16(ops.NT, x, self._panels[pn][:q.numel()].view(q.shape), out=out, R=R, epilogue=epilogue)
+        self._ev_use[pn].record(main)
+        self._last_pn = pn
+        nxt = self._next(i, kind)
+        if self._ready[pn ^ 1] != nxt:
+            self._side.wait_event(self._ev_use[pn ^ 1])      # the GEMM that last read the other panel (never recorded: no wait)
+            self._dequant_on_side(nxt, pn ^ 1)
+        return y

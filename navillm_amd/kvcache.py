@@ -79,7 +79,8 @@ class KVCacheLM:
         # the greedy step, which runs on a side stream).  The split-K workspace handed to the decoder is only touched by the tile
         # GEMMs of prefill-sized steps (M > 16), which always run on the stream the decoder was created on; the captured decode
         # step (M = B <= 16) runs the weight streamers and never reads it.
-        key = (id(m.fp8), m.fp8 is not None and m.fp8.resident is not None, m.store.param["lm"].data_ptr())
+        key = (id(m.fp8), m.fp8 is not None and m.fp8.resident is not None, m.store.param["lm"].data_ptr(),
+               m.fp8 is not None and m.fp8.overlap)
         if self._dec is not None and self._dec_key == key:
             return self._dec
         L = ops._L()
@@ -104,6 +105,9 @@ class KVCacheLM:
         scratch = m.fp8._scratch.data_ptr() if (m.fp8 is not None and m.fp8._scratch is not None) else None
         _lib.check(L.nv_decoder_set_shared(dec, m.rope_cos.data_ptr(), m.rope_sin.data_ptr(), st.p("lang_model.model.norm.weight").data_ptr(),
                                            ops._gemm_ws(m.device) if ops.SPLITK_TAIL else None, scratch), "nv_decoder_set_shared")
+        if m.fp8 is not None and m.fp8.overlap:
+            pa, pb, side = m.fp8.pipe()
+            _lib.check(L.nv_decoder_set_fp8_overlap(dec, pa.data_ptr(), pb.data_ptr(), side.cuda_stream), "nv_decoder_set_fp8_overlap")
         self._dec, self._dec_key = dec, key
         return dec
 
@@ -182,6 +186,8 @@ class KVCacheLM:
                                  self.attn.data_ptr(), self.lse.data_ptr(), last_d.data_ptr(), hs.data_ptr(), ops._p(hs_all), M, B, Lmax, cap,
                                  qmin, None, self._ws.data_ptr(), self._ws.numel(), ops._st())
         _lib.check(rc, "nv_decoder_extend")
+        if m.fp8 is not None and M > 16:
+            m.fp8.invalidate()             # the layer loop's overlapped pre-pass wrote the two de-quantisation panels
         self.state = new_state
         self.last_stats = {"prefix": P, "new": n, "block_rows": M}
         if want_all:

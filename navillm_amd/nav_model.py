@@ -250,6 +250,7 @@ class NavModel(nn.Module):
         f8.resident = None
         n_max = max(q.shape[0] * q.shape[1] for q in f8.codes[0].values())
         f8._scratch = torch.empty((n_max,), dtype=BF16, device=self.device)
+        f8.overlap = os.environ.get("NAVILLM_FP8_OVERLAP", "0") == "1"
         self.store.release_decoder_layers_and_grads(self._named)
         if self.kv is not None:
             self.kv._dec_key = None                                # the native decoder's weight table points at the released buffers

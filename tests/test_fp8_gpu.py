@@ -179,3 +179,34 @@ def test_fp8_resident_bf16_operands_equal_the_per_call_dequantisation():
     with torch.no_grad():
         _, o2, _ = _nav_forward(res, z3)
     assert torch.equal(o2["fuse_logits"], outs["lean"][0])
+
+
+def test_fp8_overlapped_dequantisation_equals_the_in_line_one(monkeypatch):
+    """round 3: the next Linear's operand is de-quantised on a side stream while the current GEMM runs (two panels; Python path:
+    navillm_amd/fp8.py, K/V-cache path: nv_decoder_set_fp8_overlap).  Same values, same GEMMs -> bit-identical to the in-line
+    pre-pass, across repeated forwards (the prefetch wraps to layer 0) and with the two paths interleaved (they share the panels)."""
+    z3 = gold("g3_nav_bf16.npz")
+    cfg = tiny_cfg("bf16")
+    monkeypatch.setenv("NAVILLM_FP8_OVERLAP", "0")
+    inline = build(cfg)
+    f0 = inline.to_fp8_weight_only()
+    monkeypatch.setenv("NAVILLM_FP8_OVERLAP", "1")
+    over = build(cfg)
+    f1 = over.to_fp8_weight_only()
+    assert not f0.overlap and f1.overlap
+    seq = ["full", "full", "kv", "full", "kv", "kv", "full"]
+    outs = {}
+    for tag, m in (("inline", inline), ("overlap", over)):
+        got = []
+        with torch.no_grad():
+            for step in seq:
+                if step == "kv":
+                    m.enable_kv_cache(3)
+                _, o, _ = _nav_forward(m, z3)
+                m.kv = None
+                got.append(o["fuse_logits"].clone())
+        torch.cuda.synchronize()
+        outs[tag] = got
+    assert f1._panels is not None and f0._panels is None
+    for a, b in zip(outs["inline"], outs["overlap"]):
+        assert torch.equal(a, b)

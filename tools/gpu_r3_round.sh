@@ -13,6 +13,7 @@ print("HEADLINE", d["config"]["training_mode"], d["value"], d["ms_per_step"], "f
 o = d.get("other_mode", {})
 print("OTHER", o.get("mode"), o.get("nav_steps_per_s_per_gpu"), o.get("ms_per_step"), (o.get("roofline") or {}).get("frac"), (o.get("roofline") or {}).get("by_layout_tflops"), o.get("error"))
 print(d["config"].get("timed_window"))
+print("WHOLE", d.get("whole_episodes"))
 for k in ("inference_forward_only", "inference_prefix_kv_reuse"):
     print(k, (d.get(k) or {}).get("nav_steps_per_s_per_gpu"))
 PY
