@@ -430,55 +430,70 @@ def test_clip_and_adamw_match_oracle_sequence():
 def test_clip_and_adamw_vs_reference_fixture_g8():
     """the HIP clip + AdamW against fixture G8 DIRECTLY -- three steps of torch's own
     `clip_grad_norm_(params, 40.)` + `torch.optim.AdamW` on two bf16 tensors and one fp32 tensor (train.py:86-89,
-    tools/optims.py:43-45), clipping active at every step (norms 45 / 4520 / 45).  The fused clip keeps the global norm in
-    fp32 where torch rounds each per-tensor norm to the gradient dtype first: the total norm must agree to 0.5 % (measured 0.26 %); the clip
-    coefficient then differs in its last digits, which flips the bf16 rounding of a moment here and there, so a few per cent of the
-    bf16 parameters may differ from torch's -- by at most 2 % of the update (an AdamW update is ~lr = 1e-3 whatever the gradient;
-    torch's bf16 sequence rounds five times on the way -- lerp, mul, addcmul, sqrt / div / add, addcdiv -- 2^-9 to 2^-8 relative each, and
-    a coefficient that differs in its last digits moves every one of those roundings) or two bf16 spacings of the element, whichever is
-    larger; the fp32 tensor agrees to 1e-5 relative.  Measured on MI355X: 1.2 % of the elements differ, by <= 3 spacings of elements
-    ~5e-4 in size (= 1.1 % of the update)."""
+    tools/optims.py:43-45), clipping active at every step (norms 45 / 4500 / 45).
+
+    The ONE deliberate deviation: the fused clip keeps the global norm in fp32 where torch rounds each per-tensor norm to the
+    gradient dtype first (0.17-0.26 % apart here; asserted 0.5 %).  Two assertions follow from that:
+    (a) against torch's own update arithmetic fed with the fp32-norm coefficient (the G8-pinned oracle's `adamw_step_`, every
+        intermediate rounded to the tensor dtype) the kernel is bit-identical (a stray element may round differently through the
+        GPU's sqrt / division: < 0.1 %, one spacing);
+    (b) against the fixture itself: the coefficient's last digits flip the bf16 rounding of a moment here and there, so 1.2 % /
+        3.2 % / 4.7 % of the bf16 parameters differ from torch's after steps 1 / 2 / 3 -- all but 0.03 % of them by at most two
+        spacings of the element or 2 % of an update (~lr), the rest by < 0.1 lr (|p| ~ 1e-5, where a spacing is 1e-7); the fp32
+        tensor within lr x the coefficient difference (4e-6 after three steps).  The numbers are reproduced exactly by running
+        the oracle with the fp32-norm coefficient on the CPU."""
+    import math
     import os
     import numpy as np
     from navillm_amd import ops
+    from util import load_oracle
+    O = load_oracle()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     z = np.load(os.path.join(root, "tests", "golden", "g8_adamw.npz"))
     T_ = lambda k: torch.from_numpy(np.ascontiguousarray(z[k]))
     dts = [BF, BF, F32]
+    lr = 1e-3
     shapes = [T_(f"p0_{i}").shape for i in range(3)]
     ps = [T_(f"p0_{i}").to(dts[i]).reshape(-1).to(dev()) for i in range(3)]
     ms = [torch.zeros_like(p) for p in ps]
     vs = [torch.zeros_like(p) for p in ps]
+    e_ps = [T_(f"p0_{i}").to(dts[i]) for i in range(3)]          # (a): the oracle's sequence with the fp32-norm coefficient, on the CPU
+    e_ms = [torch.zeros_like(p) for p in e_ps]
+    e_vs = [torch.zeros_like(p) for p in e_ps]
     for s_ in range(3):
         prev = [p.float().cpu().view(shapes[i]).clone() for i, p in enumerate(ps)]
-        gs = [T_(f"g{s_}_{i}").to(dts[i]).reshape(-1).to(dev()) for i in range(3)]
+        gs_cpu = [T_(f"g{s_}_{i}").to(dts[i]) for i in range(3)]
+        gs = [g.reshape(-1).to(dev()) for g in gs_cpu]
         coef = ops.clip_coef(gs, 40.0)
         torch.cuda.synchronize()
         want_norm = float(z["norms"][s_])
-        assert abs(coef[0].item() - want_norm) <= 5e-3 * want_norm, (s_, coef[0].item(), want_norm)   # torch: per-tensor norms rounded to bf16 (2^-8) first
+        assert abs(coef[0].item() - want_norm) <= 5e-3 * want_norm, (s_, coef[0].item(), want_norm)
+        tot = math.sqrt(sum((g.double() ** 2).sum().item() for g in gs_cpu))
+        assert abs(coef[0].item() - tot) <= 1e-4 * tot and abs(coef[1].item() - min(1.0, 40.0 / (tot + 1e-6))) <= 1e-4 * coef[1].item()
+        c32 = coef[1].cpu()                                                      # the device's own fp32 coefficient
         for i in range(3):
-            ops.adamw_(ps[i], gs[i], ms[i], vs[i], s_ + 1, 1e-3, clip=coef)
+            ops.adamw_(ps[i], gs[i], ms[i], vs[i], s_ + 1, lr, clip=coef)
+            O.adamw_step_(e_ps[i], (gs_cpu[i].float() * c32).to(dts[i]), e_ms[i], e_vs[i], s_ + 1, lr=lr)
         torch.cuda.synchronize()
         for i in range(3):
-            got, ref = ps[i].float().cpu().view(shapes[i]), T_(f"p{s_ + 1}_{i}").float()
+            got, ref, emu = ps[i].float().cpu().view(shapes[i]), T_(f"p{s_ + 1}_{i}").float(), e_ps[i].float()
+            d = (got - ref).abs()
             if dts[i] == BF:
                 spacing = torch.exp2(torch.floor(torch.log2(torch.maximum(ref.abs(), prev[i].abs()).clamp_min(1e-30))) - 7)
-                d = (got - ref).abs()
+                de = (got - emu).abs()
+                print(f"[g8 step {s_ + 1} tensor {i}] vs torch arithmetic with the fp32-norm coefficient: {(de > 0).float().mean().item():.3%} "
+                      f"of the elements differ (max {(de / spacing).max().item():.2f} spacings)")
+                assert (de > 0).float().mean().item() < 1e-3 and bool((de <= spacing).all()), (s_, i)
                 frac = (d > 0).float().mean().item()
-                worst = (d / spacing).max().item()
-                print(f"[g8 step {s_ + 1} tensor {i}] bf16 params: {frac:.2%} of the elements differ from torch's, by at most {worst:.2f} spacings")
-                # measured: 1.2 % / 3.2 % / 4.7 % of the elements differ after steps 1 / 2 / 3 (the bf16 moments carry a flipped rounding
-                # forward); all but a handful by at most 2 spacings or 2 % of an update, the worst (|p| ~ 1e-5, where a spacing is
-                # 1e-7) by a few % of lr once the clipped step's 0.26 % coefficient difference sits in the moments
-                lr = 1e-3
                 over = d > torch.maximum(2.0 * spacing, torch.full_like(d, 2e-2 * lr))
-                print(f"    beyond max(2 spacings, 2 % lr): {over.float().mean().item():.3%}, worst |diff| = {d.max().item() / lr:.3f} lr")
-                assert over.float().mean().item() < 1e-3 and d.max().item() <= 0.1 * lr and frac < 0.10, (s_, i, frac, worst, d.max().item())
+                worst_over = d[over].max().item() / lr if bool(over.any()) else 0.0
+                print(f"[g8 step {s_ + 1} tensor {i}] vs the fixture: {frac:.2%} of the elements differ, by at most {(d / spacing).max().item():.2f} "
+                      f"spacings; beyond max(2 spacings, 2 % lr): {over.float().mean().item():.3%} (worst {worst_over:.3f} lr)")
+                assert frac < 0.10 and over.float().mean().item() < 1e-3 and worst_over <= 0.25, (s_, i, frac, worst_over)
             else:
-                # the clip coefficient differs from torch's by up to 0.5 % (asserted above: torch rounds each tensor's norm to
-                # bf16 first), which moves an update of size lr by up to lr * 0.5 % = 5e-6 once a clipped and an unclipped
-                # step are mixed in the moments (measured 2.2e-6 after step 2)
-                assert torch.allclose(got, ref, rtol=1e-5, atol=5e-6), (s_, i, (got - ref).abs().max().item())
+                assert torch.allclose(got, emu, rtol=1e-6, atol=1e-9), (s_, i, (got - emu).abs().max().item())
+                # lr x the relative coefficient difference (<= 0.5 %), summed over the steps whose moments mix the coefficients
+                assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), (s_, i, d.max().item())
 
 
 # ------------------------------------------------------------------------------ fp32 encoder kernels
