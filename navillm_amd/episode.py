@@ -354,8 +354,9 @@ class PrefixEpisode:
                     return self._E[i + 1]["x"][r0:r0 + M]
                 return self._buf(f"s{i}.{name}", (M, width) if width else (M,), dt)
             n1, rstd1 = ops.rmsnorm_fwd(x, w1, eps, out=t("n1", d), rstd=t("r1", 0, F32))
-            qkv = ops.gemm_bf16(ops.NT, n1, Wqkv, out=E["qkv"][r0:r0 + M] if allm else self._buf("qkv", (M, 3 * d)))
-            ops.rope_rows_(qkv, m.rope_cos, m.rope_sin, step["pos"], H, hd)
+            # q|k|v with RoPE in the GEMM epilogue (bit-identical to the GEMM followed by nv_rope_rows_bf16), row r at position pos[r]
+            qkv = ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, cap, 2 * H * hd, out=E["qkv"][r0:r0 + M] if allm else self._buf("qkv", (M, 3 * d)),
+                                    pos_i32=step["pos"])
             ops.scatter_rows_bf16_(qkv, step["crow"], self.cache[i])
             lse_i = self.lse_s[k][i] if allm else self.lse[i]
             ops.attn_fwd_strided(self.cache[i], self.kv0, B, Lmax, cap, H, hd, out=self.attn_buf[i], lse2=lse_i, q_row_min=qmin)
