@@ -178,6 +178,22 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
 
 // torch.optim.AdamW single-tensor update, every intermediate rounded to the storage dtype
 // (oracle/navillm_oracle.py: adamw_step_), gradient pre-scaled by the clip coefficient.
+// one element of torch.optim.AdamW's single-tensor update; every intermediate is rounded to the storage dtype exactly where torch
+// rounds it (lerp_, mul_, addcmul_, sqrt / div / add_, addcdiv_)
+template <typename T>
+__device__ __forceinline__ void adamw_elem(float& pi, float g_raw, float& mi, float& vi, float coef, float decay, float w1, float b2,
+                                           float w2, float eps, float step_size, float sqrt_bc2) {
+    const float gi = rnd<T>(g_raw * coef);
+    pi = rnd<T>(pi * decay);
+    mi = rnd<T>(mi + w1 * (gi - mi));                             // lerp_, weight < 0.5 form
+    vi = rnd<T>(vi * b2);
+    vi = rnd<T>(vi + w2 * gi * gi);                               // addcmul_
+    float den = rnd<T>(sqrtf(vi));
+    den = rnd<T>(den / sqrt_bc2);
+    den = rnd<T>(den + eps);
+    pi = rnd<T>(pi - step_size * (mi / den));                     // addcdiv_
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ p, const T* __restrict__ g, T* __restrict__ m,
                                                     T* __restrict__ v, long n, float decay, float w1, float b2, float w2,
@@ -185,17 +201,29 @@ __global__ __launch_bounds__(256) void adamw_kernel(T* __restrict__ p, const T* 
                                                     const float* __restrict__ clip) {
     // scalars arrive already rounded the way torch rounds its python-double hyper-parameters to fp32
     const float coef = clip ? clip[1] : 1.f;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
-        const float gi = rnd<T>(ldf<T>(g, i) * coef);
-        float pi = rnd<T>(ldf<T>(p, i) * decay);
-        const float mo = ldf<T>(m, i);
-        const float mi = rnd<T>(mo + w1 * (gi - mo));            // lerp_, weight < 0.5 form
-        float vi = rnd<T>(ldf<T>(v, i) * b2);
-        vi = rnd<T>(vi + w2 * gi * gi);                           // addcmul_
-        float den = rnd<T>(sqrtf(vi));
-        den = rnd<T>(den / sqrt_bc2);
-        den = rnd<T>(den + eps);
-        pi = rnd<T>(pi - step_size * (mi / den));                         // addcdiv_
+    long done = 0;
+    if constexpr (sizeof(T) == 2) {
+        // 8 elements = one 16-byte access per array and thread (round 3: the element-wise form issued 7 two-byte accesses per element)
+        if (((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0) {
+            const long n8 = n / 8;
+            for (long i = blockIdx.x * 256L + threadIdx.x; i < n8; i += gridDim.x * 256L) {
+                float pf[8], gf[8], mf[8], vf[8];
+                ld8((const bf16_t*)p + i * 8, pf);
+                ld8((const bf16_t*)g + i * 8, gf);
+                ld8((const bf16_t*)m + i * 8, mf);
+                ld8((const bf16_t*)v + i * 8, vf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) adamw_elem<T>(pf[j], gf[j], mf[j], vf[j], coef, decay, w1, b2, w2, eps, step_size, sqrt_bc2);
+                *(u32x4*)((bf16_t*)p + i * 8) = u32x4{pack2bf(pf[0], pf[1]), pack2bf(pf[2], pf[3]), pack2bf(pf[4], pf[5]), pack2bf(pf[6], pf[7])};
+                *(u32x4*)((bf16_t*)m + i * 8) = u32x4{pack2bf(mf[0], mf[1]), pack2bf(mf[2], mf[3]), pack2bf(mf[4], mf[5]), pack2bf(mf[6], mf[7])};
+                *(u32x4*)((bf16_t*)v + i * 8) = u32x4{pack2bf(vf[0], vf[1]), pack2bf(vf[2], vf[3]), pack2bf(vf[4], vf[5]), pack2bf(vf[6], vf[7])};
+            }
+            done = n8 * 8;
+        }
+    }
+    for (long i = done + blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        float pi = ldf<T>(p, i), mi = ldf<T>(m, i), vi = ldf<T>(v, i);
+        adamw_elem<T>(pi, ldf<T>(g, i), mi, vi, coef, decay, w1, b2, w2, eps, step_size, sqrt_bc2);
         stf<T>(p, i, pi);
         stf<T>(m, i, mi);
         stf<T>(v, i, vi);

@@ -279,7 +279,7 @@ def test_two_rank_rehearsal_on_one_gpu_prints_one_n2_line():
     env = dict(os.environ, NAVILLM_BENCH_REHEARSAL="1", NAVILLM_BUILD_REUSE="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--model", "tiny", "--steps", "7", "--warmup", "1",
-                        "--prewarm", "1", "--instr-len", "40", "--batch", "2", "--no-extras", "--no-cpu-baseline", "--infer-steps", "0"],
+                        "--prewarm", "1", "--instr-len", "40", "--batch", "2", "--no-cpu-baseline", "--infer-steps", "0"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -287,3 +287,7 @@ def test_two_rank_rehearsal_on_one_gpu_prints_one_n2_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 7 and d["value"] > 0 and "rehearsal" in d
     assert d["config"]["parallelism"] == "dp2" and d["dp"]["reduce"] == "step"
+    # K = 7: episodes of 6 + 1 steps, the last timed step closes its episode; then both ranks run the whole-episode window and the
+    # other training mode (each with its own exchanges) and still agree on one line
+    assert "6 + 1" in d["config"]["timed_window"] and d["whole_episodes"]["steps"] == 18 and d["whole_episodes"]["nav_steps_per_s"] > 0
+    assert d["other_mode"]["mode"] == "recompute" and d["other_mode"].get("nav_steps_per_s_per_gpu", 0) > 0, d["other_mode"]
