@@ -207,6 +207,25 @@ def test_prefix_episode_rejects_foreign_prompts_and_wrong_use():
         m.begin_episode([[1, cfg.cand_token_id, 5], [1, 2, 3]])
 
 
+def test_episode_buffers_refuse_to_outgrow_the_device(monkeypatch):
+    """the deferred forms keep every token row of an episode (131.6 KB per row and layer at 7B): when the rows would not fit the free
+    device memory the episode says so and names the way out, instead of dying in the allocator halfway through a rollout"""
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.synthetic import SyntheticEpisodes
+    cfg = _mid_cfg()
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
+    ep = SyntheticEpisodes(cfg, 2, seed=3, instr_len=60, device=torch.device(DEV))
+    m.begin_episode(ep.prefix_ids())                                  # fits: builds the episode object and its buffers
+    assert m.episode._rows_fit(m.episode._ecap + 1024)
+    m.episode_abort()
+    real = torch.cuda.mem_get_info
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (0, real()[1]))
+    assert not m.episode._rows_fit(10 * m.episode._ecap + (1 << 22))
+    m.episode._E, m.episode._ecap = None, 0                           # as if the next episode had to build them afresh
+    with pytest.raises(RuntimeError, match="NAVILLM_EPISODE_DEFER=none"):
+        m.episode._ensure_rows(1 << 24)
+
+
 def test_prefix_episode_under_the_data_parallel_wrapper_world1():
     """the episode mode behind NavDataParallel (world of one, exchange forced): the per-layer exchanges are launched from the
     prefix's deferred backward inside final_backward(); gradients must equal the unwrapped episode bit for bit and nothing may
