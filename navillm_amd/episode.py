@@ -555,7 +555,9 @@ class PrefixEpisode:
             Lp_max = P["Lmax"]
             self._lens_dev = P["lens_dev"]
             epi_tab = lse_tab = None
-            if os.environ.get("NAVILLM_EPISODE_ATTN_BWD", "episode") != "steps":
+            # (the one-launch kernels keep a step table of 128 entries and 1536 statistics rows in LDS: longer episodes / blocks take
+            # the per-step path)
+            if os.environ.get("NAVILLM_EPISODE_ATTN_BWD", "episode") != "steps" and len(recs) <= 128 and Mz // B <= 1536:
                 # where every step's block sits (r0 | rows per sample | live rows of each sample) and, per layer, where its lse is
                 T = len(recs)
                 tab = np.concatenate([np.array([r["r0"] for r in recs], np.int32), np.array([r["step"]["N"] for r in recs], np.int32),
