@@ -160,11 +160,11 @@ int nv_attn_bwd_strided_kvacc_bf16(const void* qkv, const void* out, const void*
                                    int head_dim, int q_row_min, void* stream);
 /*   attention backward of ALL T steps of a prefix-reuse episode for one layer, in place on the episode's row buffers
  *   (navillm_amd/episode.py, mode "all"; the reference runs one full-prompt backward per step, mp3d_agent.py:756): rows [0, Mp) =
- *   the packed prompt prefixes (cu [B+1]), then T step blocks described by tab (device int32: r0[T] | N[T] | n[T*B]: step t, sample
- *   b = rows r0[t] + b*N[t] + j, j < n[t*B+b] live, the rest padding); lse_ptrs = T device pointers to the steps' lse2 [B, H, cap]
- *   (indexed by cache position prefix_len + j).  Writes dqkv rows [Mp, R) (dQ and the steps' own dK|dV, through RoPE^T when the
- *   tables are given, position = prefix_len + j; padding rows: zeros) and STORES the fp32 sum over the steps of the prefix rows'
- *   dK|dV in kv_acc [B*cap, 2*H*head_dim] (row b*cap + key).  workspace: (R - Mp) * H floats */
+ *   the packed prompt prefixes (cu [B+1]), then T packed step blocks described by tab (device int32: off[T*B] = first row of step t,
+ *   sample b | n[T*B] = its rows; together they tile [Mp, R)); lse_ptrs = T device pointers to the steps' lse2 [B, H, cap] (indexed by
+ *   cache position prefix_len + j).  Writes dqkv rows [Mp, R) (dQ and the steps' own dK|dV, through RoPE^T when the tables are given,
+ *   position = prefix_len + j) and STORES the fp32 sum over the steps of the prefix rows' dK|dV in kv_acc [B*cap, 2*H*head_dim]
+ *   (row b*cap + key).  workspace: (R - Mp) * H floats; at most 128 steps, at most 1536 rows per sample and step */
 int nv_attn_bwd_episode_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, void* workspace, const void* lse_ptrs,
                              const int* cu, const int* tab, float* kv_acc, const void* rope_cos, const void* rope_sin, int T, int B, int H,
                              int head_dim, int cap, int Mp, long R, int Lp_max, int N_max, void* stream);

@@ -856,11 +856,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 
 // =========================================================================== backward of a prefix-reuse EPISODE's steps (round 3)
 // navillm_amd/episode.py, mode "all": at finish_episode() one layer's q|k|v, attention outputs and output gradients of EVERY token row
-// of the episode sit in [R, .] buffers -- the prompt prefixes packed (sample b = rows [cu[b], cu[b+1])), then one block per step
-// (step t = rows r0_t + b*N_t + j, j < n_t[b] live, the rest of the N_t rows padding).  A step's queries see their sample's whole
+// of the episode sit in [R, .] buffers -- the prompt prefixes packed (sample b = rows [cu[b], cu[b+1])), then one block per step,
+// packed as well (step t, sample b = rows off[t,b] + j, j < n[t,b]).  A step's queries see their sample's whole
 // prefix and the step's own earlier rows.  One launch per kernel covers all T steps: the prefix key blocks walk the query tiles of
 // every step and leave the fp32 sum of the K/V gradients in kv_acc (round 3a ran one launch per step, each re-reading and
-// re-writing 139 MB of fp32 accumulator); nothing is scattered into the K/V cache layout and back.  Padding rows get zeros.
+// re-writing 139 MB of fp32 accumulator); nothing is scattered into the K/V cache layout and back.
 // descriptor whose base / span come from values LOADED in the kernel (wave-uniform, but in vector registers)
 __device__ __forceinline__ u32x4 make_desc_u(const void* base, uint32_t bytes) {
     const uint64_t a = (uint64_t)base;
@@ -875,7 +875,7 @@ struct EpiArgs {
     const float* dsum;              // [H, R - Mp]: row-sums of dO * O over the steps' rows
     const float* const* lse;        // [T] device pointers: lse2 [B, H, cap] of each step, indexed by cache position (prefix_len + j)
     const int* cu;                  // [B + 1]
-    const int* tab;                 // [T] r0 | [T] N | [T * B] n
+    const int* tab;                 // [T * B] off (first row of step t, sample b) | [T * B] n (its rows)
     float* kvacc;                   // fp32 [B * cap, 2 * H * HD], row b * cap + key
     const bf16_t* rope_cos; const bf16_t* rope_sin;
     int T, B, H, ld, cap, Mp, Rs, nPB, nSB;
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(256) void epi_bwd_dkv_kernel(EpiArgs p) {
     } else {
         const int y = blockIdx.y - p.nPB;
         t_beg = y / p.nSB; t_end = t_beg + 1; kblk = (y % p.nSB) * 64;
-        klen = p.tab[T + t_beg]; krow0 = p.tab[t_beg] + (long)b * klen;
+        klen = p.tab[T * B + t_beg * B + b]; krow0 = p.tab[t_beg * B + b];
     }
     if (kblk >= klen) return;
     const int ki = lane & 15, g = lane >> 4;
@@ -921,10 +921,10 @@ __global__ __launch_bounds__(256) void epi_bwd_dkv_kernel(EpiArgs p) {
 
     // the step table of this sample and the steps' lse pointers, read inside the tile loop, live in LDS (see attn_bwd_dkv_kernel:
     // no compiler-visible vector-memory load may sit between the asm-issued prefetches), and so do the current step's statistics
-    __shared__ int s_r0[EPI_TMAX], s_N[EPI_TMAX], s_n[EPI_TMAX];
+    __shared__ int s_off[EPI_TMAX], s_n[EPI_TMAX];
     __shared__ const float* s_lsep[EPI_TMAX];
     for (int t = tid; t < T; t += 256) {
-        s_r0[t] = p.tab[t]; s_N[t] = p.tab[T + t]; s_n[t] = p.tab[2 * T + t * B + b]; s_lsep[t] = p.lse[t];
+        s_off[t] = p.tab[t * B + b]; s_n[t] = p.tab[T * B + t * B + b]; s_lsep[t] = p.lse[t];
     }
     LDS_PTR(float) s_lse = (LDS_PTR(float))(smem + DKV_SLOTS * 2 * TILE);
     LDS_PTR(float) s_ds = s_lse + p.stat_cap;
@@ -932,8 +932,8 @@ __global__ __launch_bounds__(256) void epi_bwd_dkv_kernel(EpiArgs p) {
     auto nvalid = [&](int t) { return s_n[t]; };
     auto norm = [&](int& t, int& q) { while (t < t_end && q * 32 >= nvalid(t)) { ++t; q = 0; } };
     auto stage = [&](int t, int q, int slot) {
-        const int N = s_N[t], n = nvalid(t);
-        const long row0 = s_r0[t] + (long)b * N;
+        const int n = nvalid(t);
+        const long row0 = s_off[t];
         const u32x4 rq = make_desc_u(p.qkv + row0 * ld, (uint32_t)(((long)(n - 1) * ld + 3 * p.H * HD) * 2));
         const u32x4 rdo = make_desc_u(p.dout + row0 * od, (uint32_t)(((long)(n - 1) * od + od) * 2));
         stage_rows<32, 256>(rq, smem + slot * 2 * TILE, q * 32, h * HD, ld, tid);
@@ -959,8 +959,8 @@ __global__ __launch_bounds__(256) void epi_bwd_dkv_kernel(EpiArgs p) {
         const int wkey_hi = kblk + wave * 16 + 15;
         while (t0 < t_end) {
             const bool more = t3 < t_end;
-            const int N = s_N[t0], n = nvalid(t0);
-            const long row0 = s_r0[t0] + (long)b * N;
+            const int n = nvalid(t0);
+            const long row0 = s_off[t0];
             if (t0 != t_stats) {
                 // a new step: its statistics (n <= stat_cap rows, padded to the tile) into LDS.  Every wave left the previous step's
                 // reads behind at the barrier that ended the last tile step; this is the one place the loop drains its prefetches.
@@ -1084,9 +1084,9 @@ __global__ __launch_bounds__(256) void epi_bwd_dq_kernel(EpiArgs p) {
     const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int T = p.T, ld = p.ld, od = p.H * HD;
     const int t = blockIdx.y / p.nSB, q0 = (blockIdx.y % p.nSB) * 64;
-    const int N = p.tab[T + t], n = p.tab[2 * T + t * p.B + b];
-    if (q0 >= N) return;
-    const long row0 = p.tab[t] + (long)b * N;
+    const int n = p.tab[T * p.B + t * p.B + b];
+    if (q0 >= n) return;
+    const long row0 = p.tab[t * p.B + b];
     const int lp = p.cu[b + 1] - p.cu[b];
     const int qi = lane & 15, g = lane >> 4;
     const int q = q0 + wave * 16 + qi;
@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(256) void epi_bwd_dq_kernel(EpiArgs p) {
             cur ^= 1;
         }
     }
-    if (q >= N) return;
+    if (q >= n) return;
     const int pos = lp + q < p.cap ? lp + q : p.cap - 1;
     bf16_t* qp = p.dqkv + (row0 + q) * ld + h * HD + g * 4;
     store_grad_row(qp, dq, p.scale, p.rope_cos ? p.rope_cos + (long)pos * HD + g * 4 : nullptr,
@@ -1405,10 +1405,11 @@ int nv_attn_bwd_varlen_bf16(const void* qkv, const void* out, const void* dout, 
 
 // Attention backward of ALL the steps of a prefix-reuse episode for one layer, in place on the episode's row buffers (see EpiArgs):
 // qkv / dqkv [R, 3*H*head_dim], out / dout [R, H*head_dim]; rows [0, Mp) are the packed prompt prefixes (cu [B+1]), then the T step
-// blocks described by tab (device int32: r0[T] | N[T] | n[T*B]); lse_ptrs = T device pointers to the steps' lse2 [B, H, cap].
-// Writes dqkv rows [Mp, R) (dQ and the steps' own dK|dV, through RoPE^T when the tables are given: position = prefix_len + j;
-// padding rows: zeros) and STORES the fp32 sum over the steps of the prefix rows' dK|dV in kv_acc [B*cap, 2*H*head_dim] (row b*cap + key).
-// workspace: (R - Mp) * H floats.  Lp_max / N_max: the longest prefix / the largest N.
+// blocks, packed too, described by tab (device int32: off[T*B] = first row of step t / sample b | n[T*B] = its rows; together they
+// tile [Mp, R)); lse_ptrs = T device pointers to the steps' lse2 [B, H, cap].  Writes dqkv rows [Mp, R) (dQ and the steps' own dK|dV,
+// through RoPE^T when the tables are given: position = prefix_len + j) and STORES the fp32 sum over the steps of the prefix rows'
+// dK|dV in kv_acc [B*cap, 2*H*head_dim] (row b*cap + key).  workspace: (R - Mp) * H floats.  Lp_max / N_max: the longest prefix /
+// the most rows a sample has in one step.
 int nv_attn_bwd_episode_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, void* workspace, const void* lse_ptrs,
                              const int* cu, const int* tab, float* kv_acc, const void* rope_cos, const void* rope_sin, int T, int B, int H,
                              int head_dim, int cap, int Mp, long R, int Lp_max, int N_max, void* stream) {

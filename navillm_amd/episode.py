@@ -124,7 +124,9 @@ class PrefixEpisode:
         n = int(np.prod(shape))
         t = self._slab.get(tag)
         if t is None or t.numel() < n or t.dtype != dtype:
-            t = torch.empty((n,), dtype=dtype, device=self.m.device)
+            # 1/8 of head room: the row count of a step / an episode wanders by a few per cent, and every new maximum would otherwise
+            # free and re-allocate the slab (hipFree synchronises: tens of ms when the [R, 2 ff] ones move)
+            t = torch.empty((n + n // 8 + 64,), dtype=dtype, device=self.m.device)
             self._slab[tag] = t
         return t[:n].view(*shape)
 
@@ -281,8 +283,12 @@ class PrefixEpisode:
             assert ids_list[b][:lp] == P["ids"][b], "the prompt does not start with the prefix registered for this episode"
             assert lp < len(ids_list[b]) <= cap, "prompt longer than the cache (left truncation is not supported in this mode)"
             n.append(len(ids_list[b]) - lp)
+        # the step's rows are PACKED, sample after sample (round 3b; round 2 padded every sample to the longest suffix: 6.8 % of the
+        # steps' rows at the bench shape were padding that went through every GEMM and row kernel of the step)
         N = max(n)
-        M = B * N
+        off = np.zeros(B + 1, np.int64)
+        off[1:] = np.cumsum(n)
+        M = int(off[B])
         junk = B * cap
         ids_new = np.full(M, self.m.cfg.pad_token_id, np.int32)
         vix_new = np.full(M, -1, np.int32)
@@ -292,14 +298,13 @@ class PrefixEpisode:
         last = np.zeros(B, np.int32)
         for b in range(B):
             lp = int(P["lens"][b])
-            s, e = b * N, b * N + n[b]
+            s, e = int(off[b]), int(off[b + 1])
             ids_new[s:e] = ids_list[b][lp:]
             vix_new[s:e] = vis_idx_list[b][lp:]
             ar = np.arange(lp, lp + n[b], dtype=np.int32)
             pos_new[s:e] = ar
             crow[s:e] = b * cap + ar
             grow[s:e] = b * cap + ar
-            grow[e:b * N + N] = b * cap
             last[b] = e - 1
         tok_rows = np.flatnonzero(vix_new >= 0)
         R = 0 if vis_all is None else int(vis_all.shape[0])
@@ -309,7 +314,7 @@ class PrefixEpisode:
         packed = np.concatenate([ids_new, vix_new, pos_new, crow, grow, last, vis_rows])
         idx = ops.h2d(torch.from_numpy(packed), self.m.device)
         parts = [idx[k * M:(k + 1) * M] for k in range(5)] + [idx[5 * M:5 * M + B], idx[5 * M + B:]]
-        step = dict(M=M, N=N, n=n, Lmax=int(max(int(P["lens"][b]) + n[b] for b in range(B))), qmin=(int(P["lens"].min()) // 128) * 128,
+        step = dict(M=M, N=N, n=n, off=[int(x) for x in off[:B]], Lmax=int(max(int(P["lens"][b]) + n[b] for b in range(B))), qmin=(int(P["lens"].min()) // 128) * 128,
                     ids=parts[0], vix=parts[1], pos=parts[2], crow=parts[3], grow=parts[4], last=parts[5], vis_rows=parts[6],
                     ids_np=ids_new)
         self.stats["suffix_rows"].append(int(sum(n)))
@@ -557,10 +562,11 @@ class PrefixEpisode:
             epi_tab = lse_tab = None
             # (the one-launch kernels keep a step table of 128 entries and 1536 statistics rows in LDS: longer episodes / blocks take
             # the per-step path)
-            if os.environ.get("NAVILLM_EPISODE_ATTN_BWD", "episode") != "steps" and len(recs) <= 128 and Mz // B <= 1536:
+            Nz = max(r["step"]["N"] for r in recs)
+            if os.environ.get("NAVILLM_EPISODE_ATTN_BWD", "episode") != "steps" and len(recs) <= 128 and Nz <= 1536:
                 # where every step's block sits (r0 | rows per sample | live rows of each sample) and, per layer, where its lse is
                 T = len(recs)
-                tab = np.concatenate([np.array([r["r0"] for r in recs], np.int32), np.array([r["step"]["N"] for r in recs], np.int32),
+                tab = np.concatenate([np.array([[r["r0"] + o for o in r["step"]["off"]] for r in recs], np.int32).reshape(-1),
                                       np.array([r["step"]["n"] for r in recs], np.int32).reshape(-1)])
                 ptrs = np.array([[self.lse_s[r["k"]][i].data_ptr() for r in recs] for i in range(L)], dtype=np.int64)
                 epi_tab = ops.h2d(torch.from_numpy(tab), m.device)
@@ -592,7 +598,7 @@ class PrefixEpisode:
                     # ONE launch per kernel for all the steps, reading the episode buffers in place: the prefix key blocks walk every
                     # step's queries and STORE the fp32 sum in dkv_acc; dQ and the steps' own dK|dV land in dqkv through RoPE^T
                     ops.attn_bwd_episode(E["qkv"][:R], E["attn"][:R], dattn, dqkv, lse_tab[i], P["cu"], epi_tab, self.dkv_acc[i], len(recs), B, H, hd,
-                                         cap, Mp, Lp_max, Mz // B, rope=(m.rope_cos, m.rope_sin))
+                                         cap, Mp, Lp_max, Nz, rope=(m.rope_cos, m.rope_sin))
                 else:
                     self._attn_bwd_by_step(i, recs, E, dattn, dqkv, zeros_md)
                 ops.kv_grad_inject(dqkv[:Mp], self.dkv_acc[i], P["crow"])

@@ -303,7 +303,7 @@ def attn_bwd_episode(qkv, out, dout, dqkv, lse_ptrs_i64, cu_i32, tab_i32, kv_acc
     """attention backward of all T steps of a prefix-reuse episode for one layer (nv_attn_bwd_episode_bf16): rows [Mp, R) of dqkv and
     the fp32 prefix K/V gradient sums in kv_acc are written; rope = (cos, sin) applies RoPE^T to dQ / dK as they are stored"""
     R = qkv.shape[0]
-    assert out.shape[0] == R and dout.shape[0] == R and dqkv.shape[0] == R and lse_ptrs_i64.numel() == T and tab_i32.numel() == 2 * T + T * B
+    assert out.shape[0] == R and dout.shape[0] == R and dqkv.shape[0] == R and lse_ptrs_i64.numel() == T and tab_i32.numel() == 2 * T * B
     ws = _workspace(max(R - Mp, 1) * H * 4, qkv.device, "attn_episode")
     cos, sin = (rope[0].data_ptr(), rope[1].data_ptr()) if rope is not None else (0, 0)
     if rope is not None:

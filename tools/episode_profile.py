@@ -4,7 +4,7 @@ import os
 import sys
 import time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("NAVILLM_PKG_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (A/B runs: another checkout)
 from navillm_amd import config as nvcfg
 from navillm_amd.nav_model import NavModel
 from navillm_amd.losses import CrossEntropyLoss
