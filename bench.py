@@ -159,7 +159,7 @@ MODE_WHAT = {
                     "through the LM forward ONCE (K/V cached per layer); every nav step pushes only its suffix rows (history, candidates, "
                     "hints, <cls_1>) forward over the cache and its backward() records the gradient of its B output rows; finish_episode() then "
                     "walks the layers ONCE for every token row of the episode (prefix + all steps' rows: dgrad and ONE weight-gradient GEMM "
-                    "per weight over ~8 300 rows, the attention backward per step over the cache, each step's visual-token gradient sent "
+                    "per weight over ~7 700 rows, the attention backward of all steps in one launch per kernel, each step's visual-token gradient sent "
                     "into that step's scene-encoder graph) (navillm_amd/episode.py).  Same losses and gradients as the per-step recompute up to bf16 rounding order -- the weights "
                     "are frozen inside an episode (train.py:86-89) -- pinned to the reference's own 3-step episode by fixture G12 "
                     "(tests/test_parity_gpu.py::test_g12_episode_accumulated_gradients_vs_reference[prefix_reuse])",
