@@ -124,6 +124,35 @@ def _worker(rank, world, port, q):
     ok &= all_mean(2) and not ddp._pending
     ddp.flush()
     ok &= all_mean(2)
+    # ---- a backward that runs OUTSIDE the autograd engine (navillm_amd/episode.py::finish_episode in its default form: the steps'
+    # backward() calls only record output gradients; finish_episode() walks the layers itself inside final_backward(), hands every
+    # finished layer to the wrapper and closes the exchange by hand)
+    st.zero_grad()
+    with ddp.final_backward():
+        ddp.on_deferred_backward_begin()
+        for i in reversed(range(cfg.num_layers)):
+            s, e = st.layer_slice(i)
+            st.grad["lm"][s:e] += 2.0 * (rank + 1) * (i + 1)
+            ddp.on_layer_done(i, [])
+        st.grad["f32"] += 2.0 * (rank + 1) * 0.5
+        st.grad["lm"][:st.layer_slice(0)[0]] += 2.0 * (rank + 1) * 7.0
+        ok &= ddp._exchanging()
+        ddp._finalize()
+    ok &= all_mean(2) and not ddp._pending
+    ddp.flush()                                                     # nothing pending: the optimizer's flush must not average again
+    ok &= all_mean(2)
+    # ... and without final_backward(): nothing moves until the optimizer's flush
+    st.zero_grad()
+    ddp.on_deferred_backward_begin()
+    for i in reversed(range(cfg.num_layers)):
+        s, e = st.layer_slice(i)
+        st.grad["lm"][s:e] += 1.0 * (rank + 1) * (i + 1)
+        ddp.on_layer_done(i, [])
+    st.grad["f32"] += 1.0 * (rank + 1) * 0.5
+    st.grad["lm"][:st.layer_slice(0)[0]] += 1.0 * (rank + 1) * 7.0
+    ok &= all_local(1) and ddp._pending and not ddp._exchanging()
+    ddp.flush()
+    ok &= all_mean(1) and not ddp._pending
     # ---- which tensors AdamW updates must agree across ranks (`obj_projector` is touched only when the LOCAL batch
     # carries objects): the union over ranks is taken before the optimizer assigns step counts
     st.touched.clear()
