@@ -11,10 +11,11 @@ So the prefix's hidden states, K and V are the same tensors at every step, and t
   sum_t dL_t/dW  =  sum_t [suffix_t part]  +  backprop_prefix( sum_t dL_t/d(K,V of the prefix) )
 because backpropagation is linear in the upstream gradient.  This module does exactly that:
   begin()   prefix forward once (activations kept; post-RoPE K/V written into a per-layer cache in HBM);
-  step      only the step's suffix rows (history entries, candidates, hints, <cls_1>: ~70-130 tokens) go through the layers,
-            attending to the cached prefix; their backward runs immediately (per-step `loss.backward()` as in the reference)
-            and ADDS the K/V gradients it sends into the prefix rows to an fp32 accumulator per layer;
-  finish()  ONE backward through the prefix with the accumulated K/V gradients injected at every layer.
+  step      only the step's suffix rows (history entries, candidates, hints, <cls_1>: ~60-130 tokens) go through the layers,
+            attending to the cached prefix; the K/V gradients they send into the prefix rows are summed in fp32 per layer (by the
+            step's own backward, or -- default -- by finish());
+  finish()  ONE backward through the prefix with the accumulated K/V gradients injected at every layer (default: through every
+            token row of the episode, see "Round 3b" below).
 Per episode of 6 steps: 530 + 6*120 token-rows forward and backward instead of 6*650 -- about a third of the GEMM work --
 at the price of keeping the prefix activations and caches resident (288 GB of HBM make that a non-issue: 17 GB at 7B, B=8).
 
@@ -24,26 +25,28 @@ differences only: identical up to bf16 rounding of the rotated q/k, as in navill
 the prefix's weight gradients (one GEMM over the summed upstream gradient instead of six accumulations).  Parity against the
 per-step recompute is asserted in tests/test_episode_gpu.py (logits per step, every gradient buffer after the episode).
 
-Weight gradients are DEFERRED (round 3, `NAVILLM_EPISODE_DEFER_WGRAD=0` restores the per-step form): a suffix step has only
+Weight gradients are DEFERRED (round 3, `NAVILLM_EPISODE_DEFER=wgrad`; `none` restores the per-step form): a suffix step has only
 ~500-900 token rows, so its four weight-gradient GEMMs per layer contract over 8-14 K-tiles -- three rounds of 256x256 output
 tiles that are all prologue, epilogue and a read-modify-write of the 400 MB gradient slice.  With 288 GB of HBM the GEMM
 operands can simply stay: every step leaves its Linear inputs (n1, attn, n2, h) and output gradients (dqkv, dx1, dgu, dx) in
-per-layer episode buffers behind the prefix's rows (131 KB per token row and layer: 36 GB at 7B for a 6-step episode of B=8),
-and `finish()` runs ONE weight-gradient GEMM per weight over all ~8 300 rows of the episode -- fp32 accumulation across the
-whole episode and a single bf16 rounding, where the per-step form (and the reference's autograd) round after every step.
+per-layer episode buffers behind the prefix's rows (131 KB per token row and layer: ~33 GB at 7B for a 6-step episode of B=8),
+and `finish()` runs ONE weight-gradient GEMM per weight over all rows of the episode -- fp32 accumulation across the whole
+episode and a single bf16 rounding, where the per-step form (and the reference's autograd) round after every step.
 
-Round 3b: the WHOLE backward of the suffix steps is deferred too (`NAVILLM_EPISODE_DEFER=all`, the default; `wgrad` = only the
-weight gradients as above, `none` = everything step by step).  A step's `backward()` then only records the gradient of its B
-output rows; `finish()` walks the layers ONCE for every token row of the episode -- prefix rows and all steps' blocks side by
-side, ~8 300 rows -- so the four dgrad GEMMs per layer and the row kernels run at large-M efficiency instead of six times at
-M ~ 670 (the attention backward stays per step: each step's rows are put back into the K/V cache and differentiated over the
-cache layout, the prefix's own causal attention separately), and each step's visual-token gradient is then sent into that
-step's scene-encoder / fusion graph, which was kept alive (the step's forward hands the LM a detached copy).  Nothing reads
-`.grad` between the steps of an episode -- `optimizer.step()` only runs after it (train.py:86-89) -- so the result is the same
-sum of gradients.  What is kept per token row and layer: x, n1, qkv, attn, x1, n2, gu, h (131 KB at 7B) + the per-step lse.
+Round 3b: the WHOLE backward of the suffix steps is deferred too (`NAVILLM_EPISODE_DEFER=all`, the default).  A step's
+`backward()` then only records the gradient of its B output rows; `finish()` walks the layers ONCE for every token row of the
+episode -- prefix rows and all steps' blocks side by side, ~7 700 rows -- so the four dgrad GEMMs per layer and the row kernels
+run at large-M efficiency instead of six times at M ~ 600, the attention backward of ALL steps is one launch per kernel over
+these row buffers (nv_attn_bwd_episode_bf16; `NAVILLM_EPISODE_ATTN_BWD=steps`: one strided backward per step over the K/V
+cache), the prefix's own causal attention separately, and each step's visual-token gradient is then sent into that step's
+scene-encoder / fusion graph, which was kept alive (the step's forward hands the LM a detached copy).  Nothing reads `.grad`
+between the steps of an episode -- `optimizer.step()` only runs after it (train.py:86-89) -- so the result is the same sum of
+gradients.  What is kept per token row and layer: x, n1, qkv, attn, x1, n2, gu, h (131 KB at 7B) + the per-step lse.  A step's
+rows are packed sample after sample (no padding to the longest suffix).
 
-This is an OPTIONAL mode (`NavModel.begin_episode`): the default training path, `bench.py`'s `value` included, recomputes the
-full prompt at every step like the reference.
+`NavModel.begin_episode` / `finish_episode` switch it on per episode; `bench.py` measures it by default (`--mode prefix_reuse`)
+and the reference's per-step recompute beside it (`--mode recompute`).  Its gradients are pinned to the reference's own run of a
+3-step episode by fixture G12 (tests/test_parity_gpu.py).
 """
 import os
 
