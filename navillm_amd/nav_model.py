@@ -274,8 +274,10 @@ class NavModel(nn.Module):
     def begin_episode(self, prefix_ids, capacity=1024):
         """prefix_ids: B lists of token ids -- the part of every navigation prompt of the coming episode that never changes
         (everything up to "### History:").  Until `finish_episode()`, training-mode `model('navigation' | 'object_grounding')`
-        calls push only the rest of each prompt through the LM, over the cached prefix; their `backward()`s accumulate the
-        prefix's K/V gradients, and `finish_episode()` runs the prefix's one backward.  Exact up to bf16 rounding order."""
+        calls push only the rest of each prompt through the LM, over the cached prefix; `finish_episode()` runs the prefix's one
+        backward -- and, in the default `NAVILLM_EPISODE_DEFER=all` form, the steps' LM backward with it: ALL parameter gradients of
+        the episode appear there, the steps' `backward()` calls only record their output gradients (navillm_amd/episode.py).
+        Exact up to bf16 rounding order; call it before `optimizer.step()`."""
         from .episode import PrefixEpisode
         B = len(prefix_ids)
         if self.episode is None or self.episode.B != B or self.episode.cap != capacity:
