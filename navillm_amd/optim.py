@@ -144,7 +144,18 @@ class FlatAdamW(torch.optim.Optimizer):
     def lr(self):
         return self.param_groups[0]["lr"]
 
+    def _no_open_episode(self):
+        """prefix-reuse training (navillm_amd/episode.py) hands over its gradients -- in the default form ALL of the LM's -- at
+        `finish_episode()`: an update in front of it would silently train on the encoder's gradients alone"""
+        ep = getattr(self.model, "episode", None)
+        P = getattr(ep, "prefix", None) if ep is not None else None
+        if P is not None and (P.get("kv_steps", 0) > 0 or any(r.get("dH") is not None for r in P.get("recs", ()))):
+            raise RuntimeError("optimizer step inside an open prefix-reuse episode: call model.finish_episode() (under "
+                               "`with model.final_backward():` when data-parallel) after the episode's last backward() and before "
+                               "clip_grad_norm_ / step, or model.episode_abort() to drop the episode")
+
     def _dp_flush(self):
+        self._no_open_episode()
         dp = getattr(self.model, "_dp", None)
         if dp is not None:
             dp.flush()                   # reduce="step": the mean over ranks of the accumulated gradient, once

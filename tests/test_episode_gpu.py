@@ -205,6 +205,22 @@ def test_prefix_episode_rejects_foreign_prompts_and_wrong_use():
         nav_step(m, CrossEntropyLoss(), ep, train=True, last=True)
     with pytest.raises(AssertionError, match="visual tokens"):
         m.begin_episode([[1, cfg.cand_token_id, 5], [1, 2, 3]])
+    # an optimizer step in front of finish_episode() would train on the encoder's gradients alone: refused
+    from navillm_amd.optim import FlatAdamW
+    opt = FlatAdamW(m, lr=1e-5)
+    ep2 = SyntheticEpisodes(cfg, 2, seed=4, instr_len=60, device=torch.device(DEV))
+    m.begin_episode(ep2.prefix_ids())
+    nav_step(m, CrossEntropyLoss(), ep2, train=True, last=False)
+    with pytest.raises(RuntimeError, match="finish_episode"):
+        opt.clip_grad_norm_(40.0)
+    with pytest.raises(RuntimeError, match="finish_episode"):
+        opt.step()
+    m.finish_episode()
+    opt.clip_grad_norm_(40.0); opt.step(); opt.zero_grad()           # fine now
+    m.begin_episode(ep2.prefix_ids())
+    nav_step(m, CrossEntropyLoss(), ep2, train=True, last=False)
+    m.episode_abort()
+    opt.step()                                                       # an aborted episode holds nothing back
 
 
 def test_episode_buffers_refuse_to_outgrow_the_device(monkeypatch):
