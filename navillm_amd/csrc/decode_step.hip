@@ -67,7 +67,8 @@ __global__ __launch_bounds__(PICK_T) void decode_pick_kernel(const bf16_t* __res
 // one block: the token picked for sample b goes to cache row b*cap + len[b] at position len[b]; dyn = {max len + 1, 128-aligned
 // first query row}; len += 1; cnt += 1.  A full cache (len == cap) sends the row to the junk row B*cap, stops growing, marks the sample
 // FINISHED (it emits `pad` from the next step on: its query would be read back from the shared junk row, i.e. be garbage) and
-// raises the sticky `overflow` word, which the host must check -- a full cache is an error of the caller, not a silent wrong answer.
+// raises the sticky `overflow` word (unless the sample had already finished), which the host must check -- a full cache is an error
+// of the caller, not a silent wrong answer.
 __global__ __launch_bounds__(64) void decode_advance_kernel(int* __restrict__ state, int B, int cap) {
     __shared__ int smax, smin;
     const int tid = threadIdx.x;
@@ -87,7 +88,12 @@ __global__ __launch_bounds__(64) void decode_advance_kernel(int* __restrict__ st
         grow[b] = b * cap + Lc;
         last[b] = b;
         if (!full) len[b] = L + 1;
-        else { state[B + b] = 1; state[7 * B + 3] = 1; }
+        else {
+            // a row that had ALREADY finished (eos) only emits `pad` from here on: its cache filling up while other samples still
+            // decode is not an error -- every token it emitted is valid
+            if (!state[B + b]) state[7 * B + 3] = 1;
+            state[B + b] = 1;
+        }
         atomicMax(&smax, Lc);
         atomicMin(&smin, Lc);
     }

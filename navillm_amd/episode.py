@@ -87,7 +87,8 @@ class _SuffixLM(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dH):
         if ctx.saved.get("batched"):
-            ctx.saved["dH"] = dH.contiguous().clone()
+            # accumulate: a second backward through the same step (retain_graph, two losses on one output) adds, as autograd would
+            ctx.saved["dH"] = dH.contiguous().clone() if ctx.saved["dH"] is None else ctx.saved["dH"] + dH
             return None, None, None, None
         dvis = ctx.ep._step_backward(ctx.saved, dH.contiguous())
         return (dvis if ctx.has_vis else None), None, None, None
@@ -173,6 +174,15 @@ class PrefixEpisode:
             new.append(bufs)
             new32.append(b32)
             if self._E is not None:
+                if self._cursor and self.prefix is not None:
+                    # growing mid-episode: the prefix's saved activations are VIEWS of the old buffers -- point them at the copies,
+                    # or the old set stays alive until finish() and the fit check above under-estimates the peak
+                    a, Mp = self.prefix["layers"][i], self.prefix["Mp"]
+                    for name in list(a):
+                        if name in bufs:
+                            a[name] = bufs[name][:Mp]
+                    if b32:
+                        a["rstd1"], a["rstd2"] = b32["r1"][:Mp], b32["r2"][:Mp]
                 self._E[i] = None                      # release layer by layer: never two full copies resident
                 if self._E32 is not None:
                     self._E32[i] = None
@@ -210,12 +220,24 @@ class PrefixEpisode:
                 st.qkv(i, grad=True), st.g(p + "self_attn.o_proj.weight"), st.gate_up(i, grad=True), st.g(p + "mlp.down_proj.weight"),
                 st.g(p + "input_layernorm.weight"), st.g(p + "post_attention_layernorm.weight"))
 
+    def has_pending_gradients(self):
+        """an open episode whose steps ran a backward(): in the deferred forms those gradients exist only here until finish()"""
+        P = self.prefix
+        return P is not None and (P.get("kv_steps", 0) > 0 or any(r.get("dH") is not None for r in P.get("recs", ())))
+
+    def assert_no_pending_gradients(self, what):
+        if self.has_pending_gradients():
+            raise RuntimeError(f"{what} inside an open prefix-reuse episode whose steps already ran backward(): its LM / embedding / "
+                               "encoder gradients are handed over by model.finish_episode() -- call that first (under `with "
+                               "model.final_backward():` when data-parallel), or model.episode_abort() to drop the episode")
+
     # ------------------------------------------------------------------ prefix forward, once per episode
     @torch.no_grad()
     def begin(self, prefix_ids):
         """prefix_ids: B python lists of token ids (no visual tokens) -- the part of every prompt of this episode that never changes"""
         m, cfg, st = self.m, self.m.cfg, self.m.store
         B, cap, H, hd, eps, L = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers
+        self.assert_no_pending_gradients("begin_episode()")
         assert len(prefix_ids) == B
         lens = np.array([len(p) for p in prefix_ids], dtype=np.int32)
         assert lens.min() > 0 and lens.max() < cap

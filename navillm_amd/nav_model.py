@@ -156,6 +156,7 @@ class NavModel(nn.Module):
         self._gen_kv = None              # K/V cache object kept between generate() calls
         self.flop_log = None             # bench: list of ("lm", tokens, sum of S_b^2, backward?) / ("lm_head", rows, backward?) per LM call
         self.attn_hf_rounding = False    # tests only: attention forward through the parity instrument nv_attn_fwd_hfround_bf16
+        self.rope_frame = "batch"        # tests only: "sample" = RoPE positions from each sample's first token in the packed _lm path
         self.kv = None                   # KVCacheLM (enable_kv_cache): prefix reuse across no-grad navigation steps + generation
         self._wgrad_stream = None
         self._dp = None
@@ -273,13 +274,17 @@ class NavModel(nn.Module):
     # ---- optional training mode: the prompt's static prefix is computed once per episode (navillm_amd/episode.py)
     def begin_episode(self, prefix_ids, capacity=1024):
         """prefix_ids: B lists of token ids -- the part of every navigation prompt of the coming episode that never changes
-        (everything up to "### History:").  Until `finish_episode()`, training-mode `model('navigation' | 'object_grounding')`
-        calls push only the rest of each prompt through the LM, over the cached prefix; `finish_episode()` runs the prefix's one
+        (everything up to "### History:").  Until `finish_episode()`, training-mode `model('navigation')` calls push only the rest
+        of each prompt through the LM, over the cached prefix (every other mode -- object_grounding included -- takes the full `_lm`
+        path: its gradients land in `.grad` at once, as always); `finish_episode()` runs the prefix's one
         backward -- and, in the default `NAVILLM_EPISODE_DEFER=all` form, the steps' LM backward with it: ALL parameter gradients of
         the episode appear there, the steps' `backward()` calls only record their output gradients (navillm_amd/episode.py).
         Exact up to bf16 rounding order; call it before `optimizer.step()`."""
         from .episode import PrefixEpisode
         B = len(prefix_ids)
+        if self.episode is not None:
+            # a begin before the previous episode's finish would silently drop that episode's deferred gradients (ADVICE r3, medium)
+            self.episode.assert_no_pending_gradients("begin_episode()")
         if self.episode is None or self.episode.B != B or self.episode.cap != capacity:
             self.episode = PrefixEpisode(self, B, capacity)
         self.episode.begin(prefix_ids)
@@ -294,6 +299,15 @@ class NavModel(nn.Module):
         if self.episode is not None:
             self.episode.prefix = None
             self.episode._cursor = 0
+
+    def parameters(self, recurse=True):
+        """nn.Module.parameters, except that asking for the parameters while a prefix-reuse episode still HOLDS gradients (its steps
+        ran backward(), finish_episode() has not run) raises: the only caller of `model.parameters()` inside the reference's
+        training loop is `torch.nn.utils.clip_grad_norm_(model.parameters(), 40.)` (train.py:87), which would clip -- and the
+        optimizer then step on -- the encoder's gradients alone.  (FlatAdamW guards its own clip/step the same way.)"""
+        if self.episode is not None:
+            self.episode.assert_no_pending_gradients("model.parameters() [e.g. torch.nn.utils.clip_grad_norm_(model.parameters(), ...)]")
+        return super().parameters(recurse)
 
     def _lm_episode(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None):
         ids_l, vix_l, vis_all, _ = self._vis_layout(ids_cpu, am_cpu, cand_vis, hist_vis, obj_vis)
@@ -497,6 +511,11 @@ class NavModel(nn.Module):
             cu_np = np.zeros(B + 1, dtype=np.int32)
             cu_np[1:] = np.cumsum(lens_np)
             pos_np = np.broadcast_to(np.arange(S, dtype=np.int32)[None], (B, S)).reshape(-1)[keep_np]
+            if self.rope_frame == "sample":
+                # parity instrument (tests): positions counted from each sample's first token, the frame of the prefix-reuse /
+                # K/V-cache paths, instead of the reference's arange(S) over the left padding
+                pos_np = pos_np - np.repeat(kv_np, lens_np)
+                kv_start = torch.zeros(B, dtype=torch.int32)
             keep = torch.from_numpy(keep_np)
             flat = torch.from_numpy(ids_cpu.numpy().reshape(-1)[keep_np])
             self._row_map = keep

@@ -72,6 +72,9 @@ def reference_optimizer_to_flat(store, sd, names=None):
         raise ValueError(f"reference optimizer state: {len(idx)} parameters whose shapes fit none of the known parameter orders "
                          f"({[len(c) for c in cands]} names); pass names=names_from_model_state_dict(ckpt['model_state_dict'], cfg)")
     store.init_optimizer_state()
+    for buf in (store.exp_avg, store.exp_avg_sq):        # an optimizer that has already stepped: no stale moments for parameters the
+        for t in buf.values():                           # checkpoint has no entry for
+            t.zero_()
     steps = {}
     for j, k in enumerate(idx):
         st = sd["state"].get(k)
@@ -211,6 +214,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if "state" in sd and "param_groups" in sd and "exp_avg" not in sd:
             # a reference checkpoint's `optimizer` entry (tools/optims.py:26-29 calls exactly this method with it)
             self.step_count, self.born, hyper = reference_optimizer_to_flat(self.store, sd, names)
+            self.store.touched.clear()                   # (old flags would re-birth stale tensors at the next step)
             self.store.touched.update(self.born)
             self._segs_key = None
             self.param_groups[0].update(hyper)

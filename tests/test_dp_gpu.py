@@ -291,3 +291,82 @@ def test_two_rank_rehearsal_on_one_gpu_prints_one_n2_line():
     # other training mode (each with its own exchanges) and still agree on one line
     assert "6 + 1" in d["config"]["timed_window"] and d["whole_episodes"]["steps"] == 18 and d["whole_episodes"]["nav_steps_per_s"] > 0
     assert d["other_mode"]["mode"] == "recompute" and d["other_mode"].get("nav_steps_per_s_per_gpu", 0) > 0, d["other_mode"]
+
+
+def _prefix_episode(model, wrapped, seed, steps, dev=DEV):
+    """one prefix-reuse training episode (navillm_amd/episode.py, the bench's default mode): every step's backward() only records its
+    output gradient; ALL gradients of the episode appear in finish_episode(), which under the wrapper runs inside `final_backward()`
+    and launches the per-layer exchange from the deferred backward walk"""
+    from navillm_amd.synthetic import SyntheticEpisodes, prefix_reuse_episode
+    from navillm_amd.losses import CrossEntropyLoss
+    ep = SyntheticEpisodes(model.cfg, 3, seed=seed, instr_len=150, device=torch.device(dev))
+    model.zero_grad()
+    torch.manual_seed(1)
+    prefix_reuse_episode(wrapped, CrossEntropyLoss(), ep, steps)
+    torch.cuda.synchronize()
+    return {k: v.clone() for k, v in model.store.grad.items()}
+
+
+def _shared_gpu_rank_prefix(rank, world, port, q, steps_by_rank):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      NAVILLM_COMM="torch")
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.parallel import init_distributed_device, NavDataParallel
+    from navillm_amd.optim import FlatAdamW
+    dev, r, w = init_distributed_device(backend="gloo", device_index=0)
+    model = NavModel(nav_config=_cfg(), device=dev, seed=4 + rank)
+    model.train()
+    ddp = NavDataParallel(model, reduce="step")
+    p0 = {k: v.clone().cpu() for k, v in model.store.param.items()}
+    g = _prefix_episode(model, ddp, 100 + rank, steps_by_rank[rank], dev=str(dev))
+    pending = ddp._pending
+    opt = FlatAdamW(model, lr=1e-3)
+    opt.clip_grad_norm_(40.0)
+    torch.cuda.synchronize()
+    g_after = {k: v.clone().cpu() for k, v in model.store.grad.items()}
+    opt.step()
+    torch.cuda.synchronize()
+    p1 = {k: v.clone().cpu() for k, v in model.store.param.items()}
+    pack = lambda d: {k: v.detach().cpu().float().numpy() for k, v in d.items()}
+    q.put((rank, pack(g), pack(g_after), pack(p0), pack(p1), pending))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_world2_shared_gpu_prefix_reuse_episode_mean_and_replica_consistency():
+    """the HEADLINE training mode under data parallelism with two real ranks and the real kernels.  Rank 0 runs a
+    2-step episode, rank 1 a 3-step one (ranks may run different numbers of nav steps, mp3d_agent.py:661-676: only the final backward
+    synchronises); the exchange is launched from inside finish_episode()'s deferred backward walk under final_backward().  After it both
+    ranks hold bit-identical gradients == the mean of the two single-rank prefix-reuse gradients, nothing is left for the optimizer's
+    flush, and after clip + AdamW the replicas are bit-identical."""
+    import torch.multiprocessing as mp
+    from navillm_amd.nav_model import NavModel
+    world, steps_by_rank = 2, (2, 3)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_gpu_rank_prefix, args=(r, world, port, q, steps_by_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+    unpack = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    (_, g0, ga0, p00, p10, pend0), (_, g1, ga1, p01, p11, pend1) = [(r_[0],) + tuple(unpack(x) for x in r_[1:5]) + (r_[5],) for r_ in res]
+    model = NavModel(nav_config=_cfg(), device=torch.device(DEV), seed=4)
+    model.train()
+    a = _prefix_episode(model, model, 100, steps_by_rank[0])
+    b = _prefix_episode(model, model, 101, steps_by_rank[1])
+    assert not pend0 and not pend1, "the exchange must have run from inside finish_episode() (final_backward), not be left to the flush"
+    for k in a:
+        assert torch.equal(p00[k], p01[k]), "parameters were not broadcast from rank 0"
+        assert torch.equal(g0[k], g1[k]), f"ranks disagree on the averaged gradient buffer {k}"
+        assert torch.equal(g0[k], ga0[k]) and torch.equal(g1[k], ga1[k]), "the optimizer's flush averaged a second time"
+        want = (a[k].float() + b[k].float()).cpu() * 0.5
+        got = g0[k].float()
+        err, scale = (got - want).abs().max().item(), want.abs().max().item()
+        assert err <= 0.01 * scale + 1e-6, (k, err, scale)
+        assert (got - a[k].float().cpu()).abs().max().item() > 1e-3 * scale      # a real mean, not rank 0's own gradient
+    for k in p10:
+        assert torch.equal(p10[k], p11[k]), f"replicas diverged after the optimizer step ({k})"
+        assert not torch.equal(p10[k], p00[k])

@@ -1,0 +1,375 @@
+"""GPU, round 4 (VERDICT r3 "next" #1): the HEADLINE training mode (`prefix_reuse`, navillm_amd/episode.py) gets the parity evidence
+the per-step recompute already had.
+
+  (a) FULL 32-layer Vicuna-7B, B = 8, a 3-step training episode (BASELINE config 2): `prefix_reuse` vs `recompute` (logits per step,
+      every gradient buffer) and BOTH against the CPU oracle's bf16 (= the reference's rounding points) and fp32 logits at every step,
+      action selection argmax-exact over all 24 rows wherever the oracle's margin allows (tasks/agents/mp3d_agent.py:726-757).
+  (b) accumulated GRADIENTS of a 2-step episode through 8 Vicuna-7B-width layers against the oracle's autograd in bf16 and fp32, both
+      modes (train.py:86-89: gradients accumulate over the steps of an episode).
+  (c) the one formulation difference between the two modes' forward that is not a summation order -- the RoPE position FRAME (the
+      reference numbers positions over the batch's left padding, the prefix-reuse path from each sample's first token) -- isolated: the
+      recompute path run in the sample frame.
+  + the guards around an open episode.
+"""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from util import (gold, T, tiny_cfg, meta_of, load_oracle, GOLDEN_SEED, bf16_ulps_at_scale, episode_step_batch)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).norm() / (b.norm() + 1e-20)).item()
+
+
+def _rel_cos_big(a, b, chunk=1 << 28):
+    """(relative error, cosine, |b|) of two flat buffers of up to 6.7e9 elements without widening them whole"""
+    a, b = a.reshape(-1), b.reshape(-1)
+    dd = aa = bb = ab = 0.0
+    for o in range(0, a.numel(), chunk):
+        x, y = a[o:o + chunk].double(), b[o:o + chunk].double()
+        dd += float(((x - y) ** 2).sum()); aa += float((x * x).sum()); bb += float((y * y).sum()); ab += float((x * y).sum())
+    return (dd ** 0.5) / (bb ** 0.5 + 1e-30), ab / ((aa ** 0.5) * (bb ** 0.5) + 1e-30), bb ** 0.5
+
+
+def _hip_episode(m, cfg, B, steps, mode, seed, instr_len, frame="batch", ragged=0, keep_inputs=False, grad_names=()):
+    """one TRAINING episode of the synthetic rollout through the HIP model: per step panorama -> navigation -> CE / B -> backward(),
+    teacher forcing (the trajectory does not depend on the logits, so both modes and the oracle see the same inputs).
+    -> (per-step records, {group: flat gradient clone on the device}, {name: gradient on the host})"""
+    from navillm_amd.synthetic import SyntheticEpisodes
+    from navillm_amd.losses import CrossEntropyLoss
+    ep = SyntheticEpisodes(cfg, B, seed=seed, instr_len=instr_len, device=torch.device(DEV))
+    for b in range(B):
+        ep.instr[b] = ep.instr[b][: instr_len - ragged * b]
+    crit = CrossEntropyLoss()
+    m.zero_grad()
+    m.store.touched.clear()
+    m.rope_frame = frame
+    if mode == "prefix_reuse":
+        m.begin_episode(ep.prefix_ids())
+    recs = []
+    for t in range(steps):
+        pin = ep.panorama_inputs()
+        pano = m("panorama", pin)
+        pe, pm = pano["pano_embeds"], pano["pano_masks"]
+        ep.update_maps(pe, pm, pin["cand_vpids"])
+        nav = ep.nav_inputs(pe, pm, pin["cand_vpids"])
+        ids, am = ep.tokenise(nav, "<cls_1>")
+        nav["input_ids"], nav["attention_mask"] = ids, am
+        torch.manual_seed(900 + t)
+        out = m("navigation", nav)
+        lg = out["fuse_logits"]
+        tg = ep.teacher_targets(nav, last=False)
+        (crit(lg, tg.to(DEV)) / B).backward()
+        rec = dict(logits=lg.detach().float().cpu(), targets=tg.clone(), S=int(ids.shape[1]))
+        if keep_inputs:
+            cpu = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in nav.items()}
+            cpu["hist_vis"] = [[v.detach().cpu() for v in vis] for vis in nav["hist_vis"]]
+            cpu["history"] = [list(h) for h in nav["history"]]
+            rec.update(nav=cpu, ids=ids.clone(), am=am.clone(), pin={k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in pin.items()},
+                       fuse_embeds=out["fuse_embeds"].detach().cpu())
+        recs.append(rec)
+        ep.advance(nav, tg, out["fuse_embeds"])
+    if mode == "prefix_reuse":
+        m.finish_episode()
+        assert m.episode.prefix is None
+    m.rope_frame = "batch"
+    torch.cuda.synchronize()
+    flat = {g: t.detach().clone() for g, t in m.store.grad.items()}
+    named = {n: m.store.g(n).detach().float().cpu().clone() for n in grad_names}
+    return recs, flat, named
+
+
+def _oracle_logits(O, P, c, rec, t):
+    torch.manual_seed(900 + t)
+    with torch.no_grad():
+        return O.navigation(P, c, rec["nav"], rec["ids"], rec["am"])["fuse_logits"]
+
+
+class _LazyF32(dict):
+    """fp32 view of a bf16 weight dict, one tensor at a time (the oracle only indexes `P[name]`)"""
+
+    def __init__(self, P16):
+        super().__init__()
+        self._p = P16
+
+    def __getitem__(self, k):
+        return self._p[k].float()
+
+    def __contains__(self, k):
+        return k in self._p
+
+
+def test_full_depth_7b_b8_episode_prefix_reuse_vs_recompute_vs_oracle():
+    """(a) -- see the module docstring.  What a 32-layer random-weight decoder does to a last-bit difference is known (DESIGN.md §2
+    Determinism: packed vs padded rows of the SAME path differ by 0.23 in the logits at full depth), so the criterion at full depth is the
+    distance to the fp32 TRUTH relative to the bf16 oracle's own distance to it, and argmax agreement -- for both modes alike."""
+    from navillm_amd import config as nvcfg
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.params import synth_state_dict
+    O = load_oracle()
+    cfg = nvcfg.vicuna_7b(image_feat_size=768)
+    B, steps = 8, 3
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=5)
+    m.eval()
+    P16 = synth_state_dict(cfg, 5)
+    with torch.no_grad():
+        assert m.load_reference_state_dict(P16) == len(P16)
+    rc, g_rc, _ = _hip_episode(m, cfg, B, steps, "recompute", 77, 512, keep_inputs=True)
+    pr, g_pr, _ = _hip_episode(m, cfg, B, steps, "prefix_reuse", 77, 512)
+    # gradients of the whole episode, prefix reuse vs recompute, per flat buffer + cosine
+    for g in g_rc:
+        rel, cos, nrm = _rel_cos_big(g_pr[g], g_rc[g])
+        print(f"[7b-full-depth-episode] gradient buffer '{g}' prefix_reuse vs recompute: rel {rel:.4f}  cosine {cos:.5f}  |g| {nrm:.4e}")
+        # full depth amplifies last-bit differences (the SAME path, packed vs padded rows: 7.7 % in gradient norm)
+        assert rel < 0.15 and cos > 0.99, (g, rel, cos)
+    del g_rc, g_pr
+    torch.cuda.empty_cache()
+    cfg32 = nvcfg.NavConfig(**{**cfg.__dict__, "precision": "fp32"})
+    P32 = _LazyF32(P16)
+    decided_all = agree_rc = agree_pr = rows = 0
+    for t in range(steps):
+        t0 = time.time()
+        o16 = _oracle_logits(O, P16, cfg, rc[t], t)
+        t1 = time.time()
+        o32 = _oracle_logits(O, P32, cfg32, rc[t], t)
+        t2 = time.time()
+        fin = torch.isfinite(o16)
+        scale = float(o16[fin].abs().max())
+        ulp = 2.0 ** (int(np.floor(np.log2(scale))) - 7)
+        e_ref = (o16[fin] - o32[fin]).abs().max().item()
+        line = f"[7b-full-depth-episode step {t}] S={rc[t]['S']} oracle bf16 {t1 - t0:.0f} s / fp32 {t2 - t1:.0f} s; |orc16-orc32|={e_ref:.4f}"
+        gaps = {}
+        for tag, rec in (("recompute", rc[t]), ("prefix_reuse", pr[t])):
+            lg = rec["logits"]
+            assert torch.equal(torch.isfinite(lg), fin)
+            e_hip = (lg[fin] - o32[fin]).abs().max().item()
+            gap = (lg[fin] - o16[fin]).abs().max().item()
+            gaps[tag] = gap
+            line += f"; {tag}: |hip-orc32|={e_hip:.4f} (ratio {e_hip / e_ref:.2f}) |hip-orc16|={gap:.4f} = {gap / ulp:.1f} spacings"
+            # as close to the truth as the reference's own bf16 evaluation (x1.25 + one output spacing), both modes
+            assert e_hip <= 1.25 * e_ref + ulp, (tag, t, e_hip, e_ref, ulp)
+        hh = (pr[t]["logits"][fin] - rc[t]["logits"][fin]).abs().max().item()
+        line += f"; prefix_reuse vs recompute {hh:.4f} = {hh / ulp:.1f} spacings at the logit scale {scale:.2f}"
+        print(line)
+        top2 = torch.topk(o16.masked_fill(~fin, -1e9), 2, dim=1).values
+        for b in range(B):
+            rows += 1
+            a16 = int(o16[b].argmax())
+            agree_rc += int(rc[t]["logits"][b].argmax()) == a16
+            agree_pr += int(pr[t]["logits"][b].argmax()) == a16
+            if (top2[b, 0] - top2[b, 1]).item() > 2 * max(gaps.values()):
+                decided_all += 1
+                assert int(rc[t]["logits"][b].argmax()) == a16, ("recompute", t, b)
+                assert int(pr[t]["logits"][b].argmax()) == a16, ("prefix_reuse", t, b)
+    print(f"[7b-full-depth-episode] argmax vs the bf16 oracle over {rows} rows: recompute {agree_rc}, prefix_reuse {agree_pr} agree; "
+          f"{decided_all} rows have a top-2 margin > 2 x the larger gap (asserted exact there)")
+    del m
+    torch.cuda.empty_cache()
+
+
+GRAD_NAMES = ["out_head.0.weight", "lang_model.model.layers.0.self_attn.q_proj.weight", "lang_model.model.layers.0.self_attn.k_proj.weight",
+              "lang_model.model.layers.3.mlp.gate_proj.weight", "lang_model.model.layers.7.self_attn.v_proj.weight",
+              "lang_model.model.layers.7.mlp.down_proj.weight", "lang_model.model.layers.4.input_layernorm.weight",
+              "img_embeddings.mapper.weight", "img_embeddings.img_linear.weight", "gmap_pos_embeddings.0.weight"]
+
+
+def test_eight_layer_7b_width_episode_gradients_vs_oracle_autograd():
+    """(b): 8 decoder layers at Vicuna-7B width (d = 4096, 32 heads, ff = 11008), B = 2, 512-token instructions, a 2-step episode with
+    gradients accumulating over the steps: selected gradients (action head, first / middle / last decoder layers, a norm weight, the
+    encoder's mapper and input projection, the map-position embedding) of BOTH HIP training modes against the oracle's autograd on
+    the host in bf16 (the reference's rounding points) and fp32.  Asserted: each HIP gradient is as close to the fp32 gradient as the
+    oracle's own bf16 gradient is (x1.5 + 2 %), and within 6 % of the bf16 oracle's."""
+    from navillm_amd import config as nvcfg
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.params import synth_state_dict
+    O = load_oracle()
+    cfg = nvcfg.vicuna_7b(image_feat_size=768, num_layers=8, base_vocab_size=2000)
+    B, steps = 2, 2
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=5)
+    m.eval()
+    P16 = synth_state_dict(cfg, 5)
+    with torch.no_grad():
+        assert m.load_reference_state_dict(P16) == len(P16)
+    rc, _, n_rc = _hip_episode(m, cfg, B, steps, "recompute", 83, 512, ragged=37, keep_inputs=True, grad_names=GRAD_NAMES)
+    pr, _, n_pr = _hip_episode(m, cfg, B, steps, "prefix_reuse", 83, 512, ragged=37, grad_names=GRAD_NAMES)
+    del m
+    torch.cuda.empty_cache()
+    cfg32 = nvcfg.NavConfig(**{**cfg.__dict__, "precision": "fp32"})
+    og = {}
+    for prec, c in (("bf16", cfg), ("fp32", cfg32)):
+        t0 = time.time()
+        P = {k: (v.float() if prec == "fp32" else v.clone()).requires_grad_(k in GRAD_NAMES) for k, v in P16.items()}
+        for t in range(steps):
+            r = rc[t]
+            pin = r["pin"]
+            pano = O.scene_encoder(P, cfg32, pin["view_img_fts"], pin["view_lens"], pin["loc_fts"], pin["nav_types"])
+            nav = dict(r["nav"])
+            pe = pano["pano_embeds"]
+            nav["vp_img_embeds"] = torch.cat([torch.zeros_like(pe[:, :1]), pe], 1)       # NOT detached (mp3d_agent.py:268-270)
+            torch.manual_seed(900 + t)
+            out = O.navigation(P, c, nav, r["ids"], r["am"])
+            if prec == "bf16":
+                u = bf16_ulps_at_scale(r["logits"], out["fuse_logits"].detach())
+                v = bf16_ulps_at_scale(pr[t]["logits"], out["fuse_logits"].detach())
+                print(f"[8-layer step {t}] logits vs the bf16 oracle: recompute {u:.2f}, prefix_reuse {v:.2f} bf16 spacings")
+            (O.action_loss(out["fuse_logits"], r["targets"]) / B).backward()
+        og[prec] = {n: P[n].grad.detach().float().clone() for n in GRAD_NAMES}
+        print(f"[8-layer] oracle {prec} episode (forward + backward x {steps}): {time.time() - t0:.0f} s")
+        del P
+    worst = {}
+    for n in GRAD_NAMES:
+        base = _rel(og["bf16"][n], og["fp32"][n])
+        line = f"[8-layer grad] {n}: |orc16-orc32| {base:.4f}"
+        for tag, g in (("recompute", n_rc[n]), ("prefix_reuse", n_pr[n])):
+            e16, e32 = _rel(g, og["bf16"][n]), _rel(g, og["fp32"][n])
+            line += f"; {tag} vs orc16 {e16:.4f} vs orc32 {e32:.4f}"
+            worst[tag] = max(worst.get(tag, 0.0), e16)
+            assert e32 <= 1.5 * base + 2e-2, (tag, n, e32, base)
+            assert e16 <= 6e-2, (tag, n, e16)
+        print(line)
+    print(f"[8-layer grad] worst rel err vs the bf16 oracle: {worst}")
+
+
+def _g12_run(m, zb, meta, mode, frame):
+    from navillm_amd.losses import CrossEntropyLoss
+    from test_parity_gpu import _g12_prefix_ids, pano_batch
+    B = meta["B"]
+    m.zero_grad()
+    m.store.touched.clear()
+    m.rope_frame = frame
+    crit = CrossEntropyLoss()
+    if mode == "prefix_reuse":
+        m.begin_episode(_g12_prefix_ids(zb, meta))
+    hist = [[] for _ in range(B)]
+    out_l = []
+    for t in range(len(meta["steps"])):
+        pre = f"s{t}/"
+        zt = {k[len(pre):]: v for k, v in zb.items() if k.startswith(pre)}
+        pano = m("panorama", pano_batch(zt))
+        batch, ms = episode_step_batch(zb, meta, t, pano["pano_embeds"], hist)
+        for k in ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_visited_masks", "gmap_masks", "pano_masks", "vp_pos_fts"):
+            batch[k] = batch[k].to(DEV)
+        batch["input_ids"], batch["attention_mask"] = T(zt["input_ids"]), T(zt["attention_mask"])
+        torch.manual_seed(ms["seed_before_nav"])
+        out = m("navigation", batch)
+        out_l.append(out["fuse_logits"].detach().float().cpu())
+        tg = torch.tensor(ms["targets"], device=DEV)
+        (crit(out["fuse_logits"], tg) * meta["train_ml"] / B / meta["accum"]).backward()
+        for b in range(B):
+            if ms["targets"][b] != -100:
+                hist[b].append(out["fuse_embeds"][b][ms["targets"][b]].detach())
+    if mode == "prefix_reuse":
+        m.finish_episode()
+    m.rope_frame = "batch"
+    torch.cuda.synchronize()
+    return out_l
+
+
+def test_rope_frame_isolated_on_the_reference_episode_g12():
+    """(c): VERDICT r3 weak #1.  Against the reference's own bf16 logits of the G12 episode the prefix-reuse mode measured up to 3.00
+    bf16 spacings where the per-step recompute measured 2.00.  The two forwards differ in summation order (tile cuts) and in ONE
+    formulation detail: the reference numbers RoPE positions over the batch's left padding (`arange(S)`, modified_lm.py:112-116 via HF),
+    the prefix-reuse path from each sample's first token (scores depend on position differences only; the bf16 rounding of the rotated
+    q / k does not).  Here the recompute path runs in BOTH frames: what the frame alone does to the distance from the reference is
+    printed and bounds what is asked of the prefix-reuse mode -- it must be no farther from the reference than the recompute path in
+    ITS frame (+ half a spacing for the summation order), and within 1.5 spacings of that run itself."""
+    from test_parity_gpu import build, ULPS_LOGITS
+    zb = gold("g12_episode_bf16.npz")
+    meta = meta_of(zb)
+    m = build(tiny_cfg("bf16"))
+    runs = {"recompute/batch": _g12_run(m, zb, meta, "recompute", "batch"),
+            "recompute/sample": _g12_run(m, zb, meta, "recompute", "sample"),
+            "prefix_reuse": _g12_run(m, zb, meta, "prefix_reuse", "batch")}
+    worst = {k: 0.0 for k in runs}
+    pr_vs_sample = 0.0
+    for t in range(len(meta["steps"])):
+        ref = T(zb[f"s{t}/fuse_logits"])
+        for k, v in runs.items():
+            worst[k] = max(worst[k], bf16_ulps_at_scale(v[t], ref))
+        pr_vs_sample = max(pr_vs_sample, bf16_ulps_at_scale(runs["prefix_reuse"][t], runs["recompute/sample"][t]))
+    print(f"[g12 rope frame] worst bf16 spacings from the REFERENCE's logits over the episode: {worst}; prefix_reuse vs recompute-in-the-"
+          f"sample-frame: {pr_vs_sample:.2f}")
+    assert worst["recompute/batch"] <= ULPS_LOGITS
+    assert worst["prefix_reuse"] <= max(worst["recompute/sample"], worst["recompute/batch"]) + 0.5
+    assert pr_vs_sample <= 1.5
+
+
+def test_rope_frame_isolated_at_7b_width():
+    """the same isolation where round 3 measured the largest HIP-vs-HIP gap (Vicuna-7B width, two layers: 2.3-3.0 spacings between the
+    modes): recompute in the batch frame vs recompute in the sample frame vs prefix reuse, ragged prompts (so the frames differ)."""
+    from navillm_amd import config as nvcfg
+    from navillm_amd.nav_model import NavModel
+    cfg = nvcfg.vicuna_7b(image_feat_size=768, num_layers=2, base_vocab_size=2000)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
+    m.eval()
+    kw = dict(seed=31, instr_len=180, ragged=23)
+    rb, gb, _ = _hip_episode(m, cfg, 3, 4, "recompute", frame="batch", **kw)
+    rs, gs, _ = _hip_episode(m, cfg, 3, 4, "recompute", frame="sample", **kw)
+    pr, gp, _ = _hip_episode(m, cfg, 3, 4, "prefix_reuse", **kw)
+    frame_eff = max(bf16_ulps_at_scale(rs[t]["logits"], rb[t]["logits"]) for t in range(4))
+    pr_vs_b = max(bf16_ulps_at_scale(pr[t]["logits"], rb[t]["logits"]) for t in range(4))
+    pr_vs_s = max(bf16_ulps_at_scale(pr[t]["logits"], rs[t]["logits"]) for t in range(4))
+    rel = {k: (_rel(gs["lm"], gb["lm"]), _rel(gp["lm"], gb["lm"]), _rel(gp["lm"], gs["lm"])) for k in ("lm",)}
+    print(f"[7b-width rope frame] logits, worst over 4 steps, bf16 spacings: recompute sample-frame vs batch-frame {frame_eff:.2f}; prefix_reuse vs "
+          f"recompute batch-frame {pr_vs_b:.2f}, vs recompute sample-frame {pr_vs_s:.2f}; LM gradient rel (sample vs batch, prefix vs batch, "
+          f"prefix vs sample): {rel['lm']}")
+    # the prefix-reuse mode is no farther from the reference formulation than a mere change of frame moves the reference formulation
+    # itself (+1 spacing: tile cuts, one GEMM over the episode's rows instead of per-step accumulations)
+    assert pr_vs_b <= frame_eff + 1.0, (pr_vs_b, frame_eff)
+
+
+def test_open_episode_guards():
+    """begin_episode() before finish_episode() used to drop the open episode's deferred gradients silently; the same
+    for a foreign `clip_grad_norm_(model.parameters())` (train.py:87) inside an open episode.  Both raise now; episode_abort() is the
+    explicit way out.  A second backward through the same step output ACCUMULATES (autograd semantics)."""
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step
+    from navillm_amd.losses import CrossEntropyLoss
+    from navillm_amd.nav_model import NavModel
+    from test_round2_gpu import _mid_cfg
+    cfg = _mid_cfg()
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=3)
+    m.eval()
+    crit = CrossEntropyLoss()
+    ep = SyntheticEpisodes(cfg, 2, seed=5, instr_len=60, device=torch.device(DEV))
+    m.zero_grad()
+    m.begin_episode(ep.prefix_ids())
+    list(m.parameters())                                   # nothing pending yet: fine
+    nav_step(m, crit, ep, train=True, last=False)
+    with pytest.raises(RuntimeError, match="finish_episode"):
+        m.begin_episode(ep.prefix_ids())
+    with pytest.raises(RuntimeError, match="finish_episode"):
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 40.0)
+    m.episode_abort()
+    m.begin_episode(ep.prefix_ids())                       # after an abort a new episode may begin
+    m.finish_episode()                                     # (no step ran: nothing to hand over)
+    # two backwards through one step's output: gradients add
+    res = []
+    for twice in (False, True):
+        epx = SyntheticEpisodes(cfg, 2, seed=9, instr_len=60, device=torch.device(DEV))
+        m.zero_grad()
+        m.begin_episode(epx.prefix_ids())
+        pin = epx.panorama_inputs()
+        with torch.no_grad():
+            pano = m("panorama", pin)
+        epx.update_maps(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+        nav = epx.nav_inputs(pano["pano_embeds"], pano["pano_masks"], pin["cand_vpids"])
+        nav["input_ids"], nav["attention_mask"] = epx.tokenise(nav, "<cls_1>")
+        torch.manual_seed(1)
+        lg = m("navigation", nav)["fuse_logits"]
+        tg = epx.teacher_targets(nav, last=False).to(DEV)
+        if twice:
+            (crit(lg, tg) / 2).backward(retain_graph=True)
+            (crit(lg, tg) / 2).backward()
+        else:
+            crit(lg, tg).backward()
+        m.finish_episode()
+        torch.cuda.synchronize()
+        res.append(m.store.grad["lm"].detach().float().clone())
+    assert _rel(res[1], res[0]) < 2e-2 and res[0].norm().item() > 0
