@@ -95,7 +95,9 @@ class GemmTimer:
             e1.record()
             M, N = r.shape
             K = A.shape[1] if layout != 2 else A.shape[0]
-            timer.recs.append((2.0 * M * N * K, e0, e1, layout))
+            # algorithmic bytes of the launch: both operands read once, C written once (+ read once by the residual / accumulate epilogues)
+            byts = 2.0 * (M * K + N * K + M * N) + (2.0 * M * N if (R is not None or epilogue == ops.EPI_ACCUM) else 0.0)
+            timer.recs.append((2.0 * M * N * K, e0, e1, layout, byts))
             return r
         ops.gemm_bf16 = timed
         self.orig_rope = ops.gemm_qkv_rope
@@ -107,7 +109,8 @@ class GemmTimer:
             e0.record()
             r = timer.orig_rope(x, W, cos_t, sin_t, S, rope_cols, out=out, pos_i32=pos_i32)
             e1.record()
-            timer.recs.append((2.0 * r.shape[0] * r.shape[1] * x.shape[1], e0, e1, 0))
+            timer.recs.append((2.0 * r.shape[0] * r.shape[1] * x.shape[1], e0, e1, 0,
+                               2.0 * (r.shape[0] * x.shape[1] + r.shape[1] * x.shape[1] + r.shape[0] * r.shape[1])))
             return r
         ops.gemm_qkv_rope = timed_rope
 
@@ -123,13 +126,14 @@ class GemmTimer:
             return None
         fl = sum(r[0] for r in recs)
         sec = sum(r[1].elapsed_time(r[2]) for r in recs) * 1e-3
-        return {"launches": len(recs), "flops_per_launch": fl / len(recs),
+        return {"launches": len(recs), "flops_per_launch": fl / len(recs), "bytes_per_launch": sum(r[4] for r in recs) / len(recs),
                 "avg_launch_ms": sec / len(recs) * 1e3, "tflops": fl / sec / 1e12, "gemm_seconds": sec}
 
 
-def gemm_traffic_from_profile():
-    """HBM bytes per GEMM launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950 correction
-    + WRITE_SIZE; separate --pmc runs of this same command, tools/gpu_pmc_bench_r3.sh).  -> (bytes or None, note).  A profile is
+def gemm_traffic_from_profile(mode):
+    """HBM-side bytes per GEMM launch of training mode `mode` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 per
+    the gfx950 correction + WRITE_SIZE; separate --pmc runs of this same command, tools/gpu_pmc_bench_r4.sh: two whole episodes of the
+    mode, so the average is over the mode's own launch mix).  -> (bytes or None, note).  A profile is
     only used when it was taken from THIS kernel source: tools/pmc_traffic.py records the sha256 of gemm_bf16.hip, and a file
     whose hash differs (the kernel changed and the counters were not collected again) is refused -- `traffic` is then null
     rather than stale (VERDICT r2 weak #16)."""
@@ -140,7 +144,8 @@ def gemm_traffic_from_profile():
     except OSError:
         return None, "kernel source not found"
     stale = []
-    for name in ("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"):
+    names = (f"r04_gemm_traffic_{mode}.json",) + (("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json") if mode == "recompute" else ())
+    for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)
@@ -180,12 +185,12 @@ def roofline_of(timer, dt, steps, mode, model):
     # wgrad side stream only the forward launches run alone.
     r = g if model.overlap_wgrad else allg
     per = {n: timer.summary(layouts=(l,)) for n, l in (("forward_NT", 0), ("dgrad_NN", 1), ("wgrad_TN", 2))}
-    traffic, traffic_src = gemm_traffic_from_profile()
-    if mode != "recompute":
-        traffic, traffic_src = None, "the committed PMC profile is of the recompute-mode step (see other_mode)"
+    traffic, traffic_src = gemm_traffic_from_profile(mode)
     return {"bound": "mfma", "achieved": round(r["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(r["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": round(r["bytes_per_launch"]),
+            "traffic_over_algorithmic": (round(traffic / r["bytes_per_launch"], 2) if traffic else None),
             "kernel": "gemm_bf16_kernel<256,256,2,4,64,2,*,*,*,PIPE,TME> -- every bf16 GEMM launch of one whole episode of the timed region "
                       "(%d of the %d steps: forward y = x W^T, dgrad, wgrad of qkv / o / gate|up / down in every layer; in prefix_reuse mode the "
                       "suffix steps' few-hundred-row GEMMs run the cut-off 128..224 x 256 tiles; bracketing all steps costs the step 0.9 %%)"
@@ -199,8 +204,10 @@ def roofline_of(timer, dt, steps, mode, model):
             "gemm_share_of_step": round(allg["gemm_seconds"] / n_sampled / (dt / steps), 3),
             "note": "peak = nominal dense bf16 MFMA; with N(0,1) operands the MFMA pipe of this part sustains 1.87-2.0 PFLOP/s "
                     "(power-limited clock; tools/ubench/mix_rate.hip, DESIGN.md §4); traffic = 2*FETCH_SIZE+WRITE_SIZE per launch from the "
-                    "separate rocprofv3 --pmc passes committed under profiles/ (`traffic_source`; null when that profile was taken from "
-                    "another version of gemm_bf16.hip or another training mode)"}
+                    "separate rocprofv3 --pmc passes of THIS training mode committed under profiles/ (`traffic_source`; null when that profile was taken from "
+                    "another version of gemm_bf16.hip); it counts the L2s' fabric requests, Infinity-Cache hits included (MI355X_MICROARCH.md "
+                    "§HBM), so it is an upper bound of the HBM bytes; algorithmic_bytes_per_launch = operands read once + C written once "
+                    "(+ C / R read once by the accumulate / residual epilogues)"}
 
 
 def inference_extras(a, model, wrapped, crit, ep):

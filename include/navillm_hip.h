@@ -168,6 +168,11 @@ int nv_attn_bwd_strided_kvacc_bf16(const void* qkv, const void* out, const void*
 int nv_attn_bwd_episode_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, void* workspace, const void* lse_ptrs,
                              const int* cu, const int* tab, float* kv_acc, const void* rope_cos, const void* rope_sin, int T, int B, int H,
                              int head_dim, int cap, int Mp, long R, int Lp_max, int N_max, void* stream);
+/*   the same; accumulate != 0 ADDS the prefix rows' dK|dV to kv_acc instead of storing them: later segments of a long episode whose
+ *   deferred backward is flushed in pieces (navillm_amd/episode.py; the first segment stores, the following ones add) */
+int nv_attn_bwd_episode_acc_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, void* workspace, const void* lse_ptrs,
+                                 const int* cu, const int* tab, float* kv_acc, const void* rope_cos, const void* rope_sin, int T, int B, int H,
+                                 int head_dim, int cap, int Mp, long R, int Lp_max, int N_max, int accumulate, void* stream);
 int nv_attn_bwd_varlen_bf16(const void* qkv, const void* out, const void* dout, const float* lse2, const int* cu, const int* pos0,
                             void* dqkv, void* workspace, const void* rope_cos, const void* rope_sin, int B, int S_max, long rows,
                             int H, int head_dim, int q_row_min, void* stream);
@@ -248,6 +253,17 @@ int nv_graph_path(const nv_graph* g, int x, int y, int* out, int cap);/* FloydGr
 /*   GraphMap.get_pos_fts (graph_utils.py:144-165) for n slots at once (ids[i] < 0 = the `None` slot): out [n, angle_feat_size+3] */
 int nv_graph_pos_fts(const nv_graph* g, int cur, const int* ids, int n, double cur_heading, double cur_elevation,
                      int angle_feat_size, float* out);
+/*   GraphMap.node_step_ids[vp] = step (tasks/agents/mp3d_agent.py:688) */
+int nv_graph_set_step_id(nv_graph* g, int node, int step);
+/*   MP3DAgent.nav_gmap_variable + the pose half of nav_vp_variable (tasks/agents/mp3d_agent.py:264-371) for a whole batch in one
+ *   call: map slots [stop] + visited + unvisited nodes per sample, padded to the batch's longest list G (returned; <= Gcap, the
+ *   row capacity of every buffer); gmap_ids [B,G] i32, gmap_step_ids [B,G] i64, gmap_visited / gmap_masks [B,G] u8,
+ *   gmap_pos_fts [B,G,afs+3] f32, gmap_lens [B], no_vp_left [B] u8, pair_dists [B,G,G] f32 or NULL, vp_pos_fts [B,Nv,2(afs+3)] f32,
+ *   vp_cand_ids [B,Nv] i32.  cand_ids = the panoramas' candidate node ids, sample b's at cand_off[b]..cand_off[b+1]. */
+int nv_nav_collate(nv_graph* const* graphs, int B, const int* cur, const int* start, const double* heading, const double* elevation,
+                   const int* cand_ids, const int* cand_off, int Nv, int angle_feat_size, int enc_full_graph, int Gcap,
+                   int* gmap_ids, long* gmap_step_ids, unsigned char* gmap_visited, unsigned char* gmap_masks, float* gmap_pos_fts,
+                   int* gmap_lens, unsigned char* no_vp_left, float* pair_dists, float* vp_pos_fts, int* vp_cand_ids);
 /*   nav_model.py:174-190: src [B*G] (view row feeding each map slot or -1), inv [B*Nv] (its inverse), ttype [B*G] */
 int nv_nav_match_tables(const int* gmap_ids, const unsigned char* gmap_visited, const int* cand_ids, int B, int G, int Nv, int* src,
                         int* inv, int* ttype);

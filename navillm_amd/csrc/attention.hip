@@ -880,6 +880,7 @@ struct EpiArgs {
     const bf16_t* rope_cos; const bf16_t* rope_sin;
     int T, B, H, ld, cap, Mp, Rs, nPB, nSB;
     int stat_cap;                   // floats per statistics row in LDS: N_max rounded up to the 32-query tile
+    int kvacc_add;                  // != 0: the prefix rows' dK | dV are ADDED to kvacc (a later segment of a long episode), else stored
     float scale2, scale;
 };
 
@@ -1063,8 +1064,10 @@ __global__ __launch_bounds__(256) void epi_bwd_dkv_kernel(EpiArgs p) {
         float* av = ak + p.H * HD;
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
-            *(f32x4*)(ak + dt * 16) = dk[dt] * p.scale;
-            *(f32x4*)(av + dt * 16) = dv[dt];
+            f32x4 k4 = dk[dt] * p.scale, v4 = dv[dt];
+            if (p.kvacc_add) { k4 += *(const f32x4*)(ak + dt * 16); v4 += *(const f32x4*)(av + dt * 16); }
+            *(f32x4*)(ak + dt * 16) = k4;
+            *(f32x4*)(av + dt * 16) = v4;
         }
         return;
     }
@@ -1410,9 +1413,20 @@ int nv_attn_bwd_varlen_bf16(const void* qkv, const void* out, const void* dout, 
 // through RoPE^T when the tables are given: position = prefix_len + j) and STORES the fp32 sum over the steps of the prefix rows'
 // dK|dV in kv_acc [B*cap, 2*H*head_dim] (row b*cap + key).  workspace: (R - Mp) * H floats.  Lp_max / N_max: the longest prefix /
 // the most rows a sample has in one step.
+// `accumulate` != 0: the prefix rows' dK|dV are ADDED to kv_acc instead of stored -- segments of a long episode (navillm_amd/episode.py
+// flushes the deferred backward of the steps so far when their rows no longer fit; the first segment stores, later ones add).
+int nv_attn_bwd_episode_acc_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, void* workspace, const void* lse_ptrs,
+                                 const int* cu, const int* tab, float* kv_acc, const void* rope_cos, const void* rope_sin, int T, int B, int H,
+                                 int head_dim, int cap, int Mp, long R, int Lp_max, int N_max, int accumulate, void* stream);
 int nv_attn_bwd_episode_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, void* workspace, const void* lse_ptrs,
                              const int* cu, const int* tab, float* kv_acc, const void* rope_cos, const void* rope_sin, int T, int B, int H,
                              int head_dim, int cap, int Mp, long R, int Lp_max, int N_max, void* stream) {
+    return nv_attn_bwd_episode_acc_bf16(qkv, out, dout, dqkv, workspace, lse_ptrs, cu, tab, kv_acc, rope_cos, rope_sin, T, B, H, head_dim, cap, Mp,
+                                        R, Lp_max, N_max, 0, stream);
+}
+int nv_attn_bwd_episode_acc_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, void* workspace, const void* lse_ptrs,
+                                 const int* cu, const int* tab, float* kv_acc, const void* rope_cos, const void* rope_sin, int T, int B, int H,
+                                 int head_dim, int cap, int Mp, long R, int Lp_max, int N_max, int accumulate, void* stream) {
     if (!qkv || !out || !dout || !dqkv || !workspace || !lse_ptrs || !cu || !tab || !kv_acc) return NV_ERR_ARG;
     if ((rope_cos == nullptr) != (rope_sin == nullptr)) return NV_ERR_ARG;
     if (head_dim != HD || T < 0 || B <= 0 || H <= 0 || cap <= 0 || Mp < 0 || R < Mp || Lp_max <= 0 || Lp_max > cap || N_max < 0) return NV_ERR_SHAPE;
@@ -1435,7 +1449,7 @@ int nv_attn_bwd_episode_bf16(const void* qkv, const void* out, const void* dout,
     p.lse = (const float* const*)lse_ptrs; p.cu = cu; p.tab = tab; p.kvacc = kv_acc;
     p.rope_cos = (const bf16_t*)rope_cos; p.rope_sin = (const bf16_t*)rope_sin;
     p.T = T; p.B = B; p.H = H; p.ld = 3 * H * HD; p.cap = cap; p.Mp = Mp; p.Rs = (int)Rs;
-    p.nPB = (Lp_max + 63) / 64; p.nSB = (N_max + 63) / 64; p.stat_cap = scap;
+    p.nPB = (Lp_max + 63) / 64; p.nSB = (N_max + 63) / 64; p.stat_cap = scap; p.kvacc_add = accumulate ? 1 : 0;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
     NV_LAUNCH(epi_bwd_dkv_kernel, dim3(B * H, p.nPB + T * p.nSB), dim3(256), 65536 + 8 * scap, st, p);
     NV_LAUNCH(epi_bwd_dq_kernel, dim3(B * H, T * p.nSB), dim3(256), 65536, st, p);

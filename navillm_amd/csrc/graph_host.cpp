@@ -35,6 +35,7 @@ struct nv_graph {
     std::vector<uint8_t> visited;  // [cap]
     std::vector<double> pos;       // [cap, 3]
     std::vector<uint8_t> has_pos;
+    std::vector<int> step_id;      // [cap]  GraphMap.node_step_ids (0 = never stood on)
 
     void grow(int need) {
         if (need <= cap) return;
@@ -51,6 +52,7 @@ struct nv_graph {
         visited.resize(nc, 0);
         pos.resize((size_t)nc * 3, 0.0);
         has_pos.resize(nc, 0);
+        step_id.resize(nc, 0);
         cap = nc;
     }
     double D(int i, int j) const { return i == j ? 0.0 : dis[(size_t)i * cap + j]; }
@@ -182,6 +184,102 @@ int nv_graph_pos_fts(const nv_graph* g, int cur, const int* ids, int n, double c
         o[angle_feat_size] = d0; o[angle_feat_size + 1] = d1; o[angle_feat_size + 2] = d2;
     }
     return NV_OK;
+}
+
+// GraphMap.node_step_ids[vp] = step (mp3d_agent.py:688): kept next to the node so that the collation below needs no Python dict
+int nv_graph_set_step_id(nv_graph* g, int node, int step) {
+    if (!g || node < 0 || node >= g->n) return NV_ERR_ARG;
+    g->step_id[node] = step;
+    return NV_OK;
+}
+
+// MP3DAgent.nav_gmap_variable + the pose half of nav_vp_variable (tasks/agents/mp3d_agent.py:264-371) for a whole batch in ONE call.
+// Per sample b (map graphs[b], agent at node cur[b] with heading / elevation, episode start node start[b], the current panorama's
+// candidate nodes cand_ids[cand_off[b] .. cand_off[b+1])):
+//   map slots = [stop] + visited nodes + unvisited nodes (enc_full_graph) or [stop] + unvisited nodes, each group in the order the
+//   nodes entered `node_positions` (= node-id order: the Python shell interns a node when its position is first set);
+//   G = the longest slot list of the batch; every output row is padded to G (zeros / -1 / false), rows are G apart:
+//     gmap_ids [B,G] i32 (-1 = stop slot / padding)      gmap_step_ids [B,G] i64       gmap_visited [B,G] u8      gmap_masks [B,G] u8
+//     gmap_pos_fts [B,G,afs+3] f32 (GraphMap.get_pos_fts of every slot)               gmap_lens [B] i32          no_vp_left [B] u8
+//     pair_dists [B,G,G] f32 or NULL (graph.distance between the slots' nodes; the reference builds it, NaviLLM's model never reads it)
+//     vp_pos_fts [B,Nv,2*(afs+3)] f32: [:, :afs+3] = pose of the start node, rows 1..K [afs+3:] = pose of candidate k (mp3d_agent.py:275-289)
+//     vp_cand_ids [B,Nv] i32 (-1 at slot 0 and past the K candidates)
+// Every output buffer must hold the row counts for G = Gcap.  Returns G (>= 1), or a negative status (Gcap too small: NV_ERR_ARG).
+// Pure host code on the caller's (pinned) staging buffers; no allocation beyond two small scratch vectors.
+int nv_nav_collate(nv_graph* const* graphs, int B, const int* cur, const int* start, const double* heading, const double* elevation,
+                   const int* cand_ids, const int* cand_off, int Nv, int angle_feat_size, int enc_full_graph, int Gcap,
+                   int* gmap_ids, long* gmap_step_ids, uint8_t* gmap_visited, uint8_t* gmap_masks, float* gmap_pos_fts, int* gmap_lens,
+                   uint8_t* no_vp_left, float* pair_dists, float* vp_pos_fts, int* vp_cand_ids) {
+    if (!graphs || B <= 0 || !cur || !start || !heading || !elevation || !cand_ids || !cand_off || Nv < 1 || angle_feat_size < 4 ||
+        (angle_feat_size & 3) || Gcap < 1 || !gmap_ids || !gmap_step_ids || !gmap_visited || !gmap_masks || !gmap_pos_fts || !gmap_lens ||
+        !no_vp_left || !vp_pos_fts || !vp_cand_ids)
+        return NV_ERR_ARG;
+    const int w = angle_feat_size + 3;
+    int G = 1;
+    for (int b = 0; b < B; ++b) {
+        const nv_graph* g = graphs[b];
+        if (!g || cur[b] < 0 || cur[b] >= g->n || start[b] < 0 || start[b] >= g->n) return NV_ERR_ARG;
+        int len = 1;
+        for (int v = 0; v < g->n; ++v) len += (g->has_pos[v] && (enc_full_graph || !g->visited[v])) ? 1 : 0;
+        gmap_lens[b] = len;
+        G = len > G ? len : G;
+        const int K = cand_off[b + 1] - cand_off[b];
+        if (K < 0 || K > Nv - 1) return NV_ERR_ARG;
+    }
+    if (G > Gcap) return NV_ERR_ARG;
+    memset(gmap_step_ids, 0, sizeof(long) * (size_t)B * G);
+    memset(gmap_visited, 0, (size_t)B * G);
+    memset(gmap_masks, 0, (size_t)B * G);
+    memset(gmap_pos_fts, 0, sizeof(float) * (size_t)B * G * w);
+    memset(vp_pos_fts, 0, sizeof(float) * (size_t)B * Nv * 2 * w);
+    if (pair_dists) memset(pair_dists, 0, sizeof(float) * (size_t)B * G * G);
+    std::vector<float> tmp;
+    for (int b = 0; b < B; ++b) {
+        const nv_graph* g = graphs[b];
+        int* ids = gmap_ids + (size_t)b * G;
+        for (int j = 0; j < G; ++j) ids[j] = -1;
+        int j = 1, n_unvis = 0;
+        if (enc_full_graph)
+            for (int v = 0; v < g->n; ++v)
+                if (g->has_pos[v] && g->visited[v]) { gmap_visited[(size_t)b * G + j] = 1; ids[j++] = v; }
+        for (int v = 0; v < g->n; ++v)
+            if (g->has_pos[v] && !g->visited[v]) { ids[j++] = v; ++n_unvis; }
+        const int len = gmap_lens[b];
+        if (j != len) return NV_ERR_ARG;
+        no_vp_left[b] = n_unvis == 0;
+        for (int k = 0; k < len; ++k) {
+            gmap_masks[(size_t)b * G + k] = 1;
+            gmap_step_ids[(size_t)b * G + k] = ids[k] >= 0 ? g->step_id[ids[k]] : 0;
+        }
+        int rc = nv_graph_pos_fts(g, cur[b], ids, len, heading[b], elevation[b], angle_feat_size, gmap_pos_fts + (size_t)b * G * w);
+        if (rc != NV_OK) return rc;
+        if (pair_dists) {
+            float* pd = pair_dists + (size_t)b * G * G;
+            for (int x = 1; x < len; ++x)
+                for (int y = x + 1; y < len; ++y) pd[(size_t)x * G + y] = pd[(size_t)y * G + x] = (float)g->D(ids[x], ids[y]);
+        }
+        // nav_vp_variable: [stop] + K candidates; every row carries the start node's pose in its first half
+        const int K = cand_off[b + 1] - cand_off[b];
+        const int* cand = cand_ids + cand_off[b];
+        int* vc = vp_cand_ids + (size_t)b * Nv;
+        for (int v = 0; v < Nv; ++v) vc[v] = -1;
+        float sf[64];
+        if (w > 64) return NV_ERR_ARG;
+        rc = nv_graph_pos_fts(g, cur[b], &start[b], 1, heading[b], elevation[b], angle_feat_size, sf);
+        if (rc != NV_OK) return rc;
+        tmp.resize((size_t)(K > 0 ? K : 1) * w);
+        if (K > 0) {
+            rc = nv_graph_pos_fts(g, cur[b], cand, K, heading[b], elevation[b], angle_feat_size, tmp.data());
+            if (rc != NV_OK) return rc;
+        }
+        float* vp = vp_pos_fts + (size_t)b * Nv * 2 * w;
+        for (int v = 0; v < Nv; ++v) memcpy(vp + (size_t)v * 2 * w, sf, sizeof(float) * w);
+        for (int k = 0; k < K; ++k) {
+            memcpy(vp + (size_t)(k + 1) * 2 * w + w, tmp.data() + (size_t)k * w, sizeof(float) * w);
+            vc[k + 1] = cand[k];
+        }
+    }
+    return G;
 }
 
 // nav_model.py:174-190 on integer ids.  Per sample b: map slots gmap_ids[b, 0..G) (-1 = padding or the stop slot 0), their

@@ -223,7 +223,7 @@ class PrefixEpisode:
     def has_pending_gradients(self):
         """an open episode whose steps ran a backward(): in the deferred forms those gradients exist only here until finish()"""
         P = self.prefix
-        return P is not None and (P.get("kv_steps", 0) > 0 or any(r.get("dH") is not None for r in P.get("recs", ())))
+        return P is not None and (P.get("kv_steps", 0) > 0 or P.get("segments", 0) > 0 or any(r.get("dH") is not None for r in P.get("recs", ())))
 
     def assert_no_pending_gradients(self, what):
         if self.has_pending_gradients():
@@ -292,8 +292,32 @@ class PrefixEpisode:
             layers.append(dict(x=x, n1=n1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x1=x1, n2=n2, rstd2=rstd2, gu=gu, h=h))
             x = x2                                     # (dkv_acc needs no zero-fill: the first step SETS the prefix rows)
         self.prefix = dict(ids=[list(p) for p in prefix_ids], ids_np=ids, lens=lens, cu=cu_d, pos=pos_d, crow=crow_d, pos0=zero_pos0,
-                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0, kv_steps=0, defer=defer, lens_dev=lens_d, recs=[])
-        self.stats = {"prefix_rows": Mp, "suffix_rows": []}
+                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0, kv_steps=0, defer=defer, lens_dev=lens_d, recs=[], segments=0)
+        self.stats = {"prefix_rows": Mp, "suffix_rows": [], "segments_flushed": 0, "recomputed_steps": 0}
+
+    def fits(self, ids_list):
+        """can this step's prompts run over the cached prefix?  False: at least one prompt was LEFT-TRUNCATED by the tokenizer side
+        (`max_length=1024, truncation_side='left'`, modified_lm.py:77-87 -- long-horizon episodes): it no longer starts with the
+        registered prefix, and every hidden state of what is left differs from the cached one (the dropped tokens were attended to), so
+        the exact computation is the reference's own -- the caller pushes this step through the full `_lm` path (forward + immediate
+        backward into the same `.grad` buffers; the episode stays open for its deferred part).  A prompt that is NOT at the length
+        limit and does not start with its prefix is a caller error and raises."""
+        P = self.prefix
+        for b in range(self.B):
+            lp = int(P["lens"][b])
+            if ids_list[b][:lp] == P["ids"][b] and lp < len(ids_list[b]) <= self.cap:
+                continue
+            if len(ids_list[b]) >= self.cap:
+                self.stats["recomputed_steps"] += 1
+                return False
+            raise AssertionError("the prompt does not start with the prefix registered for this episode")
+        return True
+
+    def _segment_full(self, rows):
+        cap = int(os.environ.get("NAVILLM_EPISODE_MAX_ROWS", "0") or 0)
+        if cap and rows > max(cap, self.prefix["Mp"] + 1):
+            return True
+        return rows > self._ecap and not self._rows_fit(int(rows * 1.1) + 64)
 
     # ------------------------------------------------------------------ one step: suffix rows over the cached prefix
     def lm(self, ids_list, vis_idx_list, vis_all):
@@ -361,12 +385,17 @@ class PrefixEpisode:
         if self.mode == "all" and not step.get("batched"):
             defer = False                  # a step outside autograd (validation inside an episode): scratch only, the episode buffers hold
         allm = defer and bool(step.get("batched"))                                        # exactly the rows finish() will walk
+        if allm and self.prefix["recs"] and self._segment_full(self._cursor + M):
+            # long episodes (round 4): the rows of the steps so far no longer fit (or exceed NAVILLM_EPISODE_MAX_ROWS) -- run THEIR
+            # deferred backward now (into .grad and the fp32 prefix K/V accumulators), keep the prefix open, reuse their rows
+            self.flush_segment()
         r0 = self._cursor
         if defer:
             self._ensure_rows(r0 + M)
             self._cursor = r0 + M
+        ks = len(self.prefix["recs"])          # lse slot: the step's index inside the current segment
         if allm:
-            while len(self.lse_s) <= k:
+            while len(self.lse_s) <= ks:
                 self.lse_s.append([torch.zeros((B, H, cap), dtype=F32, device=m.device) for _ in range(L)])
         x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), step["ids"], step["vix"], vis_all,
                           out=self._E[0]["x"][r0:r0 + M] if allm else self._buf("E", (M, d)))
@@ -388,7 +417,7 @@ class PrefixEpisode:
             qkv = ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, cap, 2 * H * hd, out=E["qkv"][r0:r0 + M] if allm else self._buf("qkv", (M, 3 * d)),
                                     pos_i32=step["pos"])
             ops.scatter_rows_bf16_(qkv, step["crow"], self.cache[i])
-            lse_i = self.lse_s[k][i] if allm else self.lse[i]
+            lse_i = self.lse_s[ks][i] if allm else self.lse[i]
             ops.attn_fwd_strided(self.cache[i], self.kv0, B, Lmax, cap, H, hd, out=self.attn_buf[i], lse2=lse_i, q_row_min=qmin)
             attn = t("attn", d)
             ops._lib.check(ops._L().nv_gather_rows_bf16(self.attn_buf[i].data_ptr(), step["grow"].data_ptr(), attn.data_ptr(), M, d, ops._st()),
@@ -404,7 +433,7 @@ class PrefixEpisode:
         x_last = ops.gather_rows_bf16(x, step["last"])
         Hs, rstdf = ops.rmsnorm_fwd(x_last, st.p("lang_model.model.norm.weight"), eps)
         self.prefix["steps"] = k + 1
-        saved = dict(step=step, layers=layers, x_last=x_last, rstdf=rstdf, serial=k + 1, r0=r0, defer=defer, batched=allm, k=k, dH=None)
+        saved = dict(step=step, layers=layers, x_last=x_last, rstdf=rstdf, serial=k + 1, r0=r0, defer=defer, batched=allm, k=ks, dH=None)
         if allm:
             self.prefix["recs"].append(saved)
         return Hs, saved
@@ -551,23 +580,47 @@ class PrefixEpisode:
         if dp is not None and dp._exchanging():
             dp._finalize()                         # outside autograd: no engine callback will run the end-of-backward exchange
 
-    def _finish_batched(self):
-        """mode "all": ONE walk down the layers for every token row of the episode (prefix rows [0, Mp), then each step's block)."""
+    def flush_segment(self):
+        """long episodes (round 4; VERDICT r3 next #7a): run the deferred backward of the steps recorded SO FAR -- their rows [Mp, R) only:
+        weight gradients into `.grad`, the K/V gradients they send into the prefix rows into the fp32 accumulators (first segment:
+        stored, later ones: added), each step's visual-token gradient into its encoder graph -- and hand their rows back.  The prefix
+        stays open (its own backward runs once, in finish()); the steps of different segments never see one another (a step attends to
+        the prefix and to its own rows), so the result is the same sum.  Called automatically when the next step's rows would not fit
+        (`_segment_full`); every recorded step must have run its backward()."""
+        P = self.prefix
+        if P is None or self.mode != "all" or not P["defer"] or not P["recs"]:
+            return
+        if any(r["dH"] is None for r in P["recs"]):
+            raise RuntimeError("prefix-reuse training: the episode's rows must be flushed (they no longer fit / NAVILLM_EPISODE_MAX_ROWS), but a "
+                               "recorded step has not run backward() yet; call backward() right after each loss (as the rollout loop does), "
+                               "or use NAVILLM_EPISODE_DEFER=none")
+        self._finish_batched(final=False)
+
+    def _finish_batched(self, final=True):
+        """mode "all": ONE walk down the layers for every token row of the episode (prefix rows [0, Mp), then each step's block).
+        final=False (flush_segment): the steps' rows [Mp, R) only, the prefix stays open."""
         P = self.prefix
         m, cfg, st = self.m, self.m.cfg, self.m.store
         B, cap, H, hd, L, d, ff = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.num_layers, cfg.hidden_size, cfg.intermediate_size
         Mp, R = P["Mp"], self._cursor
         recs = P["recs"]
         live = [r for r in recs if r["dH"] is not None]
-        self.prefix = None
-        self._last_rows = R - Mp
-        self._cursor = 0
-        if not live:
+        seg_before = P["segments"]                      # segments already flushed: dkv_acc holds their sums
+        self._last_rows = max(R - Mp, self._last_rows if seg_before else 0)
+        if final:
+            self.prefix = None
+            self._cursor = 0
+        else:
+            P["recs"] = []
+            P["segments"] = seg_before + 1
+            self._cursor = Mp
+            self.stats["segments_flushed"] += 1
+        if not live and not (final and seg_before):
             return
         with torch.no_grad():
             st.touch_layers()
             dp0 = getattr(m, "_dp", None)
-            if dp0 is not None:
+            if dp0 is not None and final:
                 dp0.on_deferred_backward_begin()
             normw, gnormw = st.p("lang_model.model.norm.weight"), st.g("lang_model.model.norm.weight")
             dx, other = self._buf("b.dx_a", (R, d)), self._buf("b.dx_b", (R, d))
@@ -579,7 +632,7 @@ class PrefixEpisode:
             for r in live:
                 dx_last = ops.rmsnorm_bwd(r["dH"], r["x_last"], normw, r["rstdf"], gnormw)
                 ops.scatter_rows_bf16_(dx_last, r["step"]["last"], dx[r["r0"]:r["r0"] + r["step"]["M"]])
-            Mz = max(r["step"]["M"] for r in recs)
+            Mz = max([r["step"]["M"] for r in recs] or [1])
             zeros_md = self._buf("zeros_md", (Mz, d))
             zeros_md.zero_()
             Lp_max = P["Lmax"]
@@ -587,8 +640,8 @@ class PrefixEpisode:
             epi_tab = lse_tab = None
             # (the one-launch kernels keep a step table of 128 entries and 1536 statistics rows in LDS: longer episodes / blocks take
             # the per-step path)
-            Nz = max(r["step"]["N"] for r in recs)
-            if os.environ.get("NAVILLM_EPISODE_ATTN_BWD", "episode") != "steps" and len(recs) <= 128 and Nz <= 1536:
+            Nz = max([r["step"]["N"] for r in recs] or [0])
+            if recs and os.environ.get("NAVILLM_EPISODE_ATTN_BWD", "episode") != "steps" and len(recs) <= 128 and Nz <= 1536:
                 # where every step's block sits (r0 | rows per sample | live rows of each sample) and, per layer, where its lse is
                 T = len(recs)
                 tab = np.concatenate([np.array([[r["r0"] + o for o in r["step"]["off"]] for r in recs], np.int32).reshape(-1),
@@ -601,39 +654,50 @@ class PrefixEpisode:
             for i in reversed(range(L)):
                 Wqkv, Wo, Wgu, Wd, w1, w2, gqkv, go, ggu, gd, gw1, gw2 = self._weights(i)
                 E, E32 = self._E[i], self._E32[i]
-                # the top layer's prefix rows feed nothing (only their K/V carry gradient): its MLP / o_proj backward covers the steps' rows only
-                lo = Mp if i == L - 1 else 0
-                ops.gemm_bf16(ops.NN, dx[lo:], Wd, out=dh[lo:])
-                ops.gemm_bf16(ops.TN, dx[lo:], E["h"][lo:R], out=gd, epilogue=ops.EPI_ACCUM)
-                ops.swiglu_bwd(E["gu"][lo:R], dh[lo:], out=dgu[lo:])
-                ops.gemm_bf16(ops.NN, dgu[lo:], Wgu, out=dn[lo:])
-                ops.gemm_bf16(ops.TN, dgu[lo:], E["n2"][lo:R], out=ggu, epilogue=ops.EPI_ACCUM)
-                ops.rmsnorm_bwd(dn[lo:], E["x1"][lo:R], w2, E32["r2"][lo:R], gw2, resid_grad=dx[lo:], out=dx1[lo:])
-                ops.gemm_bf16(ops.NN, dx1[lo:], Wo, out=dattn[lo:])
-                ops.gemm_bf16(ops.TN, dx1[lo:], E["attn"][lo:R], out=go, epilogue=ops.EPI_ACCUM)
+                # the top layer's prefix rows feed nothing (only their K/V carry gradient): its MLP / o_proj backward covers the steps' rows
+                # only; a segment flush (final=False) never touches the prefix rows
+                lo = Mp if (i == L - 1 or not final) else 0
+                if R > lo:
+                    ops.gemm_bf16(ops.NN, dx[lo:], Wd, out=dh[lo:])
+                    ops.gemm_bf16(ops.TN, dx[lo:], E["h"][lo:R], out=gd, epilogue=ops.EPI_ACCUM)
+                    ops.swiglu_bwd(E["gu"][lo:R], dh[lo:], out=dgu[lo:])
+                    ops.gemm_bf16(ops.NN, dgu[lo:], Wgu, out=dn[lo:])
+                    ops.gemm_bf16(ops.TN, dgu[lo:], E["n2"][lo:R], out=ggu, epilogue=ops.EPI_ACCUM)
+                    ops.rmsnorm_bwd(dn[lo:], E["x1"][lo:R], w2, E32["r2"][lo:R], gw2, resid_grad=dx[lo:], out=dx1[lo:])
+                    ops.gemm_bf16(ops.NN, dx1[lo:], Wo, out=dattn[lo:])
+                    ops.gemm_bf16(ops.TN, dx1[lo:], E["attn"][lo:R], out=go, epilogue=ops.EPI_ACCUM)
                 # attention backward.  The prefix rows' own causal attention (packed rows) ...
-                if lo == 0:
-                    ops.attn_bwd_varlen(E["qkv"][:Mp], E["attn"][:Mp], dattn[:Mp], P["layers"][i]["lse"], P["cu"], P["pos0"], B, Lp_max, H, hd,
-                                        dqkv[:Mp], q_row_min=0, rope=None)
-                else:
-                    dqkv[:Mp].zero_()
-                    dx1[:Mp].zero_()
+                if final:
+                    if lo == 0:
+                        ops.attn_bwd_varlen(E["qkv"][:Mp], E["attn"][:Mp], dattn[:Mp], P["layers"][i]["lse"], P["cu"], P["pos0"], B, Lp_max, H, hd,
+                                            dqkv[:Mp], q_row_min=0, rope=None)
+                    else:
+                        dqkv[:Mp].zero_()
+                        dx1[:Mp].zero_()
                 # ... and every step's rows over their sample's prefix and the step's own earlier rows
                 if epi_tab is not None:
                     # ONE launch per kernel for all the steps, reading the episode buffers in place: the prefix key blocks walk every
-                    # step's queries and STORE the fp32 sum in dkv_acc; dQ and the steps' own dK|dV land in dqkv through RoPE^T
+                    # step's queries and STORE the fp32 sum in dkv_acc (a later segment of a long episode: ADD to it); dQ and the steps'
+                    # own dK|dV land in dqkv through RoPE^T
                     ops.attn_bwd_episode(E["qkv"][:R], E["attn"][:R], dattn, dqkv, lse_tab[i], P["cu"], epi_tab, self.dkv_acc[i], len(recs), B, H, hd,
-                                         cap, Mp, Lp_max, Nz, rope=(m.rope_cos, m.rope_sin))
+                                         cap, Mp, Lp_max, Nz, rope=(m.rope_cos, m.rope_sin), accumulate=seg_before > 0)
+                elif recs:
+                    self._attn_bwd_by_step(i, recs, E, dattn, dqkv, zeros_md, first=seg_before == 0)
+                q0 = 0
+                if final:
+                    ops.kv_grad_inject(dqkv[:Mp], self.dkv_acc[i], P["crow"])
+                    ops.rope_rows_t_(dqkv[:Mp], m.rope_cos, m.rope_sin, P["pos"], H, hd)
                 else:
-                    self._attn_bwd_by_step(i, recs, E, dattn, dqkv, zeros_md)
-                ops.kv_grad_inject(dqkv[:Mp], self.dkv_acc[i], P["crow"])
-                ops.rope_rows_t_(dqkv[:Mp], m.rope_cos, m.rope_sin, P["pos"], H, hd)
-                ops.gemm_bf16(ops.NN, dqkv, Wqkv, out=dn)
-                ops.gemm_bf16(ops.TN, dqkv, E["n1"][:R], out=gqkv, epilogue=ops.EPI_ACCUM)
-                ndx = ops.rmsnorm_bwd(dn, E["x"][:R], w1, E32["r1"][:R], gw1, resid_grad=dx1, out=other)
-                dx, other = ndx, dx
-                m._dp_layer_done(i, [])
-            self._embed_grad(dx[:Mp], P["ids_np"])
+                    q0 = Mp
+                if R > q0:
+                    ops.gemm_bf16(ops.NN, dqkv[q0:], Wqkv, out=dn[q0:])
+                    ops.gemm_bf16(ops.TN, dqkv[q0:], E["n1"][q0:R], out=gqkv, epilogue=ops.EPI_ACCUM)
+                    ops.rmsnorm_bwd(dn[q0:], E["x"][q0:R], w1, E32["r1"][q0:R], gw1, resid_grad=dx1[q0:], out=other[q0:])
+                dx, other = other, dx
+                if final:
+                    m._dp_layer_done(i, [])
+            if final:
+                self._embed_grad(dx[:Mp], P["ids_np"])
             dvis = []
             for r in recs:
                 sp = r["step"]
@@ -648,10 +712,10 @@ class PrefixEpisode:
                     torch.autograd.backward([v], [g])
             r["step"]["vis_live"] = None
         dp = getattr(m, "_dp", None)
-        if dp is not None and dp._exchanging():
+        if final and dp is not None and dp._exchanging():
             dp._finalize()                         # outside autograd: no engine callback will run the end-of-backward exchange
 
-    def _attn_bwd_by_step(self, i, recs, E, dattn, dqkv, zeros_md):
+    def _attn_bwd_by_step(self, i, recs, E, dattn, dqkv, zeros_md, first=True):
         """round 3a form (NAVILLM_EPISODE_ATTN_BWD=steps): one strided backward per step over the K/V cache: the step's post-RoPE q|k|v
         and its attention outputs go back to their cache rows, dO to the step's rows (zero elsewhere); the gradients the step sends
         into the cached prefix rows are summed in fp32 by the kernel itself (first step: stored)"""
@@ -665,7 +729,7 @@ class PrefixEpisode:
             ops.scatter_rows_bf16_(dattn[rows], sp["crow"], self.dout_full)
             ops.attn_bwd_strided(self.cache[i], self.attn_buf[i], self.dout_full, self.lse_s[r["k"]][i], self.kv0, B, sp["Lmax"], cap,
                                  H, hd, self.dqkv_full, q_row_min=sp["qmin"], kv_acc=self.dkv_acc[i],
-                                 prefix_len_i32=self._lens_dev, first=(n_ == 0))
+                                 prefix_len_i32=self._lens_dev, first=(first and n_ == 0))
             ops.scatter_rows_bf16_(zeros_md[:sp["M"]], sp["crow"], self.dout_full)
             ops.gather_rows_bf16(self.dqkv_full, sp["crow"], out=dqkv[rows])
             ops.rope_rows_t_(dqkv[rows], m.rope_cos, m.rope_sin, sp["pos"], H, hd)

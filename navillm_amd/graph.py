@@ -116,6 +116,19 @@ class _Positions(dict):
         self._owner._push_position(k, v)
 
 
+class _StepIds(dict):
+    """`GraphMap.node_step_ids`: a dict whose writes are mirrored into the C graph (nv_nav_collate reads them there)"""
+
+    def __init__(self, owner):
+        super().__init__()
+        self._owner = owner
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v)
+        g = self._owner._graph
+        _lib.check(_L().nv_graph_set_step_id(g._g, g._id(k), int(v)), "nv_graph_set_step_id")
+
+
 class GraphMap:
     """graph_utils.py:99-165 (node embeddings kept as running sums of detached device tensors)."""
 
@@ -124,7 +137,17 @@ class GraphMap:
         self._graph = FloydGraph()
         self._positions = _Positions(self)
         self.node_embeds = {}
-        self.node_step_ids = {}
+        self._step_ids = _StepIds(self)
+
+    @property
+    def node_step_ids(self):
+        return self._step_ids
+
+    @node_step_ids.setter
+    def node_step_ids(self, d):
+        self._step_ids = _StepIds(self)
+        for k, v in dict(d).items():
+            self._step_ids[k] = v
 
     # the reference's attributes stay assignable (tests / callers replace them wholesale)
     @property
@@ -136,6 +159,8 @@ class GraphMap:
         self._graph = g
         for k, v in self._positions.items():
             self._push_position(k, v)
+        for k, v in list(self._step_ids.items()):
+            self._step_ids[k] = v
 
     @property
     def node_positions(self):
@@ -192,6 +217,98 @@ class GraphMap:
         _lib.check(_L().nv_graph_pos_fts(self._graph._g, self._graph.idx[cur_vp], _ptr(ids), len(gmap_vpids), float(cur_heading),
                                          float(cur_elevation), int(angle_feat_size), _ptr(out)), "nv_graph_pos_fts")
         return out
+
+
+# ------------------------------------------------------------------ per-step collation of the maps (the agent's tensor builders)
+class NavCollator:
+    """`MP3DAgent.nav_gmap_variable` + the pose half of `nav_vp_variable` (tasks/agents/mp3d_agent.py:264-371) for a whole batch in
+    ONE C call (`nv_nav_collate`): map slots [stop] + visited + unvisited nodes per sample padded to the batch's longest list, step
+    ids, visited / valid masks, the 7-d pose of every slot, the 14-d pose table of the panorama's views -- written straight into a
+    pinned staging buffer and shipped to the device in ONE asynchronous copy.  A ring of staging buffers guarded by events lets the
+    host run ahead of the GPU (training with teacher forcing never waits for a step's result).
+
+    `collate()` -> dict of numpy views (host side, valid until the ring comes round) and, with `device`, the device tensors under the
+    reference's batch keys: gmap_step_ids [B,G] i64, gmap_pos_fts [B,G,7] f32, gmap_visited_masks / gmap_masks [B,G] bool,
+    vp_pos_fts [B,Nv,14] f32; plus gmap_ids / vp_cand_ids (int32 node ids for `match_tables`), gmap_lens, no_vp_left."""
+
+    RING = 4
+
+    def __init__(self, B, Nv, Gcap=128, angle_feat_size=4, enc_full_graph=True, pair_dists=False, pin=None):
+        import torch
+        self.B, self.Nv, self.Gcap, self.afs, self.full, self.pair = B, Nv, Gcap, angle_feat_size, bool(enc_full_graph), bool(pair_dists)
+        w = angle_feat_size + 3
+        # regions (capacity for G = Gcap), 16-byte aligned so that dtype views of the packed buffer are legal on both sides
+        spec = [("gmap_step_ids", np.int64, B * Gcap), ("gmap_pos_fts", np.float32, B * Gcap * w), ("vp_pos_fts", np.float32, B * Nv * 2 * w),
+                ("gmap_ids", np.int32, B * Gcap), ("vp_cand_ids", np.int32, B * Nv), ("gmap_lens", np.int32, B),
+                ("gmap_visited", np.uint8, B * Gcap), ("gmap_masks", np.uint8, B * Gcap), ("no_vp_left", np.uint8, B)]
+        if self.pair:
+            spec.append(("pair_dists", np.float32, B * Gcap * Gcap))
+        self.off, o = {}, 0
+        for name, dt, n in spec:
+            self.off[name] = (o, dt, n)
+            o += (n * np.dtype(dt).itemsize + 15) // 16 * 16
+        self.nbytes = o
+        pin = torch.cuda.is_available() if pin is None else pin
+        self.ring = [torch.empty(o, dtype=torch.uint8, pin_memory=pin) for _ in range(self.RING)]
+        self.events = [None] * self.RING
+        self.k = 0
+        self._w = w
+
+    def _region(self, buf_np, name):
+        o, dt, n = self.off[name]
+        return buf_np[o:o + n * np.dtype(dt).itemsize].view(dt)
+
+    def collate(self, gmaps, cur_vps, headings, elevations, cand_vpids, device=None):
+        import torch
+        B, Nv, w = self.B, self.Nv, self._w
+        assert len(gmaps) == B
+        slot = self.k % self.RING
+        self.k += 1
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()                  # the copy that last read this staging buffer has run
+            self.events[slot] = None
+        host = self.ring[slot]
+        hnp = host.numpy()
+        handles = (ctypes.c_void_p * B)(*[g._graph._g for g in gmaps])
+        cur = np.fromiter((g._graph.idx[v] for g, v in zip(gmaps, cur_vps)), np.int32, B)
+        start = np.fromiter((g._graph.idx[g.start_vp] for g in gmaps), np.int32, B)
+        hd = np.asarray(headings, np.float64)
+        el = np.asarray(elevations, np.float64)
+        off = np.zeros(B + 1, np.int32)
+        off[1:] = np.cumsum([len(c) for c in cand_vpids])
+        cand = np.fromiter((g._graph.idx[v] for g, c in zip(gmaps, cand_vpids) for v in c), np.int32, int(off[-1]))
+        R = {n: self._region(hnp, n) for n in self.off}
+        G = _L().nv_nav_collate(handles, B, _ptr(cur), _ptr(start), _ptr(hd), _ptr(el), _ptr(cand), _ptr(off), Nv, self.afs, int(self.full),
+                                self.Gcap, _ptr(R["gmap_ids"]), _ptr(R["gmap_step_ids"]), _ptr(R["gmap_visited"]), _ptr(R["gmap_masks"]),
+                                _ptr(R["gmap_pos_fts"]), _ptr(R["gmap_lens"]), _ptr(R["no_vp_left"]),
+                                _ptr(R["pair_dists"]) if self.pair else None, _ptr(R["vp_pos_fts"]), _ptr(R["vp_cand_ids"]))
+        if G < 1:
+            raise _lib.NaviLLMHipError(f"nv_nav_collate failed ({G}): a map with more than Gcap = {self.Gcap} slots, or an unknown node")
+        shapes = {"gmap_step_ids": (B, G), "gmap_pos_fts": (B, G, w), "vp_pos_fts": (B, Nv, 2 * w), "gmap_ids": (B, G), "vp_cand_ids": (B, Nv),
+                  "gmap_lens": (B,), "gmap_visited": (B, G), "gmap_masks": (B, G), "no_vp_left": (B,), "pair_dists": (B, G, G)}
+        out = {"G": G, "host": {n: R[n][:int(np.prod(shapes[n]))].reshape(shapes[n]) for n in self.off}}
+        if device is not None:
+            dev = host.to(device, non_blocking=True)
+            if dev.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+                self.events[slot] = ev
+            tdt = {np.int64: torch.int64, np.float32: torch.float32, np.int32: torch.int32, np.uint8: torch.uint8}
+
+            def view(name):
+                o, dt, _ = self.off[name]
+                n = int(np.prod(shapes[name]))
+                return dev[o:o + n * np.dtype(dt).itemsize].view(tdt[dt]).view(*shapes[name])
+            out.update(gmap_step_ids=view("gmap_step_ids"), gmap_pos_fts=view("gmap_pos_fts"), vp_pos_fts=view("vp_pos_fts"),
+                       gmap_visited_masks=view("gmap_visited").view(torch.bool), gmap_masks=view("gmap_masks").view(torch.bool))
+            if self.pair:
+                out["gmap_pair_dists"] = view("pair_dists")
+        return out
+
+    def vpids(self, gmaps, host):
+        """the reference's `gmap_vpids` lists (viewpoint-id strings, None for the stop slot) of the last collate()"""
+        ids, lens = host["gmap_ids"], host["gmap_lens"]
+        return [[None] + [g._graph.names[i] for i in ids[b, 1:lens[b]]] for b, g in enumerate(gmaps)]
 
 
 # ------------------------------------------------------------------ per-step index tables of forward_navigation

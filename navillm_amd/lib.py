@@ -52,6 +52,7 @@ SIGNATURES = {
     "nv_attn_bwd_strided_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, i, i, vp]),
     "nv_attn_bwd_strided_kvacc_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, fp, ip, i, i, i, i, i, i, i, vp]),
     "nv_attn_bwd_episode_bf16": (i, [vp, vp, vp, vp, vp, vp, ip, ip, fp, vp, vp, i, i, i, i, i, i, l, i, i, vp]),
+    "nv_attn_bwd_episode_acc_bf16": (i, [vp, vp, vp, vp, vp, vp, ip, ip, fp, vp, vp, i, i, i, i, i, i, l, i, i, i, vp]),
     "nv_attn_bwd_varlen_bf16": (i, [vp, vp, vp, fp, ip, ip, vp, vp, vp, vp, i, i, l, i, i, i, vp]),
     "nv_attn_bwd_workspace_bytes": (sz, [i, i, i]),
     "nv_attn_bwd_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, i, vp]),
@@ -93,6 +94,8 @@ SIGNATURES = {
     "nv_graph_distance": (C.c_double, [vp, i, i]),
     "nv_graph_path": (i, [vp, i, i, vp, i]),
     "nv_graph_pos_fts": (i, [vp, i, vp, i, C.c_double, C.c_double, i, vp]),
+    "nv_graph_set_step_id": (i, [vp, i, i]),
+    "nv_nav_collate": (i, [vp, i, vp, vp, vp, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "nv_nav_match_tables": (i, [vp, vp, vp, i, i, i, vp, vp, vp]),
     "nv_nav_perm_tables": (i, [vp, vp, vp, i, i, vp, vp, vp]),
     # native inference runtime (nv_decoder* travels as void*)

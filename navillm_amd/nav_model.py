@@ -310,7 +310,11 @@ class NavModel(nn.Module):
         return super().parameters(recurse)
 
     def _lm_episode(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None):
+        """-> [B, d] over the cached prefix, or None when a prompt of this step was left-truncated at the tokenizer's max_length
+        (modified_lm.py:77-87): the caller then runs the step through the full `_lm` path (PrefixEpisode.fits)"""
         ids_l, vix_l, vis_all, _ = self._vis_layout(ids_cpu, am_cpu, cand_vis, hist_vis, obj_vis)
+        if not self.episode.fits(ids_l):
+            return None
         return self.episode.lm(ids_l, vix_l, vis_all)
 
     def reset_kv_cache(self):
@@ -705,6 +709,8 @@ class NavModel(nn.Module):
             Hs_cls = self._lm_cached(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, hist_keys=hk)
         elif self.episode is not None and self.episode.prefix is not None and torch.is_grad_enabled():
             Hs_cls = self._lm_episode(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis)
+            if Hs_cls is None:         # a left-truncated prompt: this step takes the reference's formulation, gradients land in .grad at once
+                Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)
         else:
             Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)
         pred = Fn.HeadBF16.apply(Hs_cls, self, "out_head.0")   # [B,100]

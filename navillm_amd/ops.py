@@ -299,18 +299,19 @@ def attn_bwd_strided(qkv, out, dout, lse2, kv_start_i32, B, S, S_stride, H, hd, 
     return dqkv
 
 
-def attn_bwd_episode(qkv, out, dout, dqkv, lse_ptrs_i64, cu_i32, tab_i32, kv_acc, T, B, H, hd, cap, Mp, Lp_max, N_max, rope=None):
-    """attention backward of all T steps of a prefix-reuse episode for one layer (nv_attn_bwd_episode_bf16): rows [Mp, R) of dqkv and
-    the fp32 prefix K/V gradient sums in kv_acc are written; rope = (cos, sin) applies RoPE^T to dQ / dK as they are stored"""
+def attn_bwd_episode(qkv, out, dout, dqkv, lse_ptrs_i64, cu_i32, tab_i32, kv_acc, T, B, H, hd, cap, Mp, Lp_max, N_max, rope=None, accumulate=False):
+    """attention backward of all T steps of a prefix-reuse episode for one layer (nv_attn_bwd_episode_acc_bf16): rows [Mp, R) of dqkv and
+    the fp32 prefix K/V gradient sums in kv_acc are written (accumulate: added to what an earlier segment of the episode left there);
+    rope = (cos, sin) applies RoPE^T to dQ / dK as they are stored"""
     R = qkv.shape[0]
     assert out.shape[0] == R and dout.shape[0] == R and dqkv.shape[0] == R and lse_ptrs_i64.numel() == T and tab_i32.numel() == 2 * T * B
     ws = _workspace(max(R - Mp, 1) * H * 4, qkv.device, "attn_episode")
     cos, sin = (rope[0].data_ptr(), rope[1].data_ptr()) if rope is not None else (0, 0)
     if rope is not None:
         assert rope[0].shape[0] >= cap, "RoPE tables shorter than the K/V cache"
-    _lib.check(_L().nv_attn_bwd_episode_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), ws.data_ptr(),
-                                             lse_ptrs_i64.data_ptr(), cu_i32.data_ptr(), tab_i32.data_ptr(), kv_acc.data_ptr(), cos, sin,
-                                             T, B, H, hd, cap, Mp, R, Lp_max, N_max, _st()), "nv_attn_bwd_episode_bf16")
+    _lib.check(_L().nv_attn_bwd_episode_acc_bf16(qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), ws.data_ptr(),
+                                                 lse_ptrs_i64.data_ptr(), cu_i32.data_ptr(), tab_i32.data_ptr(), kv_acc.data_ptr(), cos, sin,
+                                                 T, B, H, hd, cap, Mp, R, Lp_max, N_max, int(bool(accumulate)), _st()), "nv_attn_bwd_episode_acc_bf16")
     return dqkv
 
 

@@ -151,8 +151,7 @@ class FlatAdamW(torch.optim.Optimizer):
         """prefix-reuse training (navillm_amd/episode.py) hands over its gradients -- in the default form ALL of the LM's -- at
         `finish_episode()`: an update in front of it would silently train on the encoder's gradients alone"""
         ep = getattr(self.model, "episode", None)
-        P = getattr(ep, "prefix", None) if ep is not None else None
-        if P is not None and (P.get("kv_steps", 0) > 0 or any(r.get("dH") is not None for r in P.get("recs", ()))):
+        if ep is not None and ep.has_pending_gradients():
             raise RuntimeError("optimizer step inside an open prefix-reuse episode: call model.finish_episode() (under "
                                "`with model.final_backward():` when data-parallel) after the episode's last backward() and before "
                                "clip_grad_norm_ / step, or model.episode_abort() to drop the episode")

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .graph import GraphMap, get_angle_fts
+from .graph import GraphMap, NavCollator, get_angle_fts
 from .prompts import static_prefix, navigation_prompt, object_grounding_prompt, summarization_prompt, embodied_qa_prompt, qa3d_prompt
 
 
@@ -93,6 +93,8 @@ class SyntheticEpisodes:
         # Same arithmetic -- sum in arrival order, divide by the count at read time -- hence bit-identical embeddings
         # (tests/test_round2_gpu.py::test_fast_maps_equal_the_per_node_maps).
         self.fast_maps = fast_maps and os.environ.get("NAVILLM_FAST_MAPS", "1") != "0"     # (env: A/B measurements)
+        self.c_collate = os.environ.get("NAVILLM_C_COLLATE", "1") != "0"                   # round 4: the per-step collation in one C call
+        self._collator = None
         self.max_frontier = max_frontier
         self.task = task                  # which agent's prompts: r2r | reverie | soon | cvdn (tasks/agents/*.py)
         self.rng = np.random.RandomState(seed)
@@ -236,6 +238,40 @@ class SyntheticEpisodes:
                     gmap.update_node_embed(vp, pe[b, j])
 
     def nav_inputs(self, pano_embeds, pano_masks, cand_vpids):
+        if self.fast_maps and self.c_collate:
+            return self._nav_inputs_collated(pano_embeds, pano_masks, cand_vpids)
+        return self._nav_inputs_python(pano_embeds, pano_masks, cand_vpids)
+
+    def _nav_inputs_collated(self, pano_embeds, pano_masks, cand_vpids):
+        """nav_gmap_variable + nav_vp_variable (mp3d_agent.py:264-371) through ONE side-car call (`NavCollator` -> nv_nav_collate):
+        slot lists, step ids, masks, every pose feature -- in a pinned staging buffer, one H2D copy.  Same tensors as
+        `_nav_inputs_python` (tests/test_host_cpu.py compares them on random maps)."""
+        B, d, dev = self.B, self.cfg.hidden_size, self.device
+        Nv = pano_embeds.shape[1] + 1
+        col = self._collator
+        if col is None or col.Nv != Nv:
+            col = self._collator = NavCollator(B, Nv, Gcap=128, angle_feat_size=self.cfg.angle_feat_size)
+        c = col.collate(self.gmaps, self.cur, self.heading, [0.0] * B, cand_vpids, device=dev)
+        h, G = c["host"], c["G"]
+        gids = h["gmap_ids"].copy()
+        gmask = torch.from_numpy(h["gmap_masks"].astype(bool))
+        gvis = torch.from_numpy(h["gmap_visited"].astype(bool))
+        R = self._store_rows
+        rows = (gids.astype(np.int64) + 1) + (np.arange(B, dtype=np.int64) * R)[:, None]
+        rows_t = ops.h2d(torch.from_numpy(rows.reshape(-1)), dev)
+        inv = (1.0 / self.E_cnt.view(B * R).index_select(0, rows_t))[:, None]
+        gimg = (self.E_sum.view(B * R, d).index_select(0, rows_t) * inv).view(B, G, d)
+        vp_img = torch.cat([torch.zeros_like(pano_embeds[:, :1]), pano_embeds], 1)
+        pm = torch.cat([torch.ones_like(pano_masks[:, :1]), pano_masks], 1)
+        return {"gmap_vpids": col.vpids(self.gmaps, h), "gmap_img_embeds": gimg, "gmap_step_ids": c["gmap_step_ids"],
+                "gmap_pos_fts": c["gmap_pos_fts"], "gmap_visited_masks": c["gmap_visited_masks"], "gmap_masks": c["gmap_masks"],
+                "vp_img_embeds": vp_img, "pano_masks": pm, "vp_pos_fts": c["vp_pos_fts"],
+                "vp_nav_masks": torch.ones(B, Nv, dtype=torch.bool, device=dev),
+                "vp_cand_vpids": [[None] + x for x in cand_vpids], "hist_vis": self.hist_vis, "history": self.history,
+                "data_type": ["r2r"] * B, "instruction": ["{INSTR}"] * B,
+                "_gmask_cpu": gmask, "_gvis_cpu": gvis, "_gmap_ids": gids, "_cand_ids": h["vp_cand_ids"].copy()}
+
+    def _nav_inputs_python(self, pano_embeds, pano_masks, cand_vpids):
         B, d, dev = self.B, self.cfg.hidden_size, self.device
         vpids, vis, steps, embeds = [], [], [], []
         for b, gmap in enumerate(self.gmaps):

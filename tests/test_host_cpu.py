@@ -515,3 +515,85 @@ def test_bench_cpu_baseline_leg_runs_on_a_tiny_config():
     out = bench.cpu_baseline(types.SimpleNamespace(instr_len=24), cfg, seed=3)
     assert out["kind"] == "port" and out["unit"] == "nav-steps/s" and out["value"] is not None and out["value"] > 0
     assert 1 <= out["cores"] <= (os.cpu_count() or 1)
+
+
+def test_nav_collate_one_c_call_equals_the_per_map_python_collation():
+    """SURVEY.md §8f item 3 / VERDICT r3 next #6: `nv_nav_collate` (one C call per step for the whole batch: nav_gmap_variable + the
+    pose half of nav_vp_variable, tasks/agents/mp3d_agent.py:264-371) against the per-map Python collation it replaces, restated
+    here literally from the reference's loops over `GraphMap` (slot order [stop] + visited + unvisited in `node_positions` order,
+    `node_step_ids.get(vp, 0)`, `get_pos_fts` per slot list, zero padding, pair distances), on random growing maps with ragged
+    batches -- every tensor bit-identical."""
+    from navillm_amd.graph import GraphMap, NavCollator
+    rng = np.random.RandomState(7)
+    B, Nv = 5, 13
+    for trial in range(6):
+        full = trial % 3 != 2                                  # enc_full_graph on / off
+        gmaps, curs, heads, elevs, cands = [], [], [], [], []
+        for b in range(B):
+            pos = {f"s{b}_0": rng.randn(3)}
+            gm = GraphMap(f"s{b}_0")
+            cur = f"s{b}_0"
+            steps = int(rng.randint(1, 9))
+            for t in range(steps):
+                K = int(rng.randint(1, 7))
+                cc = []
+                for j in range(K):
+                    known = [v for v in pos if v != cur and all(c["viewpointId"] != v for c in cc)]
+                    if known and rng.rand() < 0.3:
+                        vp = known[rng.randint(len(known))]
+                    else:
+                        vp = f"s{b}_{len(pos)}"
+                        pos[vp] = pos[cur] + rng.randn(3) * np.array([2.0, 2.0, 0.3])
+                    cc.append({"viewpointId": vp, "position": pos[vp]})
+                gm.update_graph({"viewpoint": cur, "position": pos[cur], "candidate": cc})
+                gm.node_step_ids[cur] = t + 1
+                if t < steps - 1:
+                    cur = cc[rng.randint(len(cc))]["viewpointId"]
+            gmaps.append(gm); curs.append(cur); heads.append(float(rng.rand() * 6.28)); elevs.append(float(rng.rand() - 0.5))
+            cands.append([c["viewpointId"] for c in cc])
+        col = NavCollator(B, Nv, Gcap=64, enc_full_graph=full, pair_dists=True, pin=False)
+        out = col.collate(gmaps, curs, heads, elevs, cands, device=torch.device("cpu"))
+        h, G = out["host"], out["G"]
+        # the reference's loops
+        vpids_ref = []
+        for gm in gmaps:
+            vis = [k for k in gm.node_positions if gm.graph.visited(k)]
+            unv = [k for k in gm.node_positions if not gm.graph.visited(k)]
+            vpids_ref.append([None] + (vis + unv if full else unv))
+        assert G == max(len(v) for v in vpids_ref)
+        assert col.vpids(gmaps, h) == vpids_ref
+        for b, gm in enumerate(gmaps):
+            gv = vpids_ref[b]
+            n = len(gv)
+            assert h["gmap_lens"][b] == n
+            assert bool(h["no_vp_left"][b]) == (not any(not gm.graph.visited(k) for k in gm.node_positions))
+            want_vis = np.array([0] + [int(gm.graph.visited(v)) for v in gv[1:]] + [0] * (G - n), np.uint8) if full else np.zeros(G, np.uint8)
+            assert np.array_equal(h["gmap_visited"][b], want_vis)
+            assert np.array_equal(h["gmap_masks"][b], np.array([1] * n + [0] * (G - n), np.uint8))
+            assert np.array_equal(h["gmap_step_ids"][b], np.array([gm.node_step_ids.get(v, 0) for v in gv] + [0] * (G - n)))
+            pf = np.zeros((G, 7), np.float32)
+            pf[:n] = gm.get_pos_fts(curs[b], gv, heads[b], elevs[b])
+            assert np.array_equal(h["gmap_pos_fts"][b], pf)
+            pd = np.zeros((G, G), np.float32)
+            for i in range(1, n):
+                for j in range(i + 1, n):
+                    pd[i, j] = pd[j, i] = gm.graph.distance(gv[i], gv[j])
+            assert np.array_equal(h["pair_dists"][b], pd)
+            vp = np.zeros((Nv, 14), np.float32)
+            vp[:, :7] = gm.get_pos_fts(curs[b], [gm.start_vp], heads[b], elevs[b])
+            cf = gm.get_pos_fts(curs[b], cands[b], heads[b], elevs[b])
+            vp[1:len(cf) + 1, 7:] = cf
+            assert np.array_equal(h["vp_pos_fts"][b], vp)
+            ci = np.full(Nv, -1, np.int32)
+            ci[1:len(cands[b]) + 1] = gm.node_ids(cands[b])
+            assert np.array_equal(h["vp_cand_ids"][b], ci)
+        # the "device" tensors (here: CPU) are views of the one packed copy, under the reference's batch keys and dtypes
+        assert out["gmap_step_ids"].dtype == torch.int64 and tuple(out["gmap_step_ids"].shape) == (B, G)
+        assert out["gmap_masks"].dtype == torch.bool and out["gmap_visited_masks"].dtype == torch.bool
+        assert np.array_equal(out["gmap_pos_fts"].numpy(), h["gmap_pos_fts"]) and np.array_equal(out["vp_pos_fts"].numpy(), h["vp_pos_fts"])
+        assert np.array_equal(out["gmap_masks"].numpy(), h["gmap_masks"].astype(bool))
+        assert tuple(out["gmap_pair_dists"].shape) == (B, G, G)
+    # capacity is checked, not overrun
+    small = NavCollator(B, Nv, Gcap=2, pin=False)
+    with pytest.raises(Exception, match="nv_nav_collate"):
+        small.collate(gmaps, curs, heads, elevs, cands)
