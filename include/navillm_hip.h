@@ -71,6 +71,16 @@ int nv_fp8_decode_table(void* out256_bf16, void* stream);
 int nv_gemv_fp8w(const void* A, const void* Wq, const float* scales, void* C, const void* R, int M, int N, int K, int lda, int ldw,
                  int ldc, int ldr, int epilogue, void* stream);
 
+/*   the tile GEMM on the CODES themselves (round 4; "fp8 MFMA path" of BASELINE config 5): C[M,N] = A[M,K] @ bf16(s*q)^T (+R) with the
+ *   weight tile DMA'd as e4m3fn bytes (half the fabric / LDS bytes of the bf16 operand) and converted on the MFMA fragment path.
+ *   Serves the few-hundred-row GEMMs of K/V-reuse steps -- the shapes whose launch plan is a 128 / 160-row cut-off tile; every
+ *   other shape returns NV_ERR_SHAPE (-2) and the caller runs nv_fp8_dequant_rows + nv_gemm_bf16.  mode: 0 = default, 7 = operand
+ *   bf16(s*q) bit for bit as nv_fp8_dequant_rows writes it, 8 = v_cvt_scalef32_pk_bf16_fp8 with s as its scale operand, 9 = the same
+ *   unscaled + s[n] on the fp32 accumulator (one bf16 rounding per weight less than the reference-on-de-quantised-weights
+ *   semantics).  tile_cfg 0 | 84 | 85; epilogue 0 (store) | 2 (residual); K % 64 == 0, ldq % 16 == 0; workspace as nv_gemm_bf16_ws */
+int nv_gemm_fp8w(const void* A, const void* codes, const float* scales, void* C, const void* R, int M, int N, int K, int lda, int ldq,
+                 int ldc, int ldr, int epilogue, int mode, int tile_cfg, void* workspace, void* stream);
+
 /* ---- K6: embedding gather + visual-token add, models/modified_lm.py:100-110.
  *   out[m] = table[ids[m]]  or  bf16(f32(table[ids[m]]) + vis[vis_idx[m]])  when vis_idx[m] >= 0 */
 int nv_embed_vis_bf16(const void* table, const int* ids, const int* vis_idx, const float* vis, void* out, int M, int d,

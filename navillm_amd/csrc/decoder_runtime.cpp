@@ -120,6 +120,13 @@ static int linear(const nv_decoder* p, const Layer& ly, int kind, const void* x,
         if (M <= 16 && (K & 63) == 0) return nv_gemv_fp8w(x, ly.q[kind], ly.s[kind], out, R, M, N, K, K, K, N, N, epi, stream);
         if (ly.w[kind])                                                // the de-quantised operand is resident: no pre-pass
             return nv_gemm_bf16_ws(0, x, ly.w[kind], out, R, M, N, K, K, K, N, N, epi, 0, p->gemm_ws, stream);
+        // round 4: few-hundred-row steps multiply with the codes themselves (weight tile DMA'd as bytes, converted on the MFMA
+        // fragment path); NV_ERR_SHAPE = not a cut-off-tile shape -> the de-quantisation pre-pass + the bf16 GEMM
+        static const bool tile_fp8 = [] { const char* e = getenv("NAVILLM_FP8_TILE_GEMM"); return !e || e[0] != '0'; }();
+        if (tile_fp8) {
+            const int rc8 = nv_gemm_fp8w(x, ly.q[kind], ly.s[kind], out, R, M, N, K, K, K, N, N, epi, 0, 0, p->gemm_ws, stream);
+            if (rc8 != NV_ERR_SHAPE) return rc8;
+        }
         if (!p->fp8_scratch) return NV_ERR_ARG;
         int rc = nv_fp8_dequant_rows(ly.q[kind], ly.s[kind], p->fp8_scratch, N, K, K, K, stream);
         if (rc) return rc;

@@ -58,6 +58,9 @@ struct GemmArgs {
     // m is m % rope_S; R = cos table, rope_sin = sin table, both [maxS][128] bf16 as nv_rope_bf16 takes them
     const bf16_t* rope_sin; int rope_S, rope_cols;
     const int* rope_pos;    // optional: position of row m (packed rows); nullptr -> m % rope_S
+    // weight-only fp8 B operand (PIPE 7 / 8, nv_gemm_fp8w): B = e4m3fn codes [N][K] (ldb in bytes), one fp32 scale per output channel n
+    const float* b_scales;
+    int fp8_epi;            // PIPE 8 only: 1 = the codes are converted unscaled and s[n] multiplies the fp32 accumulator in the epilogue
 };
 
 // ---- LDS images (BKT = K extent of a stage, 64 or 32) -----------------------------------
@@ -241,7 +244,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
     constexpr int NT = WGM * WGN * 64;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 16, TN = WTN / 16;
-    constexpr bool IL = (PIPE == 4 || PIPE == 6);          // interleaved fragment rows (hand-scheduled loops)
+    constexpr bool IL = (PIPE == 4 || PIPE >= 6);          // interleaved fragment rows (hand-scheduled loops)
+    constexpr bool BF8 = PIPE >= 7;                        // B = weight-only fp8 codes + per-row scales (three-stage loop of the cut-off tiles)
     constexpr int TMU = IL ? TME : TM;                     // fragment rows per wave in use
     constexpr int BM_EFF = IL ? WGM * TME * 16 : BM;       // rows of C this tile covers
     static_assert(TME >= 1 && TME <= TM && (IL || TME == TM), "TME < TM needs the interleaved loop");
@@ -347,7 +351,225 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         }
     };
 
-    if constexpr (PIPE == 6) {
+    if constexpr (PIPE >= 7) {
+        // ---- the three-stage loop below with a WEIGHT-ONLY FP8 B operand (round 4; SURVEY.md §8f item 4, BASELINE config 5) ----------
+        // B = OCP e4m3fn codes [N][K] + one fp32 scale per output channel.  The codes are DMA'd as they are -- a K-tile of B is 16 KiB
+        // instead of 32, two DMA pieces instead of four, 8-byte fragment reads instead of 16 -- and become bf16 MFMA operands on the
+        // fragment path, in the shadow of the MFMAs of the preceding fragment:
+        //   PIPE 7: v_cvt_pk_f32_fp8 -> v_pk_mul_f32 by the lane's row scale -> v_cvt_pk_bf16_f32: the operand is bf16(s * q), bit for
+        //           bit what nv_fp8_dequant_rows writes (the semantics fixture G11 pins);
+        //   PIPE 8: v_cvt_scalef32_pk_bf16_fp8 (one instruction per pair); p.fp8_epi = 0: the lane's scale is the instruction's scale
+        //           operand, = 1: the codes are converted unscaled (exact: e4m3 fits bf16) and s[n] multiplies the fp32 accumulator in
+        //           the epilogue (differs from bf16(s * q) by that one rounding per weight).
+        // Why only here: the few-hundred-row GEMMs (K/V-reuse steps) are latency-bound -- MFMA pipe 37 % busy, the B-tile DMA and the
+        // B fragment reads are the part of a K-step that does not shrink with the tile -- so halving B's bytes pays and
+        // the conversions find idle issue slots; at prefill sizes the loop is MFMA-issue-bound and the pre-pass (3 B per weight) is
+        // the cheaper form.
+        // LDS image of a B stage: [256 rows][64 codes] = 64-B rows, four 16-B slots per row, phys slot = slot ^ ((row >> 2) & 3): the 16
+        // rows x 2 halves a half-wave's ds_read_b64 touches cover the 64 banks once.
+        static_assert(A_KMAJ && B_KMAJ && BKT == 64 && TN == 4 && NT == 512 && BN == 256 && TME >= 4 && TME <= 5, "fp8-B loop: cut-off tiles, forward layout");
+        constexpr int A_STG = BM_EFF * BKT * 2;                 // 16 / 20 KiB
+        constexpr int B_STG = BN * BKT;                         // 16 KiB of codes
+        constexpr int B_REG = 3 * A_STG;
+        constexpr int DUMMY = B_REG + 3 * B_STG;
+        static_assert(DUMMY + 4096 <= 160 * 1024 && 2 * B_STG + 3 * 1024 + 64 < 65536, "LDS budget / ds_read immediates");
+        constexpr int A_PCS = (BM_EFF + 63) / 64;
+        constexpr bool HALF = (BM_EFF % 64) != 0;
+        constexpr int B_PCS = B_STG / 8192;                     // 2
+        constexpr int LT = A_PCS + B_PCS;
+        FragAddr<BM, true, TM, WGM> fa_;
+        fa_.init(wm * 16, lane);
+        uint32_t offA[2], offB[2];
+        const int idx_ = lane & 15, kg_ = lane >> 4;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            offA[q] = smem_addr + fa_.off[q];
+            offB[q] = smem_addr + B_REG + (wn * WTN + idx_) * 64 + ((((q * 2 + (kg_ >> 1)) ^ ((idx_ >> 2) & 3))) << 4) + (kg_ & 1) * 8;
+            asm volatile("" : "+v"(offA[q]));
+            asm volatile("" : "+v"(offB[q]));
+        }
+        if (smem_addr != 0) __builtin_trap();
+        auto ldA = [&](auto SC, auto JC, auto KC) -> bf16x8 {
+            constexpr int st = decltype(SC)::value, j = decltype(JC)::value, kk = decltype(KC)::value;
+            return *(LDS_PTR(bf16x8))(uintptr_t)(offA[kk] + (st * A_STG + j * 2048 * WGM));
+        };
+        auto ldB = [&](auto SC, auto IC, auto KC) -> u32x2 {       // the 8 codes k = kk*32 + kg*8 .. +7 of row wn*64 + i*16 + idx
+            constexpr int st = decltype(SC)::value, i = decltype(IC)::value, kk = decltype(KC)::value;
+            return *(LDS_PTR(u32x2))(uintptr_t)(offB[kk] + (st * B_STG + i * 1024));
+        };
+        // the lane's four row scales (row n0 + wn*64 + i*16 + idx): loaded by hand BEFORE the first DMA so that the prologue's counted
+        // vmcnt wait covers them (loads retire in order) and no compiler-inserted vmcnt(0) drains the prefetch ring later
+        float sc[TN];
+        {
+            const float* sp = p.b_scales + n0 + wn * WTN + idx_;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int n = n0 + wn * WTN + i * 16 + idx_;
+                const float* q = sp + i * 16;
+                if (n >= p.N) q = p.b_scales;                   // (rows past N read zero codes; any finite scale will do)
+                asm volatile("global_load_dword %0, %1, off" : "=v"(sc[i]) : "v"(q) : "memory");
+            }
+        }
+        auto cvt = [&](const u32x2& c, float s_) -> bf16x8 {
+            if constexpr (PIPE == 7) {
+                typedef __attribute__((ext_vector_type(2))) float f2;
+                const f2 a = __builtin_amdgcn_cvt_pk_f32_fp8(c[0], false) * s_, b = __builtin_amdgcn_cvt_pk_f32_fp8(c[0], true) * s_;
+                const f2 d = __builtin_amdgcn_cvt_pk_f32_fp8(c[1], false) * s_, e = __builtin_amdgcn_cvt_pk_f32_fp8(c[1], true) * s_;
+                const u32x4 v = {pack2bf(a[0], a[1]), pack2bf(b[0], b[1]), pack2bf(d[0], d[1]), pack2bf(e[0], e[1])};
+                return __builtin_bit_cast(bf16x8, v);
+            } else {
+                const nv_bf16x2 a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(c[0], s_, false), b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(c[0], s_, true);
+                const nv_bf16x2 d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(c[1], s_, false), e = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(c[1], s_, true);
+                const bf16x8 v = {a[0], a[1], b[0], b[1], d[0], d[1], e[0], e[1]};
+                return v;
+            }
+        };
+        // DMA addressing: A as in the bf16 loop; B: a piece = 128 rows x 64 B (8 KiB), lane -> row chunk*16 + lane/4, phys slot lane%4
+        uint32_t pva = piece_voff<BM, true, NT, BKT>(m0, 0, p.lda, tid, 0);
+        uint32_t pvb;
+        {
+            const int row = wave * 16 + (lane >> 2);
+            const int slot = (lane & 3) ^ ((row >> 2) & 3);
+            pvb = (uint32_t)((long)(n0 + row) * p.ldb + slot * 16);
+        }
+        asm volatile("" : "+v"(pva));
+        asm volatile("" : "+v"(pvb));
+        const uint32_t a_piece = (uint32_t)((NT / 64) * (1024 / (BKT * 2)) * 2) * (uint32_t)p.lda;
+        const uint32_t b_piece = 128u * (uint32_t)p.ldb;
+        const uint32_t wv = __builtin_amdgcn_readfirstlane(wave);
+        const uint32_t m0base = wv * 1024;
+        uint32_t m0half[3];
+#pragma unroll
+        for (int st = 0; st < 3; ++st) m0half[st] = wv < 4 ? st * A_STG + 2 * 8192 + wv * 1024 : DUMMY + (wv - 4) * 1024;
+        const uint32_t a_step = BKT * 2, b_step = BKT;
+        uint64_t a_base = (uint64_t)p.A + (uint64_t)a_step * kt0, b_base = (uint64_t)p.B + (uint64_t)b_step * kt0;
+        uint32_t a_left = p.a_bytes - a_step * (uint32_t)kt0, b_left = p.b_bytes - b_step * (uint32_t)kt0;
+        auto piece = [&](auto SC, auto CC, const u32x4& da, const u32x4& db) {
+            constexpr int st = decltype(SC)::value, c = decltype(CC)::value;
+            if constexpr (c < A_PCS) {
+                if constexpr (HALF && c == A_PCS - 1) set_m0_imm<0>(m0half[st]);
+                else set_m0_imm<st * A_STG + c * 8192>(m0base);
+                dma16_m0set(da, pva, a_piece * c);
+            } else {
+                set_m0_imm<B_REG + st * B_STG + (c - A_PCS) * 8192>(m0base);
+                dma16_m0set(db, pvb, b_piece * (c - A_PCS));
+            }
+        };
+        auto advance = [&]() { a_base += a_step; a_left -= a_step; b_base += b_step; b_left -= b_step; };
+        static_for<3>([&](auto SC) {
+            constexpr int st = decltype(SC)::value;
+            if (st < KT) {
+                const u32x4 da = make_desc((const void*)a_base, a_left), db = make_desc((const void*)b_base, b_left);
+                static_for<LT>([&](auto CC) { piece(SC, CC, da, db); });
+                advance();
+            }
+        });
+        if (KT >= 3) wait_vmcnt<2 * LT>(); else if (KT == 2) wait_vmcnt<LT>(); else wait_vmcnt<0>();   // (covers the scale loads: issued first)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < TN; ++i) asm volatile("" : "+v"(sc[i]));     // the scales are valid from HERE on: no use may be scheduled above the wait
+        const float cs[TN] = {(PIPE == 8 && p.fp8_epi) ? 1.f : sc[0], (PIPE == 8 && p.fp8_epi) ? 1.f : sc[1],
+                              (PIPE == 8 && p.fp8_epi) ? 1.f : sc[2], (PIPE == 8 && p.fp8_epi) ? 1.f : sc[3]};
+        bf16x8 fa0[TM], fa1[TM], fbc[TN];
+        u32x2 cb0[TN], cb1[TN];
+        using std::integral_constant;
+        static_for<TME>([&](auto JC) { fa0[decltype(JC)::value] = ldA(integral_constant<int, 0>{}, JC, integral_constant<int, 0>{}); });
+        static_for<TN>([&](auto IC) { cb0[decltype(IC)::value] = ldB(integral_constant<int, 0>{}, IC, integral_constant<int, 0>{}); });
+        fbc[0] = cvt(cb0[0], cs[0]);
+        constexpr int TOT = TN * TME;
+        constexpr int NRD = TME + TN;
+        // MFMA n of a phase (n = 0 .. TOT-1, in group n * 8 / TOT) multiplies B fragment i = n / TME, so fragment i is first needed in
+        // group 2 i: it is converted in group 2 i - 1 of the SAME phase (i = 1 .. 3), and fragment 0 of the NEXT phase in group 7 of
+        // this one (its codes were read in groups 3 - 5).
+        auto body = [&](auto STC, bool in3, bool nx, bool w2) {
+            constexpr int ST = decltype(STC)::value, SN = (ST + 1) % 3;
+            using K0 = integral_constant<int, 0>;
+            using K1 = integral_constant<int, 1>;
+            static_for<8>([&](auto GC) {                        // phase 1: MFMAs of k-step 0, reads of k-step 1 (stage ST)
+                constexpr int gq = decltype(GC)::value;
+                static_for<NRD>([&](auto RC) {
+                    constexpr int r = decltype(RC)::value;
+                    if constexpr (r * 6 / NRD == gq) {
+                        if constexpr (r < TME) fa1[r] = ldA(STC, RC, K1{});
+                        else cb1[r - TME] = ldB(STC, integral_constant<int, r - TME>{}, K1{});
+                    }
+                });
+                if constexpr (gq == 1) fbc[1] = cvt(cb0[1], cs[1]);
+                if constexpr (gq == 3) fbc[2] = cvt(cb0[2], cs[2]);
+                if constexpr (gq == 5) fbc[3] = cvt(cb0[3], cs[3]);
+                static_for<TOT>([&](auto NC) {
+                    constexpr int n = decltype(NC)::value;
+                    if constexpr (n * 8 / TOT == gq) {
+                        constexpr int i = n / TME, j = n % TME;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbc[i], fa0[j], acc[i][j], 0, 0, 0);
+                    }
+                });
+                if constexpr (gq == 7) fbc[0] = cvt(cb1[0], cs[0]);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (w2) wait_vmcnt<LT>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 da = make_desc((const void*)a_base, a_left), db = make_desc((const void*)b_base, b_left);
+            static_for<8>([&](auto GC) {                        // phase 2: MFMAs of k-step 1, tile kt+1's k-step 0 reads, DMA of tile kt+3
+                constexpr int gq = decltype(GC)::value;
+                if (nx) {
+                    static_for<NRD>([&](auto RC) {
+                        constexpr int r = decltype(RC)::value;
+                        if constexpr (r * 6 / NRD == gq) {
+                            if constexpr (r < TME) fa0[r] = ldA(integral_constant<int, SN>{}, RC, K0{});
+                            else cb0[r - TME] = ldB(integral_constant<int, SN>{}, integral_constant<int, r - TME>{}, K0{});
+                        }
+                    });
+                }
+                if constexpr (gq == 1) fbc[1] = cvt(cb1[1], cs[1]);
+                if constexpr (gq == 3) fbc[2] = cvt(cb1[2], cs[2]);
+                if constexpr (gq == 5) fbc[3] = cvt(cb1[3], cs[3]);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<TOT>([&](auto NC) {
+                    constexpr int n = decltype(NC)::value;
+                    if constexpr (n * 8 / TOT == gq) {
+                        constexpr int i = n / TME, j = n % TME;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbc[i], fa1[j], acc[i][j], 0, 0, 0);
+                    }
+                });
+                if constexpr (gq == 7) { if (nx) fbc[0] = cvt(cb0[0], cs[0]); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (in3) {
+                    if constexpr (gq < LT) piece(STC, GC, da, db);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (in3) advance();
+        };
+        int kt = 0;
+        for (; kt + 5 < KT; kt += 3) {
+            body(integral_constant<int, 0>{}, true, true, true);
+            body(integral_constant<int, 1>{}, true, true, true);
+            body(integral_constant<int, 2>{}, true, true, true);
+        }
+        for (; kt < KT; ++kt) {
+            const bool in3 = kt + 3 < KT, nx = kt + 1 < KT, w2 = kt + 2 < KT;
+            const int st = kt % 3;
+            if (st == 0) body(integral_constant<int, 0>{}, in3, nx, w2);
+            else if (st == 1) body(integral_constant<int, 1>{}, in3, nx, w2);
+            else body(integral_constant<int, 2>{}, in3, nx, w2);
+        }
+        if (PIPE == 8 && p.fp8_epi) {
+            // s[n] on the fp32 accumulators: the lane holds D[n = g*4 + r][m] per 16x16 tile, n = n0 + wn*64 + i*16 + g*4 + r
+            const int g4 = (lane >> 4) * 4;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int n = n0 + wn * WTN + i * 16 + g4;
+                f32x4 s4 = {1.f, 1.f, 1.f, 1.f};
+                if (n + 3 < p.N) s4 = *(const f32x4*)(p.b_scales + n);
+                else { for (int r = 0; r < 4; ++r) if (n + r < p.N) s4[r] = p.b_scales[n + r]; }
+#pragma unroll
+                for (int j = 0; j < TMU; ++j) acc[i][j] *= s4;
+            }
+        }
+    } else if constexpr (PIPE == 6) {
         // ---- THREE LDS stages for the cut-off tiles (TME = 4, 5: 128 / 160 x 256) ------------------------------------------------
         // Why: a K-tile of a cut-off tile takes ~0.6-0.7 us of MFMA time, and the two-stage loop below issues the DMA of tile kt+2
         // only one iteration before tile kt+1 is needed -- shorter than an L2-missing load takes on the few-hundred-row GEMMs these
@@ -1017,9 +1239,11 @@ void gemm_bf16_kernel(GemmArgs p) {
 
 template <int BM, int BN, int WGM, int WGN, int BKT, int NSTAGE, bool A_KMAJ, bool B_KMAJ, int EPI, int PIPE = 0, int TME = BM / WGM / 16>
 int launch(const GemmArgs& p, hipStream_t st) {
-    constexpr int BM_EFF = (PIPE == 4 || PIPE == 6) ? WGM * TME * 16 : BM;
-    // the three-stage loop of the cut-off tiles: 3 x (A image of BM_EFF rows + B image) + a 4 KiB dummy landing area
-    constexpr int LDS = (PIPE == 6) ? 3 * (BM_EFF + BN) * BKT * 2 + 4096 : NSTAGE * (BM + BN) * BKT * 2;
+    constexpr int BM_EFF = (PIPE == 4 || PIPE >= 6) ? WGM * TME * 16 : BM;
+    // the three-stage loop of the cut-off tiles: 3 x (A image of BM_EFF rows + B image) + a 4 KiB dummy landing area (fp8 B: 1 byte per
+    // weight; at least the C tile's staging image, BM_EFF rows of 512 B)
+    constexpr int LDS3 = (PIPE >= 7) ? 3 * (BM_EFF * BKT * 2 + BN * BKT) + 4096 : 3 * (BM_EFF + BN) * BKT * 2 + 4096;
+    constexpr int LDS = (PIPE >= 6) ? (LDS3 > BM_EFF * BN * 2 ? LDS3 : BM_EFF * BN * 2) : NSTAGE * (BM + BN) * BKT * 2;
     auto kern = gemm_bf16_kernel<BM, BN, WGM, WGN, BKT, NSTAGE, A_KMAJ, B_KMAJ, EPI, PIPE, TME>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1071,6 +1295,19 @@ int launch_tme(const GemmArgs& p, int tme, hipStream_t st, bool two_stage = fals
         }
     }
     return launch<256, 256, 2, 4, 64, 2, A_KMAJ, B_KMAJ, EPI, 4, 8>(p, st);
+}
+
+// weight-only fp8 B operand: the three-stage cut-off tiles only (PIPE 7: exact bf16(s*q) operands, PIPE 8: v_cvt_scalef32)
+template <int EPI>
+int launch_fp8(const GemmArgs& p, int tme, int pipe, hipStream_t st) {
+    if (pipe == 7) {
+        if (tme == 4) return launch<256, 256, 2, 4, 64, 2, true, true, EPI, 7, 4>(p, st);
+        if (tme == 5) return launch<256, 256, 2, 4, 64, 2, true, true, EPI, 7, 5>(p, st);
+    } else if (pipe == 8) {
+        if (tme == 4) return launch<256, 256, 2, 4, 64, 2, true, true, EPI, 8, 4>(p, st);
+        if (tme == 5) return launch<256, 256, 2, 4, 64, 2, true, true, EPI, 8, 5>(p, st);
+    }
+    return NV_ERR_SHAPE;
 }
 
 template <bool A_KMAJ, bool B_KMAJ, int EPI>
@@ -1146,6 +1383,7 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
     p.slabs = workspace ? (float*)((char*)workspace + 4096) : nullptr;
     p.full_blocks = 0; p.rem = 1; p.split = 1;
     p.rope_sin = (const bf16_t*)rope_sin; p.rope_S = rope_S; p.rope_cols = rope_cols; p.rope_pos = rope_pos;
+    p.b_scales = nullptr; p.fp8_epi = 0;
     {
         // tuning / measurement knobs, read once per process
         static const int env_debug = [] { const char* e = getenv("NV_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
@@ -1177,6 +1415,51 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
             return dispatch_epi<false, false>(p, epilogue, tile_cfg, st);
     }
     return NV_ERR_ARG;
+}
+
+// y = x W^T with W given as weight-only fp8: OCP e4m3fn codes [N, K] (ldq bytes per row) + one fp32 scale per output channel.
+// Serves the few-hundred-row GEMMs of K/V-reuse inference steps (the shapes whose launch plan is a 128 / 160-row cut-off tile);
+// any other shape returns NV_ERR_SHAPE and the caller runs nv_fp8_dequant_rows + nv_gemm_bf16 (the pre-pass form) -- a documented
+// two-kernel path, not a fallback to another backend.  mode: 0 = default (NV_GEMM_FP8_MODE, else 7), 7 = operands bf16(s*q)
+// bit-exact (what the pre-pass writes), 8 = v_cvt_scalef32 with the scale as its operand, 9 = v_cvt_scalef32 unscaled + s[n] on
+// the fp32 accumulator.  tile_cfg: 0 = planned, 84 / 85 = force the 128 / 160-row tile (tests).  epilogue: EPI_STORE | EPI_RESID.
+extern "C" int nv_gemm_fp8w(const void* A, const void* codes, const float* scales, void* C, const void* R, int M, int N, int K, int lda,
+                            int ldq, int ldc, int ldr, int epilogue, int mode, int tile_cfg, void* workspace, void* stream) {
+    if (!A || !codes || !scales || !C || M < 0 || N < 0 || K <= 0) return NV_ERR_ARG;
+    if (epilogue != EPI_STORE && epilogue != EPI_RESID) return NV_ERR_ARG;
+    if (epilogue == EPI_RESID && !R) return NV_ERR_ARG;
+    if (M == 0 || N == 0) return NV_OK;
+    if ((lda & 7) || (ldq & 15) || (K & 63) || ((((uintptr_t)A) | ((uintptr_t)codes)) & 15) || (((uintptr_t)scales) & 15)) return NV_ERR_SHAPE;
+    static const int env_mode = [] { const char* e = getenv("NV_GEMM_FP8_MODE"); return e ? atoi(e) : 0; }();
+    if (mode == 0) mode = env_mode ? env_mode : 7;
+    if (mode < 7 || mode > 9) return NV_ERR_ARG;
+    const bool can_split = workspace != nullptr;
+    int tme;
+    if (tile_cfg == 84 || tile_cfg == 85) tme = tile_cfg - 80;
+    else if (tile_cfg == 0) {
+        double t256;
+        tme = plan_tme(M, N, K, can_split, true, &t256);
+        if (est_us_128(M, N, K, true) < t256) return NV_ERR_SHAPE;
+    } else return NV_ERR_ARG;
+    if (tme != 4 && tme != 5) return NV_ERR_SHAPE;
+    GemmArgs p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)codes; p.C = (bf16_t*)C; p.R = (const bf16_t*)R;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldq; p.ldc = ldc; p.ldr = ldr;
+    p.counters = (unsigned*)workspace;
+    p.slabs = workspace ? (float*)((char*)workspace + 4096) : nullptr;
+    p.full_blocks = 0; p.rem = 1; p.split = 1;
+    p.rope_sin = nullptr; p.rope_S = 1; p.rope_cols = 0; p.rope_pos = nullptr;
+    p.debug = 0; p.persist = 0; p.band_reduce = 1; p.c_nt = 1; p.group_m = 4;
+    p.col_strips = (long)N > (long)M ? 1 : 0;
+    p.b_scales = scales; p.fp8_epi = mode == 9 ? 1 : 0;
+    p.a_bytes = span_bytes(M, K, lda);
+    {
+        const long b = (long)(N - 1) * ldq + K;                      // bytes of codes addressable from the base
+        p.b_bytes = b > 0xffffffffL ? 0xffffffffu : (uint32_t)b;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int pipe = mode == 7 ? 7 : 8;
+    return epilogue == EPI_STORE ? launch_fp8<EPI_STORE>(p, tme, pipe, st) : launch_fp8<EPI_RESID>(p, tme, pipe, st);
 }
 
 extern "C" int nv_gemm_bf16_ws(int layout, const void* A, const void* B, void* C, const void* R, int M, int N, int K,

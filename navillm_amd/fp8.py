@@ -13,7 +13,10 @@ weights", the semantics tests/golden/g11_fp8_*.npz pin:
     nv_decoder_set_fp8_overlap) -- and it LOSES 1-4 % at 13B / B = 8 (profiles/r03_fp8_overlap_ab.txt: the GEMM's LDS-DMA stream and the
     pre-pass share the same CUs and the same HBM queues; the GEMM slows down by more than the pre-pass costs in line).  It stays as an
     opt-in knob, bit-identical and tested; the default is the in-line pre-pass;
-  * decode steps (M <= 16): `nv_gemv_fp8w` streams the codes themselves -- half the bytes per generated token.
+  * decode steps (M <= 16): `nv_gemv_fp8w` streams the codes themselves -- half the bytes per generated token;
+  * round 4: few-hundred-row steps (K/V-reuse inference: ~100 new rows per sample) run the tile GEMM on the CODES (`nv_gemm_fp8w`:
+    the weight tile is DMA'd as bytes and converted to bf16(s*q) on the MFMA fragment path, bit-identical operands) -- no pre-pass
+    where it hurt most; larger row counts keep the pre-pass (the kernel returns "not my shape").
 """
 import os
 
@@ -61,6 +64,25 @@ def gemv_fp8w(x, q, s, out=None, R=None, epilogue=ops.EPI_STORE):
                                out.stride(0), 0 if R is None else R.stride(0), epilogue, ops._st())
     _lib.check(rc, "nv_gemv_fp8w")
     return out
+
+
+def gemm_fp8w(x, q, s, out=None, R=None, epilogue=ops.EPI_STORE, mode=0, tile_cfg=0):
+    """the tile GEMM on the codes (nv_gemm_fp8w) -> out, or None when the shape is outside that kernel's range (the caller then runs
+    the de-quantisation pre-pass + the bf16 GEMM)"""
+    M, K = x.shape
+    N = q.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=x.device)
+    rc = ops._L().nv_gemm_fp8w(x.data_ptr(), q.data_ptr(), s.data_ptr(), out.data_ptr(), ops._p(R), M, N, K, x.stride(0), q.stride(0),
+                               out.stride(0), 0 if R is None else R.stride(0), epilogue, mode, tile_cfg,
+                               ops._gemm_ws(x.device) if ops.SPLITK_TAIL else 0, ops._st())
+    if rc == -2:
+        return None
+    _lib.check(rc, "nv_gemm_fp8w")
+    return out
+
+
+FP8_TILE_GEMM = os.environ.get("NAVILLM_FP8_TILE_GEMM", "1") != "0"     # few-hundred-row GEMMs on the codes themselves (round 4)
 
 
 class Fp8DecoderWeights:
@@ -125,6 +147,10 @@ class Fp8DecoderWeights:
         q, s = self.codes[i][kind], self.scales[i][kind]
         if x.shape[0] <= 16 and epilogue in (ops.EPI_STORE, ops.EPI_RESID) and q.shape[1] % 64 == 0:
             return gemv_fp8w(x, q, s, out=out, R=R, epilogue=epilogue)
+        if FP8_TILE_GEMM and self.resident is None and epilogue in (ops.EPI_STORE, ops.EPI_RESID):
+            y = gemm_fp8w(x, q, s, out=out, R=R, epilogue=epilogue)        # None: not a cut-off-tile shape -> pre-pass + bf16 GEMM
+            if y is not None:
+                return y
         if not self.overlap or self.resident is not None:
             return ops.gemm_bf16(ops.NT, x, self.weight(i, kind), out=out, R=R, epilogue=epilogue)
         self.pipe()

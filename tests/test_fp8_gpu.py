@@ -210,3 +210,57 @@ def test_fp8_overlapped_dequantisation_equals_the_in_line_one(monkeypatch):
     assert f1._panels is not None and f0._panels is None
     for a, b in zip(outs["inline"], outs["overlap"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,N,K,tile,resid", [(800, 5120, 5120, 85, False), (500, 15360, 5120, 84, True), (640, 4096, 11008, 85, False),
+                                              (670, 1024, 512, 84, True), (130, 776, 192, 84, False), (800, 27648, 5120, 0, False),
+                                              (900, 5120, 13824, 0, True)])
+def test_tile_gemm_on_fp8_codes_equals_prepass_then_bf16_gemm(M, N, K, tile, resid):
+    """round 4 ("fp8 codes into the GEMM"): nv_gemm_fp8w DMAs the weight tile as e4m3fn bytes and converts it to
+    bf16(s * q) on the MFMA fragment path (mode 7) -- the SAME operand values, K order and tile shape as nv_fp8_dequant_rows followed
+    by the bf16 GEMM on that tile, so the results must be BIT-IDENTICAL (ragged N, K-slices of the split-K tail, residual epilogue
+    included).  Modes 8 / 9 (one v_cvt_scalef32_pk_bf16_fp8 per pair; the scale as the instruction's operand / on the fp32
+    accumulator) are measured here too: 9 must stay within two output spacings, 8 is reported (whether the instruction honours the
+    scale's mantissa is what this run finds out)."""
+    from navillm_amd import fp8, ops
+    torch.manual_seed(3)
+    W = (torch.randn(N, K) * 0.05 * (0.25 + torch.rand(N, 1) * 4)).to(torch.bfloat16).to(DEV)     # row scales over a 16x range
+    x = torch.randn(M, K).to(torch.bfloat16).to(DEV)
+    R = torch.randn(M, N).to(torch.bfloat16).to(DEV) if resid else None
+    q, s = fp8.quantize_rows(W)
+    Wd = fp8.dequantize_rows(q, s)
+    epi = ops.EPI_RESID if resid else ops.EPI_STORE
+    got7 = fp8.gemm_fp8w(x, q, s, R=R, epilogue=epi, mode=7, tile_cfg=tile)
+    if tile == 0 and got7 is None:
+        pytest.skip("the planner does not pick a cut-off tile for this shape on this build")
+    assert got7 is not None
+    cfg = tile
+    if tile == 0:                                        # whichever of the two the planner chose: bit-identical to one of them
+        refs = [ops.gemm_bf16(ops.NT, x, Wd, R=R, epilogue=epi, tile_cfg=c) for c in (84, 85)]
+        assert any(torch.equal(got7, r) for r in refs), "mode 7 differs from the pre-pass + bf16 GEMM on both cut-off tiles"
+        ref = refs[0] if torch.equal(got7, refs[0]) else refs[1]
+    else:
+        ref = ops.gemm_bf16(ops.NT, x, Wd, R=R, epilogue=epi, tile_cfg=cfg)
+        assert torch.equal(got7, ref), f"mode 7: {(got7.float() - ref.float()).abs().max().item()} max abs diff"
+    scale = ref.float().abs().max().item()
+    ulp = 2.0 ** (np.floor(np.log2(scale)) - 7)
+    got9 = fp8.gemm_fp8w(x, q, s, R=R, epilogue=epi, mode=9, tile_cfg=tile)
+    got8 = fp8.gemm_fp8w(x, q, s, R=R, epilogue=epi, mode=8, tile_cfg=tile)
+    d9 = (got9.float() - ref.float()).abs().max().item()
+    d8 = (got8.float() - ref.float()).abs().max().item()
+    print(f"[gemm_fp8w M={M} N={N} K={K} tile={tile}] mode 7 bit-identical; mode 9 (scale on the accumulator) max diff {d9 / ulp:.2f} output spacings, "
+          f"{(got9 != ref).float().mean().item():.3%} of the elements differ; mode 8 (scale operand of v_cvt_scalef32) max diff {d8 / ulp:.2f} spacings, "
+          f"bit-identical: {torch.equal(got8, ref)}")
+    assert d9 <= 2 * ulp
+
+
+def test_tile_gemm_on_fp8_codes_declines_other_shapes():
+    """prefill-sized GEMMs keep the pre-pass: the entry point says "not my shape" (None) instead of running something slower"""
+    from navillm_amd import fp8
+    torch.manual_seed(3)
+    W = (torch.randn(4096, 4096) * 0.05).to(torch.bfloat16).to(DEV)
+    q, s = fp8.quantize_rows(W)
+    x = torch.randn(5000, 4096).to(torch.bfloat16).to(DEV)
+    assert fp8.gemm_fp8w(x, q, s) is None
+    with pytest.raises(Exception):
+        fp8.gemm_fp8w(x, q, s, epilogue=1)

@@ -24,6 +24,7 @@ DEV = "cuda:0"
 # two runs differ in the LAST BIT of the bf16 output -- not by a rounding-point deviation inside the model: switching the
 # attention kernel to HF's rounding points does not move it (tests/test_round2_gpu.py).  Asserted: measured x 1.5, rounded up.
 ULPS_LOGITS = 2.5
+ULPS_FRAME = 1.5      # what evaluating RoPE in the sample frame instead of the batch frame may add (measured 1.0 on G12: see the G12 episode test)
 
 
 def build(cfg, seed=GOLDEN_SEED):
@@ -215,7 +216,12 @@ def test_g12_episode_accumulated_gradients_vs_reference(mode):
         worst_ulps = max(worst_ulps, ulps)
         gap, e_hip, e_ref = maxerr(lg, l16), maxerr(lg, l32), maxerr(l16, l32)
         print(f"[g12 {mode} step {t}] logits |hip-ref_bf16|={gap:.5f} = {ulps:.2f} bf16 ulps; |hip-ref_fp32|={e_hip:.5f} |ref_bf16-ref_fp32|={e_ref:.5f}")
-        assert ulps <= ULPS_LOGITS + (0.5 if mode == "prefix_reuse" else 0.0) and e_hip <= 1.5 * e_ref + 4e-3
+        # prefix_reuse evaluates RoPE in the SAMPLE frame (positions from each sample's first token; the reference: arange(S) over the
+        # batch's left padding).  That alone moves the recompute path from 2.0 to 3.0 spacings on this fixture, and the prefix-reuse
+        # logits are then BIT-IDENTICAL to the recompute path run in that frame (tests/test_parity_r4_gpu.py::
+        # test_rope_frame_isolated_on_the_reference_episode_g12, profiles/r04_parity_rope_frame.txt) -- so its bound is the batch-frame
+        # bound + the measured frame effect (1.0) with the same x1.5 margin
+        assert ulps <= ULPS_LOGITS + (ULPS_FRAME if mode == "prefix_reuse" else 0.0) and e_hip <= 1.5 * e_ref + 4e-3
         top2 = torch.topk(l16.masked_fill(~torch.isfinite(l16), -1e9), 2, dim=1).values
         for b in range(B):
             if (top2[b, 0] - top2[b, 1]).item() > 2 * gap:

@@ -17,7 +17,27 @@ from navillm_amd.params import synth_state_dict  # noqa: E402
 GOLDEN_SEED = 11  # tests/golden/make_golden.py: gen_precision(seed=11)
 
 
+def usable_cpus():
+    """CPUs this process may actually use: min(cpu_count, affinity mask, cgroup quota) -- the MI355X boxes show 256 hardware threads
+    behind a cgroup quota of 16 CPUs, and torch's default of one thread per visible CPU then spends its time throttled (the same
+    oracle layers: 36 s at 256 threads, 0.7 s at 32; profiles/r02_cpu_probe.txt)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def load_oracle():
+    if torch.get_num_threads() > usable_cpus():
+        torch.set_num_threads(usable_cpus())          # the oracle is the only CPU-heavy thing a test process runs
     spec = importlib.util.spec_from_file_location("navillm_oracle", os.path.join(ROOT, "oracle", "navillm_oracle.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
