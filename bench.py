@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--extras-on-tiny", action="store_true", help="run the extras with --model tiny too (rehearsals)")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-3 (mixed tasks) and config-4 (64-step) extra measurements")
     ap.add_argument("--no-profile", action="store_true", help="skip per-launch GEMM event timing")
+    ap.add_argument("--no-tf-batch", action="store_true", help="prefix_reuse mode: run every step's LM forward when the step is called (round-3 form) "
+                    "instead of batching the teacher-forced episode's forward into finish_episode()")
     ap.add_argument("--no-other-mode", action="store_true", help="do not measure the other training mode (kernel traces of one mode)")
     ap.add_argument("--mode", default=os.environ.get("NAVILLM_BENCH_MODE", "prefix_reuse"), choices=["prefix_reuse", "recompute"],
                     help="how the training step treats the prompt's static prefix (instruction + template, ~530 of ~650 tokens): "
@@ -171,6 +173,14 @@ MODE_WHAT = {
     "recompute": "the whole ~650-token prompt goes through the LM forward and backward at every nav step, as the reference's rollout "
                  "does it (tasks/agents/mp3d_agent.py:726,756)",
 }
+
+
+TF_WHAT = ("; round 4: the rollout is imitation learning (teacher forcing: the next action is the teacher's, the next history token the "
+           "fusion output -- neither depends on the LM, tasks/agents/mp3d_agent.py:760-761,774-778), so the steps' LM FORWARD is deferred too: "
+           "model('navigation') returns fuse_embeds at once and a deferred-logits handle, criterion(handle, targets) * w / B and .backward() "
+           "record the loss, and finish_episode() pushes the suffix rows of ALL six steps through the decoder as ONE batch (~4 200 rows per "
+           "GEMM instead of six launches of ~700) before the batched backward (begin_episode(..., teacher_forced=True); sampling / argmax "
+           "rollouts keep the per-step forward)")
 
 
 def roofline_of(timer, dt, steps, mode, model):
@@ -386,7 +396,32 @@ def long_horizon_extra(a, cfg, model, wrapped, crit, device, seed, T=64):
     model.flop_log = None
     model.zero_grad()
     out["training_at_t64"] = {"nav_steps_per_s_per_gpu": round(a.batch * n / dt, 2), "ms_per_step": round(dt / n * 1e3, 1),
-                              "S": int(ep.S_hist[-1]), "algorithmic_tflops": round(fl / dt / 1e12, 1)}
+                              "S": int(ep.S_hist[-1]), "algorithmic_tflops": round(fl / dt / 1e12, 1),
+                              "what": "6 per-step-recompute training steps at the far end of the horizon (the reference's formulation)"}
+    # round 4: the WHOLE 64-step episode as one prefix-reuse training episode -- the steps' deferred backward is flushed in segments
+    # when their rows no longer fit the episode buffers (navillm_amd/episode.py::flush_segment), prompts that reach the 1024-token
+    # truncation limit fall back to the reference's formulation for that step
+    try:
+        from navillm_amd.synthetic import prefix_reuse_episode
+        model.zero_grad()
+        for rep in range(2):
+            ep.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            prefix_reuse_episode(wrapped, crit, ep, T)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            model.zero_grad()
+        stt = model.episode.stats
+        out["training_episode_T64_prefix_reuse"] = {
+            "nav_steps_per_s_per_gpu": round(a.batch * T / dt, 2), "ms_per_step": round(dt / T * 1e3, 1), "steps": T,
+            "segments_flushed": int(stt.get("segments_flushed", 0)), "steps_recomputed_after_left_truncation": int(stt.get("recomputed_steps", 0)),
+            "prefix_rows": int(stt["prefix_rows"]), "suffix_rows_first_last": [int(stt["suffix_rows"][0]), int(stt["suffix_rows"][-1])] if stt["suffix_rows"] else None,
+            "S_last": int(ep.S_hist[-1])}
+    except Exception as e:
+        out["training_episode_T64_prefix_reuse"] = {"error": f"{type(e).__name__}: {e}"}
+        model.episode_abort()
+        model.zero_grad()
     return out
 
 
@@ -399,6 +434,7 @@ def fp8_13b_extra(a, device, seed):
     from navillm_amd.nav_model import NavModel
     from navillm_amd.losses import CrossEntropyLoss
     from navillm_amd.synthetic import SyntheticEpisodes, nav_step, qa_step
+    from navillm_amd import ops
     cfg13 = C.vicuna_13b(image_feat_size=a.feat)
     torch.cuda.synchronize()
     base = torch.cuda.memory_allocated(device)
@@ -456,11 +492,22 @@ def fp8_13b_extra(a, device, seed):
     out["resident_bytes_after_quantisation"] = int(torch.cuda.memory_allocated(device) - base)
     out["lm_buffer_bytes_bf16_before"] = int(lm_bf16)
     measure("fp8_weight_only_nav_steps_per_s")
+    # the same lean form with s[n] applied to the fp32 accumulator instead of to every weight (nv_gemm_fp8w mode 9: one VALU op per pair
+    # of weights on the fragment path; within one output spacing of the exact form)
+    try:
+        f8.gemm_mode = 9
+        ops._L().nv_gemm_fp8w_default_mode(9)
+        measure("fp8_weight_only_accumulator_scale_nav_steps_per_s")
+    finally:
+        f8.gemm_mode = 7
+        ops._L().nv_gemm_fp8w_default_mode(7)
     out["what"] = ("inference nav steps/s per GPU over one 6-step episode (panorama + navigation forward, argmax actions) at B=4 and 8, and "
                    "greedy decoding of 24 tokens at B=8 (prefill included; device-side loop replayed from a hipGraph); decode steps stream "
                    "the fp8 codes (gemv_stream.hip); prefill / K/V-reuse GEMMs read either the de-quantised operands kept resident "
                    "(fp8_codes_plus_resident_bf16: 38 GB of weights) or one shared bf16 scratch panel filled per GEMM (fp8_weight_only: "
-                   "12.7 GB, a 3 B/weight pre-pass; overlapping it with the previous GEMM on a side stream was measured and loses 1-4 %)")
+                   "12.7 GB; round 4: the few-hundred-row GEMMs of K/V-reuse steps multiply with the codes themselves -- weight tile DMA'd as bytes, "
+                   "converted to bf16(s*q) on the MFMA fragment path, bit-identical to the pre-pass (nv_gemm_fp8w mode 7) -- larger GEMMs keep the "
+                   "3 B/weight pre-pass; fp8_weight_only_accumulator_scale: the same with the scale on the fp32 accumulator, mode 9)")
     del m
     torch.cuda.empty_cache()
     return out
@@ -559,8 +606,13 @@ def phase(msg):
     print(f"[bench +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+TF_BATCH = True                # prefix_reuse mode: batch the teacher-forced episode's LM forward into finish_episode() (--no-tf-batch)
+
+
 def main():
+    global TF_BATCH
     a = parse()
+    TF_BATCH = not a.no_tf_batch
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_one_rank_per_gpu(a))
     from navillm_amd.parallel import init_distributed_device, NavDataParallel
@@ -617,7 +669,9 @@ def main():
             pos = i % STEPS_PER_EPISODE
             last = pos == STEPS_PER_EPISODE - 1 or end
             if prefix and pos == 0:
-                model.begin_episode(ep.prefix_ids())          # static prompt prefix: forward once, K/V cached per layer
+                # static prompt prefix: forward once, K/V cached per layer; the rollout is teacher-forced (imitation learning), so the
+                # steps' LM forward is batched into finish_episode() as well (round 4; --no-tf-batch: per-step forward as in round 3)
+                model.begin_episode(ep.prefix_ids(), teacher_forced=TF_BATCH)
             loss, logits = nav_step(wrapped, crit, ep, train=True, last=last, final=last and not prefix)
             if last:
                 if prefix:
@@ -692,6 +746,15 @@ def main():
             whole = {"steps": w_steps, "episodes": 3, "ms_per_step": round(w_dt / w_steps * 1e3, 2),
                      "nav_steps_per_s": round(a.batch * world * w_steps / w_dt, 2),
                      "what": "the headline mode over 3 whole 6-step episodes, same process and model, right after the timed region"}
+            if a.mode == "prefix_reuse" and TF_BATCH:
+                # the round-3 form of the same mode (every step's LM forward runs when the step is called), same window
+                global_tf = TF_BATCH
+                try:
+                    globals()["TF_BATCH"] = False
+                    p_dt, _, _ = run_mode(a.mode, w_steps, 0, 0, world > 1)
+                    whole["per_step_forward_nav_steps_per_s"] = round(a.batch * world * w_steps / p_dt, 2)
+                finally:
+                    globals()["TF_BATCH"] = global_tf
         except Exception as e:
             whole = {"error": f"{type(e).__name__}: {e}"}
     # ---- the OTHER training mode, same process, same model (reported under `other_mode`, never `value`)
@@ -767,7 +830,8 @@ def main():
                                            a.steps, "deferred backward (finish_episode) and " if a.mode == "prefix_reuse" else "",
                                            "; the short last episode makes this figure conservative, see whole_episodes" if a.steps % STEPS_PER_EPISODE else ""),
                        "training_mode": a.mode,
-                       "training_mode_what": MODE_WHAT[a.mode]},
+                       "teacher_forced_forward_batched": bool(TF_BATCH and a.mode == "prefix_reuse"),
+                       "training_mode_what": MODE_WHAT[a.mode] + (TF_WHAT if (TF_BATCH and a.mode == "prefix_reuse") else "")},
         }
         if main_stats is not None:
             line["config"]["token_rows_last_episode"] = {"prefix_once": int(main_stats["prefix_rows"]),

@@ -80,6 +80,8 @@ int nv_gemv_fp8w(const void* A, const void* Wq, const float* scales, void* C, co
  *   semantics).  tile_cfg 0 | 84 | 85; epilogue 0 (store) | 2 (residual); K % 64 == 0, ldq % 16 == 0; workspace as nv_gemm_bf16_ws */
 int nv_gemm_fp8w(const void* A, const void* codes, const float* scales, void* C, const void* R, int M, int N, int K, int lda, int ldq,
                  int ldc, int ldr, int epilogue, int mode, int tile_cfg, void* workspace, void* stream);
+/*   process-wide default for mode = 0 (7 | 9; 0 = query only); returns the previous default */
+int nv_gemm_fp8w_default_mode(int mode);
 
 /* ---- K6: embedding gather + visual-token add, models/modified_lm.py:100-110.
  *   out[m] = table[ids[m]]  or  bf16(f32(table[ids[m]]) + vis[vis_idx[m]])  when vis_idx[m] >= 0 */

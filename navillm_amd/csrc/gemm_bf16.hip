@@ -1423,6 +1423,15 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
 // two-kernel path, not a fallback to another backend.  mode: 0 = default (NV_GEMM_FP8_MODE, else 7), 7 = operands bf16(s*q)
 // bit-exact (what the pre-pass writes), 8 = v_cvt_scalef32 with the scale as its operand, 9 = v_cvt_scalef32 unscaled + s[n] on
 // the fp32 accumulator.  tile_cfg: 0 = planned, 84 / 85 = force the 128 / 160-row tile (tests).  epilogue: EPI_STORE | EPI_RESID.
+static int g_fp8_default_mode = [] { const char* e = getenv("NV_GEMM_FP8_MODE"); const int m = e ? atoi(e) : 0; return (m >= 7 && m <= 9) ? m : 7; }();
+// process-wide default of nv_gemm_fp8w's `mode` (what callers that pass 0 get, e.g. the native decoder loop): 7 | 8 | 9; returns the
+// previous one, mode = 0 only queries.  A deployment choice like the NV_GEMM_* environment knobs, not per-call state.
+extern "C" int nv_gemm_fp8w_default_mode(int mode) {
+    const int prev = g_fp8_default_mode;
+    if (mode >= 7 && mode <= 9) g_fp8_default_mode = mode;
+    return prev;
+}
+
 extern "C" int nv_gemm_fp8w(const void* A, const void* codes, const float* scales, void* C, const void* R, int M, int N, int K, int lda,
                             int ldq, int ldc, int ldr, int epilogue, int mode, int tile_cfg, void* workspace, void* stream) {
     if (!A || !codes || !scales || !C || M < 0 || N < 0 || K <= 0) return NV_ERR_ARG;
@@ -1430,18 +1439,25 @@ extern "C" int nv_gemm_fp8w(const void* A, const void* codes, const float* scale
     if (epilogue == EPI_RESID && !R) return NV_ERR_ARG;
     if (M == 0 || N == 0) return NV_OK;
     if ((lda & 7) || (ldq & 15) || (K & 63) || ((((uintptr_t)A) | ((uintptr_t)codes)) & 15) || (((uintptr_t)scales) & 15)) return NV_ERR_SHAPE;
-    static const int env_mode = [] { const char* e = getenv("NV_GEMM_FP8_MODE"); return e ? atoi(e) : 0; }();
-    if (mode == 0) mode = env_mode ? env_mode : 7;
+    if (mode == 0) mode = g_fp8_default_mode;
     if (mode < 7 || mode > 9) return NV_ERR_ARG;
     const bool can_split = workspace != nullptr;
     int tme;
     if (tile_cfg == 84 || tile_cfg == 85) tme = tile_cfg - 80;
     else if (tile_cfg == 0) {
+        // this kernel (128- or 160-row tile, whichever the launch model prefers) against the alternative the caller would run: the
+        // de-quantisation pre-pass (3 B per weight at ~5 TB/s) + the bf16 GEMM on ITS best tile.  Relative K-step cost against the bf16
+        // loop on the same tile, measured on MI355X (tools/gemm_fp8_probe.py, profiles/r04_gemm_fp8_probe.txt): mode 7 (three VALU ops per
+        // pair of weights) 0.86-1.12, modes 8 / 9 (one) 0.75-0.87 -- the halved B-tile DMA and fragment reads outweigh the conversions.
+        const double t4 = est_us_256(M, N, K, 4, can_split, true), t5 = est_us_256(M, N, K, 5, can_split, true);
+        tme = t4 <= t5 ? 4 : 5;
+        const double t_fp8 = (t4 <= t5 ? t4 : t5) * (mode == 7 ? 1.0 : 0.82);
         double t256;
-        tme = plan_tme(M, N, K, can_split, true, &t256);
-        if (est_us_128(M, N, K, true) < t256) return NV_ERR_SHAPE;
+        plan_tme(M, N, K, can_split, true, &t256);
+        const double t128 = est_us_128(M, N, K, true);
+        const double t_alt = (t128 < t256 ? t128 : t256) + (double)N * (double)K * 3.0 / 5.0e6;
+        if (t_fp8 > t_alt) return NV_ERR_SHAPE;
     } else return NV_ERR_ARG;
-    if (tme != 4 && tme != 5) return NV_ERR_SHAPE;
     GemmArgs p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)codes; p.C = (bf16_t*)C; p.R = (const bf16_t*)R;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldq; p.ldc = ldc; p.ldr = ldr;

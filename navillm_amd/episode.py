@@ -223,7 +223,8 @@ class PrefixEpisode:
     def has_pending_gradients(self):
         """an open episode whose steps ran a backward(): in the deferred forms those gradients exist only here until finish()"""
         P = self.prefix
-        return P is not None and (P.get("kv_steps", 0) > 0 or P.get("segments", 0) > 0 or any(r.get("dH") is not None for r in P.get("recs", ())))
+        return P is not None and (P.get("kv_steps", 0) > 0 or P.get("segments", 0) > 0 or
+                                  any(r.get("dH") is not None or r.get("targets") is not None for r in P.get("recs", ())))
 
     def assert_no_pending_gradients(self, what):
         if self.has_pending_gradients():
@@ -233,8 +234,9 @@ class PrefixEpisode:
 
     # ------------------------------------------------------------------ prefix forward, once per episode
     @torch.no_grad()
-    def begin(self, prefix_ids):
-        """prefix_ids: B python lists of token ids (no visual tokens) -- the part of every prompt of this episode that never changes"""
+    def begin(self, prefix_ids, teacher_forced=False):
+        """prefix_ids: B python lists of token ids (no visual tokens) -- the part of every prompt of this episode that never changes.
+        teacher_forced (round 4; mode "all" only): the steps' LM FORWARD is deferred to finish() too -- see `_forward_lazy`."""
         m, cfg, st = self.m, self.m.cfg, self.m.store
         B, cap, H, hd, eps, L = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers
         self.assert_no_pending_gradients("begin_episode()")
@@ -292,7 +294,8 @@ class PrefixEpisode:
             layers.append(dict(x=x, n1=n1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x1=x1, n2=n2, rstd2=rstd2, gu=gu, h=h))
             x = x2                                     # (dkv_acc needs no zero-fill: the first step SETS the prefix rows)
         self.prefix = dict(ids=[list(p) for p in prefix_ids], ids_np=ids, lens=lens, cu=cu_d, pos=pos_d, crow=crow_d, pos0=zero_pos0,
-                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0, kv_steps=0, defer=defer, lens_dev=lens_d, recs=[], segments=0)
+                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0, kv_steps=0, defer=defer, lens_dev=lens_d, recs=[], segments=0,
+                           lazy=bool(teacher_forced) and allm and defer)
         self.stats = {"prefix_rows": Mp, "suffix_rows": [], "segments_flushed": 0, "recomputed_steps": 0}
 
     def fits(self, ids_list):
@@ -368,6 +371,22 @@ class PrefixEpisode:
                     ids_np=ids_new)
         self.stats["suffix_rows"].append(int(sum(n)))
         anchor = self.m._anchor if torch.is_grad_enabled() else None
+        if P.get("lazy") and torch.is_grad_enabled():
+            # teacher-forced episode: nothing runs now -- the step's rows are reserved in the episode buffers and its whole LM forward
+            # happens in finish() / flush_segment(), batched with every other step's (`_forward_lazy`)
+            step["vis_live"] = vis_all
+            step["batched"] = True
+            if P["recs"] and self._segment_full(self._cursor + M):
+                self.flush_segment()
+            r0 = self._cursor
+            self._ensure_rows(r0 + M)
+            self._cursor = r0 + M
+            k = P["steps"]
+            P["steps"] = k + 1
+            rec = dict(step=step, layers=[], x_last=None, rstdf=None, serial=k + 1, r0=r0, defer=True, batched=True, k=len(P["recs"]), dH=None,
+                       lazy=True, targets=None, scale=None)
+            P["recs"].append(rec)
+            return rec
         if self.mode == "all" and P["defer"] and torch.is_grad_enabled():
             # the LM sees a detached copy; the live tensor keeps this step's scene-encoder / fusion graph alive until finish()
             step["vis_live"] = vis_all
@@ -580,6 +599,91 @@ class PrefixEpisode:
         if dp is not None and dp._exchanging():
             dp._finalize()                         # outside autograd: no engine callback will run the end-of-backward exchange
 
+    def register_loss(self, rec, targets, scale):
+        """DeferredLoss.backward(): CE_sum(logits of step `rec`, targets) * scale is part of the episode's objective"""
+        if rec.get("targets") is not None:
+            raise RuntimeError("a deferred (teacher-forced) navigation step takes ONE loss; its backward() ran twice")
+        rec["targets"] = ops.h2d(torch.as_tensor(targets).to(torch.int64).contiguous(), self.m.device)
+        rec["scale"] = float(scale)
+
+    def _forward_lazy(self, recs):
+        """teacher-forced episode (round 4): the LM forward of ALL recorded steps as ONE batch over their rows [Mp, R) of the episode
+        buffers -- the qkv / o / gate|up / down GEMMs and every row kernel see M = sum of the steps' suffix rows (~4 200 at the bench
+        shape) instead of six launches of ~700 rows (the few-hundred-row forward GEMMs ran at 0.37 of the MFMA peak, the large ones at
+        0.49), the attention stays one launch per step (each step's queries see the cached prefix + its own rows).  Legal because under
+        imitation learning the next step's inputs never depend on the LM: the action is the teacher's (mp3d_agent.py:760-761) and the
+        history token is the FUSION output `fuse_embeds[b, a_t]` (mp3d_agent.py:774-778).  Then the action head and the CE of every
+        step with a registered loss; their gradient w.r.t. the steps' last rows becomes `dH`, exactly what a step's backward() records
+        in the non-lazy form -- the batched backward that follows is unchanged."""
+        from . import functions as Fn
+        P = self.prefix
+        m, cfg, st = self.m, self.m.cfg, self.m.store
+        B, cap, H, hd, eps, L, d, ff = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers, cfg.hidden_size, \
+            cfg.intermediate_size
+        Mp, R = P["Mp"], self._cursor
+        rows = slice(Mp, R)
+        assert recs[0]["r0"] == Mp and recs[-1]["r0"] + recs[-1]["step"]["M"] == R
+        with torch.no_grad():
+            vis_parts, vix_parts, off = [], [], 0
+            for r in recs:
+                sp = r["step"]
+                v = sp.get("vis_live")
+                nv = 0 if v is None else int(v.shape[0])
+                vix_parts.append(torch.where(sp["vix"] >= 0, sp["vix"] + off, sp["vix"]) if off else sp["vix"])
+                if nv:
+                    vis_parts.append(v.detach())
+                off += nv
+            ids_cat = torch.cat([r["step"]["ids"] for r in recs])
+            pos_cat = torch.cat([r["step"]["pos"] for r in recs])
+            vix_cat = torch.cat(vix_parts)
+            vis_cat = torch.cat(vis_parts, 0).contiguous() if vis_parts else None
+            while len(self.lse_s) < len(recs):
+                self.lse_s.append([torch.zeros((B, H, cap), dtype=F32, device=m.device) for _ in range(L)])
+            x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_cat, vix_cat, vis_cat, out=self._E[0]["x"][rows])
+            for i in range(L):
+                Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
+                E, E32 = self._E[i], self._E32[i]
+                n1, _ = ops.rmsnorm_fwd(x, w1, eps, out=E["n1"][rows], rstd=E32["r1"][rows])
+                ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, cap, 2 * H * hd, out=E["qkv"][rows], pos_i32=pos_cat)
+                for r in recs:                      # attention: per step over the K/V cache (prefix rows + this step's rows)
+                    sp = r["step"]
+                    sl = slice(r["r0"], r["r0"] + sp["M"])
+                    ops.scatter_rows_bf16_(E["qkv"][sl], sp["crow"], self.cache[i])
+                    ops.attn_fwd_strided(self.cache[i], self.kv0, B, sp["Lmax"], cap, H, hd, out=self.attn_buf[i], lse2=self.lse_s[r["k"]][i],
+                                         q_row_min=sp["qmin"])
+                    ops._lib.check(ops._L().nv_gather_rows_bf16(self.attn_buf[i].data_ptr(), sp["grow"].data_ptr(), E["attn"][sl].data_ptr(),
+                                                                sp["M"], d, ops._st()), "nv_gather_rows_bf16")
+                x1 = ops.gemm_bf16(ops.NT, E["attn"][rows], Wo, out=E["x1"][rows], R=x, epilogue=ops.EPI_RESID)
+                n2, _ = ops.rmsnorm_fwd(x1, w2, eps, out=E["n2"][rows], rstd=E32["r2"][rows])
+                gu = ops.gemm_bf16(ops.NT, n2, Wgu, out=E["gu"][rows])
+                h = ops.swiglu_fwd(gu, out=E["h"][rows])
+                x = ops.gemm_bf16(ops.NT, h, Wd, out=self._E[i + 1]["x"][rows] if i + 1 < L else self._buf("lz.x2", (R - Mp, d)), R=x1,
+                                  epilogue=ops.EPI_RESID)
+            last_cat = torch.cat([r["step"]["last"] + (r["r0"] - Mp) for r in recs])
+            x_last = ops.gather_rows_bf16(x, last_cat)
+            Hs_all, rstdf = ops.rmsnorm_fwd(x_last, st.p("lang_model.model.norm.weight"), eps)
+        # action head + CE on every step (tiny: B rows each), through the same autograd functions the non-lazy path uses
+        Hs_leaf = Hs_all.detach().requires_grad_(True)
+        total = None
+        with torch.enable_grad():
+            for t, r in enumerate(recs):
+                r["x_last"], r["rstdf"] = x_last[t * B:(t + 1) * B], rstdf[t * B:(t + 1) * B]
+                col, mask_not = r["head"]
+                pred = Fn.HeadBF16.apply(Hs_leaf[t * B:(t + 1) * B], m, "out_head.0")
+                logits = torch.gather(pred, 1, col).masked_fill(mask_not, float("-inf"))
+                r["logits"] = logits.detach()
+                if r.get("targets") is not None:
+                    ls = Fn.ActionCE.apply(logits, r["targets"])
+                    r["loss_sum"] = ls.detach()
+                    total = ls * r["scale"] if total is None else total + ls * r["scale"]
+            if total is not None:
+                total.backward()
+        if Hs_leaf.grad is not None:
+            g = Hs_leaf.grad
+            for t, r in enumerate(recs):
+                if r.get("targets") is not None:
+                    r["dH"] = g[t * B:(t + 1) * B].contiguous()
+
     def flush_segment(self):
         """long episodes (round 4; VERDICT r3 next #7a): run the deferred backward of the steps recorded SO FAR -- their rows [Mp, R) only:
         weight gradients into `.grad`, the K/V gradients they send into the prefix rows into the fp32 accumulators (first segment:
@@ -590,7 +694,7 @@ class PrefixEpisode:
         P = self.prefix
         if P is None or self.mode != "all" or not P["defer"] or not P["recs"]:
             return
-        if any(r["dH"] is None for r in P["recs"]):
+        if any(r["dH"] is None and not (r.get("lazy") and r.get("targets") is not None) for r in P["recs"]):
             raise RuntimeError("prefix-reuse training: the episode's rows must be flushed (they no longer fit / NAVILLM_EPISODE_MAX_ROWS), but a "
                                "recorded step has not run backward() yet; call backward() right after each loss (as the rollout loop does), "
                                "or use NAVILLM_EPISODE_DEFER=none")
@@ -604,6 +708,8 @@ class PrefixEpisode:
         B, cap, H, hd, L, d, ff = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.num_layers, cfg.hidden_size, cfg.intermediate_size
         Mp, R = P["Mp"], self._cursor
         recs = P["recs"]
+        if any(r.get("lazy") and r["x_last"] is None for r in recs):
+            self._forward_lazy(recs)                    # teacher-forced episode: the steps' forward, all at once, then heads + losses
         live = [r for r in recs if r["dH"] is not None]
         seg_before = P["segments"]                      # segments already flushed: dkv_acc holds their sums
         self._last_rows = max(R - Mp, self._last_rows if seg_before else 0)

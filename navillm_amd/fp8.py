@@ -86,8 +86,17 @@ FP8_TILE_GEMM = os.environ.get("NAVILLM_FP8_TILE_GEMM", "1") != "0"     # few-hu
 
 
 class Fp8DecoderWeights:
-    def __init__(self, model, resident_bf16=False):
+    def __init__(self, model, resident_bf16=False, gemm_mode=None):
+        """gemm_mode: how nv_gemm_fp8w turns codes into MFMA operands on few-hundred-row GEMMs -- 7 (default): bf16(s * q), bit-identical to
+        the pre-pass; 9: codes converted unscaled (exact) and s[n] applied to the fp32 accumulator -- one bf16 rounding per weight
+        FEWER than the de-quantised-weights semantics (results within one output spacing of mode 7, tests/test_fp8_gpu.py) and ~20 %
+        faster than the bf16 GEMM itself on these shapes (profiles/r04_gemm_fp8_probe.txt); NAVILLM_FP8_GEMM_MODE sets the default."""
         cfg, st = model.cfg, model.store
+        if gemm_mode is None:
+            gemm_mode = int(os.environ.get("NAVILLM_FP8_GEMM_MODE", "7"))
+        assert gemm_mode in (7, 9), gemm_mode
+        self.gemm_mode = gemm_mode
+        ops._L().nv_gemm_fp8w_default_mode(gemm_mode)          # the native K/V-cache layer loop passes mode 0
         self.codes, self.scales = [], []
         self.resident = [] if resident_bf16 else None          # per layer: the bf16 operands holding bf16(s*q) (views of the flat store)
         with torch.no_grad():
@@ -148,7 +157,7 @@ class Fp8DecoderWeights:
         if x.shape[0] <= 16 and epilogue in (ops.EPI_STORE, ops.EPI_RESID) and q.shape[1] % 64 == 0:
             return gemv_fp8w(x, q, s, out=out, R=R, epilogue=epilogue)
         if FP8_TILE_GEMM and self.resident is None and epilogue in (ops.EPI_STORE, ops.EPI_RESID):
-            y = gemm_fp8w(x, q, s, out=out, R=R, epilogue=epilogue)        # None: not a cut-off-tile shape -> pre-pass + bf16 GEMM
+            y = gemm_fp8w(x, q, s, out=out, R=R, epilogue=epilogue, mode=self.gemm_mode)   # None: not its shape -> pre-pass + bf16 GEMM
             if y is not None:
                 return y
         if not self.overlap or self.resident is not None:

@@ -26,6 +26,7 @@ SIGNATURES = {
     "nv_fp8_decode_table": (i, [vp, vp]),
     "nv_gemv_fp8w": (i, [vp, vp, fp, vp, vp, i, i, i, i, i, i, i, i, vp]),
     "nv_gemm_fp8w": (i, [vp, vp, fp, vp, vp, i, i, i, i, i, i, i, i, i, i, vp, vp]),
+    "nv_gemm_fp8w_default_mode": (i, [i]),
     "nv_embed_vis_bf16": (i, [vp, ip, ip, fp, vp, i, i, vp]),
     "nv_vis_grad_f32": (i, [vp, ip, fp, i, i, vp]),
     "nv_embed_grad_bf16": (i, [vp, ip, ip, ip, vp, i, i, vp]),

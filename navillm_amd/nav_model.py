@@ -218,18 +218,20 @@ class NavModel(nn.Module):
         return ops.gemm_bf16(ops.NT, x, self.lm_w(i, kind), out=out, R=R, epilogue=epilogue)
 
     @torch.no_grad()
-    def to_fp8_weight_only(self, resident_bf16=False):
+    def to_fp8_weight_only(self, resident_bf16=False, gemm_mode=None):
         """Deployment form for inference: decoder Linear weights -> e4m3fn codes + per-output-channel
         scales (navillm_amd/fp8.py); the bf16 copies of those weights and ALL gradient buffers are released.  Irreversible;
         training / backward / state_dict() of the decoder layers are not available afterwards.
         resident_bf16=True trades the memory back for time: the bf16 buffers are kept, overwritten with the de-quantised operand
         bf16(s*q) -- the SAME values the per-call de-quantisation produces -- so prefill / K/V-reuse GEMMs skip the pre-pass while the
-        decode steps still stream the codes (13B: 12.7 GB codes + 25.4 GB bf16 of 288 GB)."""
+        decode steps still stream the codes (13B: 12.7 GB codes + 25.4 GB bf16 of 288 GB).
+        gemm_mode (7 | 9, default NAVILLM_FP8_GEMM_MODE or 7): see fp8.Fp8DecoderWeights -- how the few-hundred-row GEMMs of K/V-reuse
+        steps consume the codes (nv_gemm_fp8w)."""
         from .fp8 import Fp8DecoderWeights
         if self.fp8 is not None:
             return self.fp8
         torch.cuda.synchronize(self.device)
-        self.fp8 = Fp8DecoderWeights(self, resident_bf16=resident_bf16)
+        self.fp8 = Fp8DecoderWeights(self, resident_bf16=resident_bf16, gemm_mode=gemm_mode)
         if resident_bf16:
             self.store.release_grads(self._named)
             self.eval()
@@ -272,14 +274,19 @@ class NavModel(nn.Module):
         return self.kv
 
     # ---- optional training mode: the prompt's static prefix is computed once per episode (navillm_amd/episode.py)
-    def begin_episode(self, prefix_ids, capacity=1024):
+    def begin_episode(self, prefix_ids, capacity=1024, teacher_forced=False):
         """prefix_ids: B lists of token ids -- the part of every navigation prompt of the coming episode that never changes
         (everything up to "### History:").  Until `finish_episode()`, training-mode `model('navigation')` calls push only the rest
         of each prompt through the LM, over the cached prefix (every other mode -- object_grounding included -- takes the full `_lm`
         path: its gradients land in `.grad` at once, as always); `finish_episode()` runs the prefix's one
         backward -- and, in the default `NAVILLM_EPISODE_DEFER=all` form, the steps' LM backward with it: ALL parameter gradients of
         the episode appear there, the steps' `backward()` calls only record their output gradients (navillm_amd/episode.py).
-        Exact up to bf16 rounding order; call it before `optimizer.step()`."""
+        Exact up to bf16 rounding order; call it before `optimizer.step()`.
+        teacher_forced=True (round 4; imitation-learning rollouts only, mp3d_agent.py:514 `feedback="teacher"`): the steps' LM FORWARD is
+        deferred as well -- `model('navigation')` returns `fuse_embeds` at once (the next step's history token) and a
+        `losses.DeferredLogits` handle as `fuse_logits`; `criterion(handle, targets) * coef / B` and `.backward()` work on it as on a
+        tensor (they record targets and scale), and `finish_episode()` pushes ALL the steps through the decoder as one batch before
+        the batched backward.  The logits / loss values exist afterwards (`handle.value`, `float(loss)`)."""
         from .episode import PrefixEpisode
         B = len(prefix_ids)
         if self.episode is not None:
@@ -287,7 +294,7 @@ class NavModel(nn.Module):
             self.episode.assert_no_pending_gradients("begin_episode()")
         if self.episode is None or self.episode.B != B or self.episode.cap != capacity:
             self.episode = PrefixEpisode(self, B, capacity)
-        self.episode.begin(prefix_ids)
+        self.episode.begin(prefix_ids, teacher_forced=teacher_forced)
         return self.episode
 
     def finish_episode(self):
@@ -713,6 +720,11 @@ class NavModel(nn.Module):
                 Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)
         else:
             Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)
+        if isinstance(Hs_cls, dict):
+            # a step of a teacher-forced prefix-reuse episode: the LM forward, the head and the loss run in finish_episode()
+            from .losses import DeferredLogits
+            Hs_cls["head"] = (ops.h2d(col, dev), ops.h2d(cand_masks.logical_not(), dev))
+            return {"fuse_embeds": fuse.detach().view(B, G, d), "fuse_logits": DeferredLogits(self.episode, Hs_cls)}
         pred = Fn.HeadBF16.apply(Hs_cls, self, "out_head.0")   # [B,100]
 
         # fuse_logits[b][cand slots] = [pred[b,0], pred[b,1:n][inv_perm]] ; -inf elsewhere (:234-242)

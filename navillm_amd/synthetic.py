@@ -407,7 +407,9 @@ def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accu
         targets = ep.teacher_targets(nav, last)
         loss = None
         if train:
-            loss = criterion(logits, ops.h2d(targets, logits.device)) * loss_weight / ep.B / accum
+            # (`logits` is a losses.DeferredLogits handle inside a teacher-forced prefix-reuse episode: same two lines, the work happens
+            # in finish_episode())
+            loss = criterion(logits, ops.h2d(targets, getattr(logits, "device", inner.device))) * loss_weight / ep.B / accum
             loss.backward()
         feedback = feedback or ("teacher" if train else "argmax")
         if feedback == "teacher":
@@ -608,13 +610,13 @@ def mixed_task_episode(model, criterion, ep, steps, enable_og=None, enable_summa
     return losses
 
 
-def prefix_reuse_episode(model, criterion, ep, steps, accum=1):
+def prefix_reuse_episode(model, criterion, ep, steps, accum=1, teacher_forced=False):
     """One training episode with the prompt's static prefix computed once (navillm_amd/episode.py): `begin_episode`, `steps`
     navigation steps whose per-step backward()s cover the suffix rows only (all inside the accumulation phase of a data-parallel
     wrapper), then the prefix's single backward -- the LAST backward before the optimizer step, from inside which a
     `NavDataParallel` wrapper exchanges the gradients, layer by layer."""
     inner = model.module if hasattr(model, "module") else model
-    inner.begin_episode(ep.prefix_ids())
+    inner.begin_episode(ep.prefix_ids(), teacher_forced=teacher_forced)
     losses = []
     for t in range(steps):
         losses.append(nav_step(model, criterion, ep, train=True, last=(t == steps - 1), accum=accum, final=False)[0])

@@ -255,12 +255,15 @@ def test_tile_gemm_on_fp8_codes_equals_prepass_then_bf16_gemm(M, N, K, tile, res
 
 
 def test_tile_gemm_on_fp8_codes_declines_other_shapes():
-    """prefill-sized GEMMs keep the pre-pass: the entry point says "not my shape" (None) instead of running something slower"""
-    from navillm_amd import fp8
+    """a shape whose bf16 plan is the full 256-row tile (one exact round of tiles) keeps the pre-pass: the entry point says "not my
+    shape" (None) instead of running something slower; whatever it does accept equals the pre-pass path bit for bit"""
+    from navillm_amd import fp8, ops
     torch.manual_seed(3)
     W = (torch.randn(4096, 4096) * 0.05).to(torch.bfloat16).to(DEV)
     q, s = fp8.quantize_rows(W)
-    x = torch.randn(5000, 4096).to(torch.bfloat16).to(DEV)
-    assert fp8.gemm_fp8w(x, q, s) is None
+    x = torch.randn(4096, 4096).to(torch.bfloat16).to(DEV)           # 16 x 16 = 256 full tiles: exactly one round
+    y = fp8.gemm_fp8w(x, q, s)
+    print(f"[gemm_fp8w 4096^3] served by the fp8 tile kernel: {y is not None}")
+    assert y is None
     with pytest.raises(Exception):
         fp8.gemm_fp8w(x, q, s, epilogue=1)

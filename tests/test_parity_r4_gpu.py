@@ -240,7 +240,7 @@ def test_eight_layer_7b_width_episode_gradients_vs_oracle_autograd():
     assert not bad, bad
 
 
-def _g12_run(m, zb, meta, mode, frame):
+def _g12_run(m, zb, meta, mode, frame, teacher_forced=False):
     from navillm_amd.losses import CrossEntropyLoss
     from test_parity_gpu import _g12_prefix_ids, pano_batch
     B = meta["B"]
@@ -249,7 +249,7 @@ def _g12_run(m, zb, meta, mode, frame):
     m.rope_frame = frame
     crit = CrossEntropyLoss()
     if mode == "prefix_reuse":
-        m.begin_episode(_g12_prefix_ids(zb, meta))
+        m.begin_episode(_g12_prefix_ids(zb, meta), teacher_forced=teacher_forced)
     hist = [[] for _ in range(B)]
     out_l = []
     for t in range(len(meta["steps"])):
@@ -262,7 +262,7 @@ def _g12_run(m, zb, meta, mode, frame):
         batch["input_ids"], batch["attention_mask"] = T(zt["input_ids"]), T(zt["attention_mask"])
         torch.manual_seed(ms["seed_before_nav"])
         out = m("navigation", batch)
-        out_l.append(out["fuse_logits"].detach().float().cpu())
+        out_l.append(out["fuse_logits"])
         tg = torch.tensor(ms["targets"], device=DEV)
         (crit(out["fuse_logits"], tg) * meta["train_ml"] / B / meta["accum"]).backward()
         for b in range(B):
@@ -272,7 +272,7 @@ def _g12_run(m, zb, meta, mode, frame):
         m.finish_episode()
     m.rope_frame = "batch"
     torch.cuda.synchronize()
-    return out_l
+    return [(lg.value if hasattr(lg, "value") else lg).detach().float().cpu() for lg in out_l]
 
 
 def test_rope_frame_isolated_on_the_reference_episode_g12():
@@ -376,3 +376,27 @@ def test_open_episode_guards():
         torch.cuda.synchronize()
         res.append(m.store.grad["lm"].detach().float().clone())
     assert _rel(res[1], res[0]) < 2e-2 and res[0].norm().item() > 0
+
+
+def test_g12_teacher_forced_batched_forward_vs_reference():
+    """the reference's own 3-step episode (fixture G12 is an imitation-learning rollout: the actions are the targets) through the
+    teacher-forced form of the prefix-reuse mode -- every step's LM forward deferred and batched into finish_episode(): logits per step
+    against the reference's bf16 logits (the sample-frame bound, see the RoPE-frame test above), accumulated gradients against the
+    reference's at the G4 / G10 / G12 tolerances, the zero-gradient set identical."""
+    from test_parity_gpu import build, ULPS_LOGITS, ULPS_FRAME
+    from util import grad_fixture_errors
+    zb = gold("g12_episode_bf16.npz")
+    meta = meta_of(zb)
+    m = build(tiny_cfg("bf16"))
+    lg = _g12_run(m, zb, meta, "prefix_reuse", "batch", teacher_forced=True)
+    worst = max(bf16_ulps_at_scale(lg[t], T(zb[f"s{t}/fuse_logits"])) for t in range(len(meta["steps"])))
+    e16 = grad_fixture_errors(zb, "acc", m.store.g)
+    print(f"[g12 teacher-forced] logits worst {worst:.2f} bf16 spacings from the reference; accumulated-gradient rel errs: "
+          f"{ {k: round(v, 4) for k, v in e16.items()} }")
+    assert worst <= ULPS_LOGITS + ULPS_FRAME
+    for k, v in e16.items():
+        assert v < (2.1e-2 if not k.startswith("rownorm/") else 5e-2), (k, v)
+    with_grad = set(str(s_) for s_ in zb["acc/grad_names_with_grad"])
+    for n in m.store.offsets:
+        if n not in with_grad:
+            assert float(m.store.g(n).float().abs().max()) == 0.0, n
