@@ -408,14 +408,14 @@ def long_horizon_extra(a, cfg, model, wrapped, crit, device, seed, T=64):
             ep.reset()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            prefix_reuse_episode(wrapped, crit, ep, T)
+            prefix_reuse_episode(wrapped, crit, ep, T, teacher_forced=TF_BATCH)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             model.zero_grad()
         stt = model.episode.stats
         out["training_episode_T64_prefix_reuse"] = {
             "nav_steps_per_s_per_gpu": round(a.batch * T / dt, 2), "ms_per_step": round(dt / T * 1e3, 1), "steps": T,
-            "segments_flushed": int(stt.get("segments_flushed", 0)), "steps_recomputed_after_left_truncation": int(stt.get("recomputed_steps", 0)),
+            "teacher_forced_forward_batched": bool(TF_BATCH), "segments_flushed": int(stt.get("segments_flushed", 0)), "steps_recomputed_after_left_truncation": int(stt.get("recomputed_steps", 0)),
             "prefix_rows": int(stt["prefix_rows"]), "suffix_rows_first_last": [int(stt["suffix_rows"][0]), int(stt["suffix_rows"][-1])] if stt["suffix_rows"] else None,
             "S_last": int(ep.S_hist[-1])}
     except Exception as e:
@@ -492,22 +492,23 @@ def fp8_13b_extra(a, device, seed):
     out["resident_bytes_after_quantisation"] = int(torch.cuda.memory_allocated(device) - base)
     out["lm_buffer_bytes_bf16_before"] = int(lm_bf16)
     measure("fp8_weight_only_nav_steps_per_s")
-    # the same lean form with s[n] applied to the fp32 accumulator instead of to every weight (nv_gemm_fp8w mode 9: one VALU op per pair
-    # of weights on the fragment path; within one output spacing of the exact form)
+    # (default nv_gemm_fp8w mode 9: codes converted unscaled, s[n] on the fp32 accumulator.)  The same lean form with the operands
+    # converted to bf16(s * q), bit-identical to the pre-pass (mode 7: three VALU ops per pair of weights on the fragment path)
     try:
-        f8.gemm_mode = 9
-        ops._L().nv_gemm_fp8w_default_mode(9)
-        measure("fp8_weight_only_accumulator_scale_nav_steps_per_s")
-    finally:
         f8.gemm_mode = 7
         ops._L().nv_gemm_fp8w_default_mode(7)
+        measure("fp8_weight_only_exact_dequant_operands_nav_steps_per_s")
+    finally:
+        f8.gemm_mode = 9
+        ops._L().nv_gemm_fp8w_default_mode(9)
     out["what"] = ("inference nav steps/s per GPU over one 6-step episode (panorama + navigation forward, argmax actions) at B=4 and 8, and "
                    "greedy decoding of 24 tokens at B=8 (prefill included; device-side loop replayed from a hipGraph); decode steps stream "
                    "the fp8 codes (gemv_stream.hip); prefill / K/V-reuse GEMMs read either the de-quantised operands kept resident "
                    "(fp8_codes_plus_resident_bf16: 38 GB of weights) or one shared bf16 scratch panel filled per GEMM (fp8_weight_only: "
                    "12.7 GB; round 4: the few-hundred-row GEMMs of K/V-reuse steps multiply with the codes themselves -- weight tile DMA'd as bytes, "
-                   "converted to bf16(s*q) on the MFMA fragment path, bit-identical to the pre-pass (nv_gemm_fp8w mode 7) -- larger GEMMs keep the "
-                   "3 B/weight pre-pass; fp8_weight_only_accumulator_scale: the same with the scale on the fp32 accumulator, mode 9)")
+                   "converted on the MFMA fragment path with s[n] applied to the fp32 accumulator (nv_gemm_fp8w mode 9; shapes the kernel declines keep "
+                   "the 3 B/weight pre-pass); fp8_weight_only_exact_dequant_operands: the same with operands bf16(s*q), bit-identical to the "
+                   "pre-pass (mode 7))")
     del m
     torch.cuda.empty_cache()
     return out

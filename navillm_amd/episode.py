@@ -202,8 +202,12 @@ class PrefixEpisode:
         cfg = self.m.cfg
         held = self._row_bytes() * self._ecap if self._E is not None else 0
         one_layer = self._row_bytes() // cfg.num_layers * cap
-        reserve = 2 << 30                                       # the batched backward's [R, .] scratch, allocator slack
-        return self._row_bytes() * cap - held + one_layer + reserve <= free + torch.cuda.memory_reserved(self.m.device) - torch.cuda.memory_allocated(self.m.device)
+        # the batched backward's [R, .] scratch (dx x2, dx1, dattn, dn, dqkv, dgu, dh = 8 d + 3 ff per row: about one layer's worth of
+        # episode buffers) is grow-only as well: what it already holds is credited, what `cap` rows would need is charged
+        scratch_have = sum(t.numel() * t.element_size() for k, t in self._slab.items() if k.startswith("b."))
+        scratch = max(0, (8 * cfg.hidden_size + 3 * cfg.intermediate_size) * 2 * cap * 9 // 8 - scratch_have)
+        reserve = 6 << 30                                       # allocator slack / fragmentation, the step scratch
+        return self._row_bytes() * cap - held + one_layer + scratch + reserve <= free + torch.cuda.memory_reserved(self.m.device) - torch.cuda.memory_allocated(self.m.device)
 
     def _weights(self, i):
         """(Wqkv, Wo, Wgu, Wd, w1, w2, their six gradient views) of layer i: views of the flat store, built once"""

@@ -95,6 +95,7 @@ class SyntheticEpisodes:
         self.fast_maps = fast_maps and os.environ.get("NAVILLM_FAST_MAPS", "1") != "0"     # (env: A/B measurements)
         self.c_collate = os.environ.get("NAVILLM_C_COLLATE", "1") != "0"                   # round 4: the per-step collation in one C call
         self._collator = None
+        self._next_x = None
         self.max_frontier = max_frontier
         self.task = task                  # which agent's prompts: r2r | reverie | soon | cvdn (tasks/agents/*.py)
         self.rng = np.random.RandomState(seed)
@@ -109,6 +110,7 @@ class SyntheticEpisodes:
     def reset(self):
         B = self.B
         self.t = 0
+        self._next_x = None
         self.instr = [self.rng.randint(3, self.cfg.base_vocab_size, size=self.instr_len).tolist() for _ in range(B)]
         self.pos = [{f"e{b}_n0": self.rng.randn(3) * 2.0} for b in range(B)]
         self.cur = [f"e{b}_n0" for b in range(B)]
@@ -168,12 +170,22 @@ class SyntheticEpisodes:
         return {"viewpoint": self.cur[b], "position": self.pos[b][self.cur[b]], "heading": self.heading[b],
                 "elevation": 0.0, "candidate": cands}
 
+    def prefetch_features(self):
+        """draw the NEXT panorama's view features now (same generator, same order of panorama draws) -- called by the inference rollout
+        right after a step's LM has been enqueued, so that this host work (2 ms at B = 8: a stand-in for the feature-DB lookup of
+        tasks/feature_db.py, which does not depend on the model either) overlaps the GPU instead of sitting between the action's
+        arrival and the next step's launches"""
+        if self._next_x is None:
+            self._next_x = torch.randn(self.B, self.N, self.cfg.image_feat_size, generator=self.tgen)
+
     # ---- tensor builders (mp3d_agent.py:143-212, 264-371)
     def panorama_inputs(self, objects=None, first12=False):
         """objects=(lo, hi): also O ~ U{lo..hi} object features per sample (panorama_feature_variable_object, mp3d_agent.py:143-212);
         first12: the 12-view variant of mp3d_agent.py:214-248 (all 36 views, the first 12 flagged navigable, no candidates)"""
         B, N, F = self.B, self.N, self.cfg.image_feat_size
-        x = torch.randn(B, N, F, generator=self.tgen)
+        x, self._next_x = self._next_x, None
+        if x is None:
+            x = torch.randn(B, N, F, generator=self.tgen)
         nav = torch.zeros(B, N, dtype=torch.int64)
         cand_vpids = []
         for b, ob in enumerate(self.obs):
@@ -412,6 +424,8 @@ def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accu
             loss = criterion(logits, ops.h2d(targets, getattr(logits, "device", inner.device))) * loss_weight / ep.B / accum
             loss.backward()
         feedback = feedback or ("teacher" if train else "argmax")
+        if not train and os.environ.get("NAVILLM_PREFETCH_FEATURES", "1") != "0":
+            ep.prefetch_features()                             # host work under the GPU's LM forward, before the wait for the action
         if feedback == "teacher":
             actions = targets
         elif feedback == "sample":

@@ -254,16 +254,28 @@ def test_tile_gemm_on_fp8_codes_equals_prepass_then_bf16_gemm(M, N, K, tile, res
     assert d9 <= 2 * ulp
 
 
-def test_tile_gemm_on_fp8_codes_declines_other_shapes():
-    """a shape whose bf16 plan is the full 256-row tile (one exact round of tiles) keeps the pre-pass: the entry point says "not my
-    shape" (None) instead of running something slower; whatever it does accept equals the pre-pass path bit for bit"""
+def test_tile_gemm_on_fp8_codes_plans_per_shape_and_validates_arguments():
+    """the entry point decides per shape (launch model: its 128 / 160-row tile against the pre-pass + the bf16 GEMM's best tile) and says
+    "not my shape" (None) where the alternative is estimated faster; whatever it accepts in mode 7 equals the pre-pass path on that
+    tile bit for bit; invalid arguments raise"""
     from navillm_amd import fp8, ops
     torch.manual_seed(3)
     W = (torch.randn(4096, 4096) * 0.05).to(torch.bfloat16).to(DEV)
     q, s = fp8.quantize_rows(W)
-    x = torch.randn(4096, 4096).to(torch.bfloat16).to(DEV)           # 16 x 16 = 256 full tiles: exactly one round
-    y = fp8.gemm_fp8w(x, q, s)
-    print(f"[gemm_fp8w 4096^3] served by the fp8 tile kernel: {y is not None}")
-    assert y is None
+    Wd = fp8.dequantize_rows(q, s)
+    served = {}
+    for M in (640, 4096, 5152):
+        x = torch.randn(M, 4096).to(torch.bfloat16).to(DEV)
+        y = fp8.gemm_fp8w(x, q, s, mode=7)
+        served[M] = y is not None
+        if y is not None:
+            assert any(torch.equal(y, ops.gemm_bf16(ops.NT, x, Wd, tile_cfg=c)) for c in (84, 85))
+    print(f"[gemm_fp8w N=K=4096, mode 7] served by the fp8 tile kernel: {served}")
+    assert served[640]
+    x = torch.randn(640, 4096).to(torch.bfloat16).to(DEV)
     with pytest.raises(Exception):
         fp8.gemm_fp8w(x, q, s, epilogue=1)
+    with pytest.raises(Exception):
+        fp8.gemm_fp8w(x, q, s, mode=5)
+    prev = ops._L().nv_gemm_fp8w_default_mode(0)
+    assert prev in (7, 9) and ops._L().nv_gemm_fp8w_default_mode(7) == prev and ops._L().nv_gemm_fp8w_default_mode(prev) == 7
