@@ -107,8 +107,10 @@ def test_fp8_weight_only_navigation_and_generation_vs_reference_on_dequantised_w
         _nav_forward(m, z3)
 
 
-def test_fp8_13b_shaped_layer_vs_fp8_oracle():
-    """BASELINE config 5's layer shape (Vicuna-13B: d=5120, 40 heads, ff=13824) with weight-only fp8, one decoder layer, B=4:
+@pytest.mark.parametrize("gemm_mode", [9, 7])
+def test_fp8_13b_shaped_layer_vs_fp8_oracle(gemm_mode):
+    """(gemm_mode: how nv_gemm_fp8w consumes the codes -- 9 = scale on the fp32 accumulator (default), 7 = operands bf16(s*q).)
+    BASELINE config 5's layer shape (Vicuna-13B: d=5120, 40 heads, ff=13824) with weight-only fp8, one decoder layer, B=4:
     prefill GEMMs on the de-quantised scratch panel (20 / 54 / 108 column tiles) and the pruned-tail rows through
     nv_gemv_fp8w -- against the oracle on de-quantised weights, in bf16 and fp32."""
     from navillm_amd import config as nvcfg
@@ -123,7 +125,7 @@ def test_fp8_13b_shaped_layer_vs_fp8_oracle():
     P16 = synth_state_dict(cfg, 5)
     with torch.no_grad():
         assert m.load_reference_state_dict(P16) == len(P16)
-    m.to_fp8_weight_only()
+    m.to_fp8_weight_only(gemm_mode=gemm_mode)
     Pq16 = O.fp8_weight_only_state_dict(P16)
     Pq32 = {k: v.float() for k, v in Pq16.items()}
     cfg32 = nvcfg.NavConfig(**{**cfg.__dict__, "precision": "fp32"})
