@@ -492,23 +492,24 @@ def fp8_13b_extra(a, device, seed):
     out["resident_bytes_after_quantisation"] = int(torch.cuda.memory_allocated(device) - base)
     out["lm_buffer_bytes_bf16_before"] = int(lm_bf16)
     measure("fp8_weight_only_nav_steps_per_s")
-    # (default nv_gemm_fp8w mode 9: codes converted unscaled, s[n] on the fp32 accumulator.)  The same lean form with the operands
-    # converted to bf16(s * q), bit-identical to the pre-pass (mode 7: three VALU ops per pair of weights on the fragment path)
+    # (default nv_gemm_fp8w mode 7: operands bf16(s * q), bit-identical to the pre-pass.)  The same lean form with the codes converted
+    # unscaled and s[n] applied to the fp32 accumulator (opt-in mode 9: one VALU op per pair of weights; one bf16 rounding per weight off
+    # the de-quantised-weights semantics, within one output spacing per GEMM)
     try:
-        f8.gemm_mode = 7
-        ops._L().nv_gemm_fp8w_default_mode(7)
-        measure("fp8_weight_only_exact_dequant_operands_nav_steps_per_s")
-    finally:
         f8.gemm_mode = 9
         ops._L().nv_gemm_fp8w_default_mode(9)
+        measure("fp8_weight_only_accumulator_scale_nav_steps_per_s")
+    finally:
+        f8.gemm_mode = 7
+        ops._L().nv_gemm_fp8w_default_mode(7)
     out["what"] = ("inference nav steps/s per GPU over one 6-step episode (panorama + navigation forward, argmax actions) at B=4 and 8, and "
                    "greedy decoding of 24 tokens at B=8 (prefill included; device-side loop replayed from a hipGraph); decode steps stream "
                    "the fp8 codes (gemv_stream.hip); prefill / K/V-reuse GEMMs read either the de-quantised operands kept resident "
                    "(fp8_codes_plus_resident_bf16: 38 GB of weights) or one shared bf16 scratch panel filled per GEMM (fp8_weight_only: "
                    "12.7 GB; round 4: the few-hundred-row GEMMs of K/V-reuse steps multiply with the codes themselves -- weight tile DMA'd as bytes, "
-                   "converted on the MFMA fragment path with s[n] applied to the fp32 accumulator (nv_gemm_fp8w mode 9; shapes the kernel declines keep "
-                   "the 3 B/weight pre-pass); fp8_weight_only_exact_dequant_operands: the same with operands bf16(s*q), bit-identical to the "
-                   "pre-pass (mode 7))")
+                   "converted to bf16(s*q) on the MFMA fragment path, bit-identical to the pre-pass (nv_gemm_fp8w mode 7; shapes the kernel declines keep "
+                   "the 3 B/weight pre-pass); fp8_weight_only_accumulator_scale: opt-in mode 9, the codes converted unscaled and s[n] applied to "
+                   "the fp32 accumulator (to_fp8_weight_only(gemm_mode=9)))")
     del m
     torch.cuda.empty_cache()
     return out

@@ -1420,10 +1420,10 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
 // y = x W^T with W given as weight-only fp8: OCP e4m3fn codes [N, K] (ldq bytes per row) + one fp32 scale per output channel.
 // Serves the few-hundred-row GEMMs of K/V-reuse inference steps (the shapes whose launch plan is a 128 / 160-row cut-off tile);
 // any other shape returns NV_ERR_SHAPE and the caller runs nv_fp8_dequant_rows + nv_gemm_bf16 (the pre-pass form) -- a documented
-// two-kernel path, not a fallback to another backend.  mode: 0 = default (nv_gemm_fp8w_default_mode / NV_GEMM_FP8_MODE, else 9), 7 = operands bf16(s*q)
+// two-kernel path, not a fallback to another backend.  mode: 0 = default (nv_gemm_fp8w_default_mode / NV_GEMM_FP8_MODE, else 7), 7 = operands bf16(s*q)
 // bit-exact (what the pre-pass writes), 8 = v_cvt_scalef32 with the scale as its operand, 9 = v_cvt_scalef32 unscaled + s[n] on
 // the fp32 accumulator.  tile_cfg: 0 = planned, 84 / 85 = force the 128 / 160-row tile (tests).  epilogue: EPI_STORE | EPI_RESID.
-static int g_fp8_default_mode = [] { const char* e = getenv("NV_GEMM_FP8_MODE"); const int m = e ? atoi(e) : 0; return (m >= 7 && m <= 9) ? m : 9; }();
+static int g_fp8_default_mode = [] { const char* e = getenv("NV_GEMM_FP8_MODE"); const int m = e ? atoi(e) : 0; return (m >= 7 && m <= 9) ? m : 7; }();
 // process-wide default of nv_gemm_fp8w's `mode` (what callers that pass 0 get, e.g. the native decoder loop): 7 | 8 | 9; returns the
 // previous one, mode = 0 only queries.  A deployment choice like the NV_GEMM_* environment knobs, not per-call state.
 extern "C" int nv_gemm_fp8w_default_mode(int mode) {

@@ -121,6 +121,7 @@ class PrefixEpisode:
         self.lse_s = []                                       # mode "all": per step, per layer lse [B, H, cap] (1 MB each at B = 8)
         self.fuse_kvacc = os.environ.get("NAVILLM_EPISODE_FUSE_KVACC", "1") != "0"
         self._E, self._E32, self._ecap, self._cursor, self._last_rows = None, None, 0, 0, 0
+        self._seg_total = 0                                   # suffix rows of the episode so far that earlier segments already flushed
 
     # ------------------------------------------------------------------ helpers
     def _buf(self, tag, shape, dtype=BF16):
@@ -207,7 +208,9 @@ class PrefixEpisode:
         scratch_have = sum(t.numel() * t.element_size() for k, t in self._slab.items() if k.startswith("b."))
         scratch = max(0, (8 * cfg.hidden_size + 3 * cfg.intermediate_size) * 2 * cap * 9 // 8 - scratch_have)
         reserve = 6 << 30                                       # allocator slack / fragmentation, the step scratch
-        return self._row_bytes() * cap - held + one_layer + scratch + reserve <= free + torch.cuda.memory_reserved(self.m.device) - torch.cuda.memory_allocated(self.m.device)
+        # (what the caching allocator holds but has not handed out is fragmented: count half of it)
+        cached = torch.cuda.memory_reserved(self.m.device) - torch.cuda.memory_allocated(self.m.device)
+        return self._row_bytes() * cap - held + one_layer + scratch + reserve <= free + cached // 2
 
     def _weights(self, i):
         """(Wqkv, Wo, Wgu, Wd, w1, w2, their six gradient views) of layer i: views of the flat store, built once"""
@@ -266,7 +269,15 @@ class PrefixEpisode:
         allm = self.mode == "all"
         if defer:
             self._cursor = 0
-            self._ensure_rows(Mp + max(self._last_rows, Mp))     # first episode: assume the steps add about as many rows as the prefix has
+            # sized for the WHOLE previous episode's suffix rows (first episode: about as many as the prefix has) -- or, when that does
+            # not fit the free memory (long-horizon episodes), for the largest share of it that does: the episode then runs in segments
+            # (flush_segment).  The buffers only grow here, between episodes: growing mid-episode copies, fragments the allocator and
+            # made the first 64-step runs die with 24 GiB reserved-but-unusable.
+            want = max(self._last_rows, Mp)
+            while want > 4096 and not self._rows_fit(int((Mp + want) * 1.1) + 64):
+                want = int(want * 0.6)
+            self._ensure_rows(Mp + want)
+            self._seg_total = 0
             self._cursor = Mp
         x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_d, vix, None,
                           out=self._E[0]["x"][:Mp] if allm else self._buf("pE", (Mp, d)))
@@ -321,10 +332,12 @@ class PrefixEpisode:
         return True
 
     def _segment_full(self, rows):
+        """would the next step's rows overflow the episode buffers?  Then the recorded steps are flushed rather than the buffers grown
+        (they are sized between episodes, see begin()); only a SINGLE step that does not fit makes `_ensure_rows` grow them."""
         cap = int(os.environ.get("NAVILLM_EPISODE_MAX_ROWS", "0") or 0)
         if cap and rows > max(cap, self.prefix["Mp"] + 1):
             return True
-        return rows > self._ecap and not self._rows_fit(int(rows * 1.1) + 64)
+        return rows > self._ecap
 
     # ------------------------------------------------------------------ one step: suffix rows over the cached prefix
     def lm(self, ids_list, vis_idx_list, vis_all):
@@ -716,7 +729,10 @@ class PrefixEpisode:
             self._forward_lazy(recs)                    # teacher-forced episode: the steps' forward, all at once, then heads + losses
         live = [r for r in recs if r["dH"] is not None]
         seg_before = P["segments"]                      # segments already flushed: dkv_acc holds their sums
-        self._last_rows = max(R - Mp, self._last_rows if seg_before else 0)
+        if final:
+            self._last_rows = self._seg_total + (R - Mp)          # the whole episode's suffix rows: what the next episode is sized for
+        else:
+            self._seg_total += R - Mp
         if final:
             self.prefix = None
             self._cursor = 0

@@ -293,7 +293,7 @@ def test_two_rank_rehearsal_on_one_gpu_prints_one_n2_line():
     assert d["other_mode"]["mode"] == "recompute" and d["other_mode"].get("nav_steps_per_s_per_gpu", 0) > 0, d["other_mode"]
 
 
-def _prefix_episode(model, wrapped, seed, steps, dev=DEV):
+def _prefix_episode(model, wrapped, seed, steps, dev=DEV, teacher_forced=False):
     """one prefix-reuse training episode (navillm_amd/episode.py, the bench's default mode): every step's backward() only records its
     output gradient; ALL gradients of the episode appear in finish_episode(), which under the wrapper runs inside `final_backward()`
     and launches the per-layer exchange from the deferred backward walk"""
@@ -302,12 +302,12 @@ def _prefix_episode(model, wrapped, seed, steps, dev=DEV):
     ep = SyntheticEpisodes(model.cfg, 3, seed=seed, instr_len=150, device=torch.device(dev))
     model.zero_grad()
     torch.manual_seed(1)
-    prefix_reuse_episode(wrapped, CrossEntropyLoss(), ep, steps)
+    prefix_reuse_episode(wrapped, CrossEntropyLoss(), ep, steps, teacher_forced=teacher_forced)
     torch.cuda.synchronize()
     return {k: v.clone() for k, v in model.store.grad.items()}
 
 
-def _shared_gpu_rank_prefix(rank, world, port, q, steps_by_rank):
+def _shared_gpu_rank_prefix(rank, world, port, q, steps_by_rank, teacher_forced=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
                       NAVILLM_COMM="torch")
     from navillm_amd.nav_model import NavModel
@@ -318,7 +318,7 @@ def _shared_gpu_rank_prefix(rank, world, port, q, steps_by_rank):
     model.train()
     ddp = NavDataParallel(model, reduce="step")
     p0 = {k: v.clone().cpu() for k, v in model.store.param.items()}
-    g = _prefix_episode(model, ddp, 100 + rank, steps_by_rank[rank], dev=str(dev))
+    g = _prefix_episode(model, ddp, 100 + rank, steps_by_rank[rank], dev=str(dev), teacher_forced=teacher_forced)
     pending = ddp._pending
     opt = FlatAdamW(model, lr=1e-3)
     opt.clip_grad_norm_(40.0)
@@ -333,19 +333,21 @@ def _shared_gpu_rank_prefix(rank, world, port, q, steps_by_rank):
     dist.destroy_process_group()
 
 
-def test_dp_world2_shared_gpu_prefix_reuse_episode_mean_and_replica_consistency():
+@pytest.mark.parametrize("teacher_forced", [False, True])
+def test_dp_world2_shared_gpu_prefix_reuse_episode_mean_and_replica_consistency(teacher_forced):
     """the HEADLINE training mode under data parallelism with two real ranks and the real kernels.  Rank 0 runs a
     2-step episode, rank 1 a 3-step one (ranks may run different numbers of nav steps, mp3d_agent.py:661-676: only the final backward
     synchronises); the exchange is launched from inside finish_episode()'s deferred backward walk under final_backward().  After it both
     ranks hold bit-identical gradients == the mean of the two single-rank prefix-reuse gradients, nothing is left for the optimizer's
-    flush, and after clip + AdamW the replicas are bit-identical."""
+    flush, and after clip + AdamW the replicas are bit-identical.  teacher_forced: the same with the steps' forward deferred and batched
+    into finish_episode() (round 4), i.e. the bench's default training step under data parallelism."""
     import torch.multiprocessing as mp
     from navillm_amd.nav_model import NavModel
     world, steps_by_rank = 2, (2, 3)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_shared_gpu_rank_prefix, args=(r, world, port, q, steps_by_rank)) for r in range(world)]
+    procs = [ctx.Process(target=_shared_gpu_rank_prefix, args=(r, world, port, q, steps_by_rank, teacher_forced)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
@@ -355,8 +357,8 @@ def test_dp_world2_shared_gpu_prefix_reuse_episode_mean_and_replica_consistency(
     (_, g0, ga0, p00, p10, pend0), (_, g1, ga1, p01, p11, pend1) = [(r_[0],) + tuple(unpack(x) for x in r_[1:5]) + (r_[5],) for r_ in res]
     model = NavModel(nav_config=_cfg(), device=torch.device(DEV), seed=4)
     model.train()
-    a = _prefix_episode(model, model, 100, steps_by_rank[0])
-    b = _prefix_episode(model, model, 101, steps_by_rank[1])
+    a = _prefix_episode(model, model, 100, steps_by_rank[0], teacher_forced=teacher_forced)
+    b = _prefix_episode(model, model, 101, steps_by_rank[1], teacher_forced=teacher_forced)
     assert not pend0 and not pend1, "the exchange must have run from inside finish_episode() (final_backward), not be left to the flush"
     for k in a:
         assert torch.equal(p00[k], p01[k]), "parameters were not broadcast from rank 0"

@@ -62,7 +62,8 @@ def test_gemv_fp8w_matches_dequantised_gemm(M, N, K, resid):
     assert ((got - want).abs() > 0).float().mean().item() < 0.05       # only accumulation-order flips of the final rounding
 
 
-def test_fp8_weight_only_navigation_and_generation_vs_reference_on_dequantised_weights():
+@pytest.mark.parametrize("gemm_mode", [7, 9])
+def test_fp8_weight_only_navigation_and_generation_vs_reference_on_dequantised_weights(gemm_mode):
     """end to end on the G3 / G9 inputs: the model after to_fp8_weight_only() against the REFERENCE run on de-quantised weights
     (fixture G11), through the full-recompute path and the K/V cache; greedy generation (decode steps = nv_gemv_fp8w) against
     the oracle on de-quantised weights; memory; inference-only."""
@@ -73,7 +74,10 @@ def test_fp8_weight_only_navigation_and_generation_vs_reference_on_dequantised_w
     cfg = tiny_cfg("bf16")
     m = build(cfg)
     lm_bf16_bytes = m.store.param["lm"].numel() * 2
-    f8 = m.to_fp8_weight_only()
+    f8 = m.to_fp8_weight_only(gemm_mode=gemm_mode)
+    # mode 7 (default) IS the fixture's semantics (operands bf16(s*q)); mode 9 applies s to the fp32 accumulator -- one bf16 rounding per
+    # weight fewer -- and is allowed one more output spacing (measured 2.0 / 3.0 where mode 7 measures 2.0 / 2.5)
+    bound = 2.5 if gemm_mode == 7 else 3.5
     dec = sum(2 * s[0] * s[1] for n, s in m.store.shape_of.items() if n in m.store.released)
     assert f8.bytes <= 0.51 * dec + 4 * 4096 and m.store.param["lm"].numel() * 2 == lm_bf16_bytes - dec     # codes + scales; bf16 copies gone
     assert m.store.grad is None and m.P("lang_model.model.layers.0.self_attn.q_proj.weight").numel() == 0
@@ -84,12 +88,14 @@ def test_fp8_weight_only_navigation_and_generation_vs_reference_on_dequantised_w
     gap_unq = maxerr(out["fuse_logits"], T(z3["fuse_logits"]))
     print(f"[fp8 g11] logits vs reference-on-dequantised-weights: {maxerr(out['fuse_logits'], l16):.5f} = {u:.2f} bf16 ulps "
           f"(distance to the UNquantised reference: {gap_unq:.4f})")
-    assert u <= 2.5 and gap_unq > 4 * maxerr(out["fuse_logits"], l16)
+    assert u <= bound and gap_unq > 4 * maxerr(out["fuse_logits"], l16)
     # through the K/V cache (prefill GEMMs on the de-quantised scratch panel)
     m.enable_kv_cache(3)
     with torch.no_grad():
         _, outc, _ = _nav_forward(m, z3)
-    assert bf16_ulps_at_scale(outc["fuse_logits"], l16) <= 2.5
+    uc = bf16_ulps_at_scale(outc["fuse_logits"], l16)
+    print(f"[fp8 g11 mode {gemm_mode}] through the K/V cache: {uc:.2f} bf16 ulps")
+    assert uc <= bound
     m.kv = None
     # generation: decode steps run on the codes (nv_gemv_fp8w); oracle = greedy recompute on de-quantised weights
     z = gold("g9_generate_bf16.npz")
