@@ -216,6 +216,10 @@ int nv_sumsq(const void* g, long n, int is_bf16, float* partial, int* n_partial_
 int nv_clip_coef(const float* partial, int n_partial, float max_norm, float* out2, void* stream);
 int nv_adamw(void* p, const void* g, void* m, void* v, long n, int is_bf16, double lr, double beta1, double beta2, double eps,
              double wd, int step, const float* clip_out2, void* stream);
+/*   the same with `optimizer.zero_grad()` (train.py:88-89) folded in: g is zeroed as it is consumed -- no separate fill pass over the
+ *   gradient buffer */
+int nv_adamw_zero_grad(void* p, void* g, void* m, void* v, long n, int is_bf16, double lr, double beta1, double beta2, double eps,
+                       double wd, int step, const float* clip, void* stream);
 
 /* ---- fp32 scene encoder + fusion (K1-K5, K12): models/image_embedding.py:51-121,
  *      models/detr_transformer.py:170-182, models/nav_model.py:146-194 */

@@ -332,12 +332,19 @@ class PrefixEpisode:
         return True
 
     def _segment_full(self, rows):
-        """would the next step's rows overflow the episode buffers?  Then the recorded steps are flushed rather than the buffers grown
-        (they are sized between episodes, see begin()); only a SINGLE step that does not fit makes `_ensure_rows` grow them."""
+        """would the next step's rows overflow the episode buffers (sized between episodes, see begin())?  Then the recorded steps are
+        flushed rather than the buffers grown -- except while the buffers are still small (cold start); a SINGLE step that does not fit
+        always makes `_ensure_rows` grow them."""
         cap = int(os.environ.get("NAVILLM_EPISODE_MAX_ROWS", "0") or 0)
         if cap and rows > max(cap, self.prefix["Mp"] + 1):
             return True
-        return rows > self._ecap
+        if rows <= self._ecap:
+            return False
+        # a cold start (first episode of a shape: the buffers were sized for "about as many suffix rows as prefix rows") may still grow
+        # them once or twice while they are small -- so that short episodes run as ONE batch from the first one on, bit-identical to the
+        # later ones; beyond ~3 prefixes' worth of rows (long-horizon episodes) the steps are flushed instead
+        small = int(rows * 1.5) + 64 <= 3 * self.prefix["Mp"] + 4096
+        return not (small and self._rows_fit(int(rows * 1.5) + 64))
 
     # ------------------------------------------------------------------ one step: suffix rows over the cached prefix
     def lm(self, ids_list, vis_idx_list, vis_all):

@@ -66,6 +66,7 @@ SIGNATURES = {
     "nv_sumsq": (i, [vp, l, i, fp, C.POINTER(C.c_int), vp]),
     "nv_clip_coef": (i, [fp, i, f, fp, vp]),
     "nv_adamw": (i, [vp, vp, vp, vp, l, i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i, fp, vp]),
+    "nv_adamw_zero_grad": (i, [vp, vp, vp, vp, l, i, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i, fp, vp]),
     "nv_gemm_f32": (i, [i, fp, fp, fp, fp, i, i, i, i, i, i, i, vp]),
     "nv_gemm_f32_workspace_bytes": (sz, [i, i]),
     "nv_gemm_f32_ws": (i, [i, fp, fp, fp, fp, i, i, i, i, i, i, i, vp, vp]),

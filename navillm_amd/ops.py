@@ -409,8 +409,8 @@ def clip_coef(flat_grads, max_norm, out2=None):
     return out2
 
 
-def adamw_(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01, clip=None):
-    _lib.check(_L().nv_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 1 if p.dtype == BF16 else 0, lr,
+def adamw_(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, wd=0.01, clip=None, zero_grad=False):
+    _lib.check((_L().nv_adamw_zero_grad if zero_grad else _L().nv_adamw)(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), 1 if p.dtype == BF16 else 0, lr,
                              beta1, beta2, eps, wd, step, _p(clip), _st()), "nv_adamw")
 
 

@@ -21,6 +21,8 @@ Optimizer state lives in this flat layout; `load_state_dict` also accepts the re
 (`torch.optim.AdamW.state_dict()` as written by tools/optims.py:65-78 and read back at :26-29) and `reference_state_dict()`
 writes one, so a run can be resumed on either side (the conversion is `reference_optimizer_to_flat` /
 `flat_to_reference_optimizer` below; pinned by tests/golden/g13_optimizer_bf16.npz)."""
+import os
+
 import torch
 from . import ops
 from .params import param_specs
@@ -141,6 +143,11 @@ class FlatAdamW(torch.optim.Optimizer):
         self.store.init_optimizer_state()
         self._clip = torch.ones(2, dtype=torch.float32, device=self.store.device)
         self._clip_valid = False
+        # round 4: `optimizer.zero_grad()` (train.py:89) folded into the update kernel -- the gradient is zeroed as it is consumed, the
+        # zero_grad() that follows only fills the gaps between the updated segments (tensors that never had a gradient: a few % of
+        # the buffer).  NAVILLM_ADAMW_ZERO_GRAD=0: separate full fill as before.
+        self.fused_zero_grad = os.environ.get("NAVILLM_ADAMW_ZERO_GRAD", "1") != "0"
+        self._zeroed_segs = None
 
     # `lr` as an attribute mirrors the single param group (tests / callers that poke it directly)
     @property
@@ -191,11 +198,24 @@ class FlatAdamW(torch.optim.Optimizer):
         for grp, segs in self._segs.items():
             for s, e, born in segs:
                 ops.adamw_(st.param[grp][s:e], st.grad[grp][s:e], st.exp_avg[grp][s:e], st.exp_avg_sq[grp][s:e],
-                           self.step_count - born, lr, b1, b2, eps, wd, clip=clip)
+                           self.step_count - born, lr, b1, b2, eps, wd, clip=clip, zero_grad=self.fused_zero_grad)
         self._clip_valid = False
+        self._zeroed_segs = {grp: [(s, e) for s, e, _ in segs] for grp, segs in self._segs.items()} if self.fused_zero_grad else None
 
     def zero_grad(self, set_to_none=False):
-        self.store.zero_grad()
+        z, self._zeroed_segs = self._zeroed_segs, None
+        if z is None or self.store.grad is None:
+            self.store.zero_grad()
+            return
+        # step() already zeroed every updated segment: fill only what lies between them
+        for grp, g in self.store.grad.items():
+            pos = 0
+            for s, e in sorted(z.get(grp, ())):
+                if s > pos:
+                    g[pos:s].zero_()
+                pos = max(pos, e)
+            if pos < g.numel():
+                g[pos:].zero_()
 
     def state_dict(self):
         """flat-layout state (copies); not a torch.optim.AdamW state dict"""

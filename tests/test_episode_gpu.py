@@ -321,7 +321,7 @@ def test_long_episode_flushes_segments_and_matches_recompute(monkeypatch):
     m.eval()
     steps = 16
     l_ref, g_ref, _ = _episode(m, cfg, steps, use_prefix=False)
-    _episode(m, cfg, steps, use_prefix=True)             # cold: the buffers are sized between episodes, the first long one runs in segments
+    _episode(m, cfg, steps, use_prefix=True)             # cold: the buffers are sized between episodes, a first long one may run in segments
     l_one, g_one, st_one = _episode(m, cfg, steps, use_prefix=True)
     assert st_one["segments_flushed"] == 0
     rows_per_step = max(st_one["suffix_rows"])

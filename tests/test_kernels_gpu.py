@@ -724,3 +724,49 @@ def test_attention_varlen_matches_padded(B, S, H, pads, tail):
             a, b_ = dq_k[:, sl].float(), dq_p[idx][:, sl].float()
             rel = (a - b_).norm() / (b_.norm() + 1e-20)
             assert rel < 2e-2, f"varlen {name}: rel err {rel.item():.3e}"
+
+
+def test_adamw_with_zero_grad_folded_in():
+    """round 4: nv_adamw_zero_grad == nv_adamw bit for bit on p / m / v, and leaves g zeroed (bf16 incl. a ragged tail, fp32);
+    FlatAdamW.step() + zero_grad() then leave EVERY gradient element zero, also where no update ran (the gaps between the updated
+    segments are filled by zero_grad itself)."""
+    from navillm_amd import ops
+    torch.manual_seed(0)
+    for dt, n in ((torch.bfloat16, 100003), (torch.bfloat16, 8 * 4096), (torch.float32, 7777)):
+        p = torch.randn(n, device=DEV).to(dt)
+        g = (torch.randn(n, device=DEV) * 0.1).to(dt)
+        m = (torch.randn(n, device=DEV) * 0.01).to(dt)
+        v = (torch.rand(n, device=DEV) * 0.01).to(dt)
+        a = [t.clone() for t in (p, g, m, v)]
+        b = [t.clone() for t in (p, g, m, v)]
+        ops.adamw_(*a, 3, 1e-3)
+        ops.adamw_(*b, 3, 1e-3, zero_grad=True)
+        torch.cuda.synchronize()
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        assert torch.equal(a[1], g) and float(b[1].float().abs().max()) == 0.0
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.optim import FlatAdamW
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step
+    from navillm_amd.losses import CrossEntropyLoss
+    from test_round2_gpu import _mid_cfg
+    cfg = _mid_cfg()
+    res = {}
+    for fused in (True, False):
+        m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=3)
+        m.eval()
+        opt = FlatAdamW(m, lr=1e-3)
+        opt.fused_zero_grad = fused
+        ep = SyntheticEpisodes(cfg, 2, seed=5, instr_len=60, device=torch.device(DEV))
+        nav_step(m, CrossEntropyLoss(), ep, train=True, last=True)
+        st = m.store
+        n_lm = "lang_model.lm_head.weight"                      # never has a gradient in navigation training: a gap between segments
+        st.g(n_lm).view(-1)[:5].fill_(1.0)
+        opt.clip_grad_norm_(40.0)
+        opt.step()
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        for grp, gbuf in st.grad.items():
+            assert float(gbuf.float().abs().max()) == 0.0, (fused, grp)
+        res[fused] = {k: v.clone() for k, v in st.param.items()}
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), k
