@@ -310,7 +310,7 @@ def mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed):
         for t, ep in eps.items():
             ep.reset()
             t1 = time.perf_counter()
-            mixed_task_episode(wrapped, crit, ep, STEPS_PER_EPISODE, prefix_reuse=True)
+            mixed_task_episode(wrapped, crit, ep, STEPS_PER_EPISODE, prefix_reuse=True, teacher_forced=TF_BATCH)
             opt.clip_grad_norm_(40.0); opt.step(); opt.zero_grad()
             nav_steps += STEPS_PER_EPISODE * a.batch
             torch.cuda.synchronize()
@@ -422,6 +422,7 @@ def long_horizon_extra(a, cfg, model, wrapped, crit, device, seed, T=64):
         out["training_episode_T64_prefix_reuse"] = {"error": f"{type(e).__name__}: {e}"}
         model.episode_abort()
         model.zero_grad()
+    model.episode_release()                      # the long episode's buffers (up to 30 % of the card): the next extra loads a 13B model
     return out
 
 

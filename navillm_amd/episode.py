@@ -195,6 +195,28 @@ class PrefixEpisode:
         per = sum(cd * cfg.hidden_size + cf * cfg.intermediate_size for cd, cf in widths.values()) * 2 + (8 if self.mode == "all" else 0)
         return per * cfg.num_layers
 
+    def _budget_bytes(self):
+        """upper bound for the episode buffers: NAVILLM_EPISODE_MAX_GB, default 30 % of the device's memory (86 GB of 288) -- a long
+        episode otherwise sizes them for whatever happens to be free (150 GB after the first 64-step run) and everything allocated
+        later in the process finds the card full; longer episodes simply run in more segments"""
+        gb = float(os.environ.get("NAVILLM_EPISODE_MAX_GB", "0") or 0)
+        if gb > 0:
+            return int(gb * (1 << 30))
+        if self.m.device.type != "cuda":
+            return 1 << 62
+        return int(0.30 * torch.cuda.get_device_properties(self.m.device).total_memory)
+
+    def release_buffers(self):
+        """drop the per-layer episode buffers and the batched backward's scratch (they are re-created, sized for the next episode, by
+        begin()); only between episodes"""
+        assert self.prefix is None or self._cursor == 0 or not self.prefix.get("recs"), "release_buffers() inside an open episode"
+        self._E, self._E32, self._ecap = None, None, 0
+        for k in [k for k in self._slab if k.startswith("b.") or k.startswith("lz.")]:
+            del self._slab[k]
+        self._last_rows = 0
+        if self.m.device.type == "cuda":
+            torch.cuda.empty_cache()
+
     def _rows_fit(self, cap):
         """would episode buffers of `cap` rows fit?  (what is held now is released layer by layer while the new ones are built)"""
         if self.m.device.type != "cuda":
@@ -274,8 +296,11 @@ class PrefixEpisode:
             # (flush_segment).  The buffers only grow here, between episodes: growing mid-episode copies, fragments the allocator and
             # made the first 64-step runs die with 24 GiB reserved-but-unusable.
             want = max(self._last_rows, Mp)
-            while want > 4096 and not self._rows_fit(int((Mp + want) * 1.1) + 64):
+            budget = self._budget_bytes()
+            while want > 4096 and (self._row_bytes() * (int((Mp + want) * 1.1) + 64) > budget or not self._rows_fit(int((Mp + want) * 1.1) + 64)):
                 want = int(want * 0.6)
+            if self._E is not None and self._ecap > 2.5 * (Mp + want) + 4096:
+                self.release_buffers()                           # a much longer episode ran before: give its rows back
             self._ensure_rows(Mp + want)
             self._seg_total = 0
             self._cursor = Mp
@@ -343,7 +368,7 @@ class PrefixEpisode:
         # a cold start (first episode of a shape: the buffers were sized for "about as many suffix rows as prefix rows") may still grow
         # them once or twice while they are small -- so that short episodes run as ONE batch from the first one on, bit-identical to the
         # later ones; beyond ~3 prefixes' worth of rows (long-horizon episodes) the steps are flushed instead
-        small = int(rows * 1.5) + 64 <= 3 * self.prefix["Mp"] + 4096
+        small = int(rows * 1.5) + 64 <= 3 * self.prefix["Mp"] + 4096 and self._row_bytes() * (int(rows * 1.5) + 64) <= self._budget_bytes()
         return not (small and self._rows_fit(int(rows * 1.5) + 64))
 
     # ------------------------------------------------------------------ one step: suffix rows over the cached prefix

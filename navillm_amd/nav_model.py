@@ -301,6 +301,14 @@ class NavModel(nn.Module):
         if self.episode is not None:
             self.episode.finish()
 
+    def episode_release(self):
+        """give the prefix-reuse episode buffers back (tens of GB after long episodes); the next begin_episode() re-creates them"""
+        if self.episode is not None:
+            self.episode.assert_no_pending_gradients("episode_release()")
+            self.episode.prefix = None
+            self.episode._cursor = 0
+            self.episode.release_buffers()
+
     def episode_abort(self):
         """drop an episode that was begun but will not be finished (its deferred gradients are discarded)"""
         if self.episode is not None:

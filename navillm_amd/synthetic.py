@@ -589,7 +589,7 @@ def qa_step(model, ep, train=True, sync="final", coef=1.0, accum=1, answer_len=8
 
 
 def mixed_task_episode(model, criterion, ep, steps, enable_og=None, enable_summarize=True, enable_fgr2r=True, accum=1, train=True,
-                       prefix_reuse=False):
+                       prefix_reuse=False, teacher_forced=False):
     """One training meta-step of the multi-task mix (BASELINE config 3; rollout of tasks/agents/mp3d_agent.py:593-964 for the
     task `ep.task`): `steps` navigation steps, each with its backward inside `no_sync` except the last; fine-grained R2R
     (embodied_qa + LM loss) on the non-last steps of an R2R episode; on the last step the object-grounding sub-task (SOON /
@@ -604,7 +604,9 @@ def mixed_task_episode(model, criterion, ep, steps, enable_og=None, enable_summa
     inner = model.module if hasattr(model, "module") else model
     prefix_reuse = prefix_reuse and train
     if prefix_reuse:
-        inner.begin_episode(ep.prefix_ids())
+        # teacher_forced: the navigation steps' LM forward is deferred and batched into finish_episode() too (the sub-tasks' prompts
+        # still go through the whole LM when they are called)
+        inner.begin_episode(ep.prefix_ids(), teacher_forced=teacher_forced)
     losses = {"nav": [], "og": None, "sum": None, "fgr2r": []}
     for t in range(steps):
         last = t == steps - 1

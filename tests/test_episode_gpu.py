@@ -276,11 +276,12 @@ def test_prefix_episode_under_the_data_parallel_wrapper_world1():
     comm.close()
 
 
-@pytest.mark.parametrize("task", ["r2r", "reverie"])
-def test_mixed_task_episode_with_navigation_over_cached_prefix(task):
+@pytest.mark.parametrize("task,tf", [("r2r", False), ("reverie", False), ("r2r", True), ("reverie", True)])
+def test_mixed_task_episode_with_navigation_over_cached_prefix(task, tf):
     """BASELINE config 3 in prefix-reuse mode: the navigation steps of a multi-task episode run over the cached prompt prefix while
     its sub-tasks (fine-grained R2R, object grounding, summarization: prompts of their own) go through the whole LM; the prefix's
-    deferred backward comes last.  Accumulated gradients and every loss must match the all-recompute episode."""
+    deferred backward comes last.  Accumulated gradients and every loss must match the all-recompute episode.  tf: the navigation
+    steps' forward deferred as well (teacher-forced episode)."""
     from navillm_amd.nav_model import NavModel
     from navillm_amd.losses import CrossEntropyLoss
     from navillm_amd.synthetic import SyntheticEpisodes, mixed_task_episode
@@ -294,7 +295,7 @@ def test_mixed_task_episode_with_navigation_over_cached_prefix(task):
         m.zero_grad()
         m.store.touched.clear()
         torch.manual_seed(9)
-        losses = mixed_task_episode(m, crit, ep, steps=3, prefix_reuse=prefix)
+        losses = mixed_task_episode(m, crit, ep, steps=3, prefix_reuse=prefix, teacher_forced=tf and prefix)
         torch.cuda.synchronize()
         flat = [float(l.detach()) for l in losses["nav"] + losses["fgr2r"] + [losses["og"], losses["sum"]] if l is not None]
         return flat, {g: t.detach().float().clone() for g, t in m.store.grad.items()}, set(m.store.touched)

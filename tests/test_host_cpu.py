@@ -597,3 +597,39 @@ def test_nav_collate_one_c_call_equals_the_per_map_python_collation():
     small = NavCollator(B, Nv, Gcap=2, pin=False)
     with pytest.raises(Exception, match="nv_nav_collate"):
         small.collate(gmaps, curs, heads, elevs, cands)
+
+
+def test_deferred_loss_handles_of_a_teacher_forced_episode():
+    """host logic of navillm_amd/losses.py (round 4): inside a teacher-forced prefix-reuse episode `fuse_logits` is a handle; the
+    rollout's own lines `loss = criterion(logits, targets) * train_ml / batch_size / accum; loss.backward()` (mp3d_agent.py:750-757)
+    must work on it -- they record targets and the accumulated scale with the episode -- and everything that would need the values
+    before finish_episode() must fail loudly."""
+    from navillm_amd.losses import CrossEntropyLoss, DeferredLogits, DeferredLoss
+
+    class FakeEpisode:
+        def __init__(self):
+            self.calls = []
+
+        def register_loss(self, rec, targets, scale):
+            self.calls.append((rec, targets, scale))
+
+    ep, rec = FakeEpisode(), {}
+    lg = DeferredLogits(ep, rec)
+    crit = CrossEntropyLoss()
+    tg = torch.tensor([2, -100, 0])
+    loss = crit(lg, tg) * 0.4 / 3 / 2
+    assert isinstance(loss, DeferredLoss) and loss.detach() is loss
+    loss.backward()
+    assert len(ep.calls) == 1 and ep.calls[0][0] is rec and ep.calls[0][1] is tg and abs(ep.calls[0][2] - 0.4 / 3 / 2) < 1e-12
+    assert abs((2.0 * crit(lg, tg))._scale - 2.0) < 1e-12                      # __rmul__
+    with pytest.raises(RuntimeError, match="finish_episode"):
+        lg.value
+    with pytest.raises(RuntimeError, match="finish_episode"):
+        float(loss)
+    with pytest.raises(AttributeError):
+        lg.argmax(1)
+    rec["logits"], rec["loss_sum"] = torch.zeros(3, 4), torch.tensor(6.0)       # what finish_episode() leaves behind
+    assert lg.value.shape == (3, 4) and abs(float(loss) - 6.0 * 0.4 / 3 / 2) < 1e-6 and abs(loss.item() - 0.4) < 1e-6
+    # real tensors still take the kernel path (no GPU here: the autograd function is reached and asks for the library / a device)
+    with pytest.raises(NotImplementedError):
+        CrossEntropyLoss(reduction="mean")

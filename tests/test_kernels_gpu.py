@@ -731,6 +731,7 @@ def test_adamw_with_zero_grad_folded_in():
     FlatAdamW.step() + zero_grad() then leave EVERY gradient element zero, also where no update ran (the gaps between the updated
     segments are filled by zero_grad itself)."""
     from navillm_amd import ops
+    DEV = "cuda:0"
     torch.manual_seed(0)
     for dt, n in ((torch.bfloat16, 100003), (torch.bfloat16, 8 * 4096), (torch.float32, 7777)):
         p = torch.randn(n, device=DEV).to(dt)

@@ -22,7 +22,7 @@ for rep in range(reps):
     ep.reset()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    prefix_reuse_episode(model, crit, ep, 6)
+    prefix_reuse_episode(model, crit, ep, 6, teacher_forced=os.environ.get("EPISODE_TF", "1") != "0")
     opt.clip_grad_norm_(40.0); opt.step(); opt.zero_grad()
     torch.cuda.synchronize()
     print(f"episode {rep}: {(time.perf_counter() - t0) * 1e3:.1f} ms -> {48 / (time.perf_counter() - t0):.1f} nav-steps/s", flush=True)
