@@ -51,8 +51,8 @@ def _hip_episode(m, cfg, B, steps, mode, seed, instr_len, frame="batch", ragged=
     m.zero_grad()
     m.store.touched.clear()
     m.rope_frame = frame
-    if mode == "prefix_reuse":
-        m.begin_episode(ep.prefix_ids())
+    if mode.startswith("prefix_reuse"):
+        m.begin_episode(ep.prefix_ids(), teacher_forced=mode.endswith("_tf"))
     recs = []
     for t in range(steps):
         pin = ep.panorama_inputs()
@@ -67,7 +67,7 @@ def _hip_episode(m, cfg, B, steps, mode, seed, instr_len, frame="batch", ragged=
         lg = out["fuse_logits"]
         tg = ep.teacher_targets(nav, last=False)
         (crit(lg, tg.to(DEV)) / B).backward()
-        rec = dict(logits=lg.detach().float().cpu(), targets=tg.clone(), S=int(ids.shape[1]))
+        rec = dict(logits=lg, targets=tg.clone(), S=int(ids.shape[1]))      # (a deferred-logits handle in the teacher-forced form)
         if keep_inputs:
             cpu = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in nav.items()}
             cpu["hist_vis"] = [[v.detach().cpu() for v in vis] for vis in nav["hist_vis"]]
@@ -76,11 +76,13 @@ def _hip_episode(m, cfg, B, steps, mode, seed, instr_len, frame="batch", ragged=
                        fuse_embeds=out["fuse_embeds"].detach().cpu())
         recs.append(rec)
         ep.advance(nav, tg, out["fuse_embeds"])
-    if mode == "prefix_reuse":
+    if mode.startswith("prefix_reuse"):
         m.finish_episode()
         assert m.episode.prefix is None
     m.rope_frame = "batch"
     torch.cuda.synchronize()
+    for r in recs:
+        r["logits"] = (r["logits"].value if hasattr(r["logits"], "value") else r["logits"]).detach().float().cpu()
     flat = {g: t.detach().clone() for g, t in m.store.grad.items()}
     named = {n: m.store.g(n).detach().float().cpu().clone() for n in grad_names}
     return recs, flat, named
@@ -129,11 +131,19 @@ def test_full_depth_7b_b8_episode_prefix_reuse_vs_recompute_vs_oracle():
         print(f"[7b-full-depth-episode] gradient buffer '{g}' prefix_reuse vs recompute: rel {rel:.4f}  cosine {cos:.5f}  |g| {nrm:.4e}")
         # full depth amplifies last-bit differences (the SAME path, packed vs padded rows: 7.7 % in gradient norm)
         assert rel < 0.15 and cos > 0.99, (g, rel, cos)
-    del g_rc, g_pr
+    del g_pr
+    torch.cuda.empty_cache()
+    # the bench's default form: the same mode with the steps' forward batched into finish_episode() (teacher-forced episode)
+    tf, g_tf, _ = _hip_episode(m, cfg, B, steps, "prefix_reuse_tf", 77, 512)
+    for g in g_rc:
+        rel, cos, nrm = _rel_cos_big(g_tf[g], g_rc[g])
+        print(f"[7b-full-depth-episode] gradient buffer '{g}' prefix_reuse + teacher-forced batch vs recompute: rel {rel:.4f}  cosine {cos:.5f}")
+        assert rel < 0.15 and cos > 0.99, (g, rel, cos)
+    del g_rc, g_tf
     torch.cuda.empty_cache()
     cfg32 = nvcfg.NavConfig(**{**cfg.__dict__, "precision": "fp32"})
     P32 = _LazyF32(P16)
-    decided_all = agree_rc = agree_pr = rows = 0
+    decided_all = agree_rc = agree_pr = agree_tf = rows = 0
     for t in range(steps):
         t0 = time.time()
         o16 = _oracle_logits(O, P16, cfg, rc[t], t)
@@ -146,7 +156,7 @@ def test_full_depth_7b_b8_episode_prefix_reuse_vs_recompute_vs_oracle():
         e_ref = (o16[fin] - o32[fin]).abs().max().item()
         line = f"[7b-full-depth-episode step {t}] S={rc[t]['S']} oracle bf16 {t1 - t0:.0f} s / fp32 {t2 - t1:.0f} s; |orc16-orc32|={e_ref:.4f}"
         gaps = {}
-        for tag, rec in (("recompute", rc[t]), ("prefix_reuse", pr[t])):
+        for tag, rec in (("recompute", rc[t]), ("prefix_reuse", pr[t]), ("prefix_reuse_tf", tf[t])):
             lg = rec["logits"]
             assert torch.equal(torch.isfinite(lg), fin)
             e_hip = (lg[fin] - o32[fin]).abs().max().item()
@@ -164,11 +174,13 @@ def test_full_depth_7b_b8_episode_prefix_reuse_vs_recompute_vs_oracle():
             a16 = int(o16[b].argmax())
             agree_rc += int(rc[t]["logits"][b].argmax()) == a16
             agree_pr += int(pr[t]["logits"][b].argmax()) == a16
+            agree_tf += int(tf[t]["logits"][b].argmax()) == a16
             if (top2[b, 0] - top2[b, 1]).item() > 2 * max(gaps.values()):
                 decided_all += 1
                 assert int(rc[t]["logits"][b].argmax()) == a16, ("recompute", t, b)
                 assert int(pr[t]["logits"][b].argmax()) == a16, ("prefix_reuse", t, b)
-    print(f"[7b-full-depth-episode] argmax vs the bf16 oracle over {rows} rows: recompute {agree_rc}, prefix_reuse {agree_pr} agree; "
+                assert int(tf[t]["logits"][b].argmax()) == a16, ("prefix_reuse_tf", t, b)
+    print(f"[7b-full-depth-episode] argmax vs the bf16 oracle over {rows} rows: recompute {agree_rc}, prefix_reuse {agree_pr}, teacher-forced batch {agree_tf} agree; "
           f"{decided_all} rows have a top-2 margin > 2 x the larger gap (asserted exact there)")
     del m
     torch.cuda.empty_cache()
@@ -199,6 +211,7 @@ def test_eight_layer_7b_width_episode_gradients_vs_oracle_autograd():
         assert m.load_reference_state_dict(P16) == len(P16)
     rc, _, n_rc = _hip_episode(m, cfg, B, steps, "recompute", 83, 512, ragged=37, keep_inputs=True, grad_names=GRAD_NAMES)
     pr, _, n_pr = _hip_episode(m, cfg, B, steps, "prefix_reuse", 83, 512, ragged=37, grad_names=GRAD_NAMES)
+    _, _, n_tf = _hip_episode(m, cfg, B, steps, "prefix_reuse_tf", 83, 512, ragged=37, grad_names=GRAD_NAMES)
     del m
     torch.cuda.empty_cache()
     cfg32 = nvcfg.NavConfig(**{**cfg.__dict__, "precision": "fp32"})
@@ -227,7 +240,7 @@ def test_eight_layer_7b_width_episode_gradients_vs_oracle_autograd():
     for n in GRAD_NAMES:
         base = _rel(og["bf16"][n], og["fp32"][n])
         line = f"[8-layer grad] {n}: |orc16-orc32| {base:.4f}"
-        for tag, g in (("recompute", n_rc[n]), ("prefix_reuse", n_pr[n])):
+        for tag, g in (("recompute", n_rc[n]), ("prefix_reuse", n_pr[n]), ("prefix_reuse_tf", n_tf[n])):
             e16, e32 = _rel(g, og["bf16"][n]), _rel(g, og["fp32"][n])
             line += f"; {tag} vs orc16 {e16:.4f} vs orc32 {e32:.4f}"
             worst[tag] = max(worst.get(tag, 0.0), e16)
