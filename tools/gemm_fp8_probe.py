@@ -11,7 +11,7 @@ from gemm_probe import bench
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 for d, ff in ((5120, 13824), (4096, 11008)):
-    for M in (500, 670, 800, 1000):
+    for M in [int(x) for x in os.environ.get("PROBE_M", "500,670,800,1000").split(",")]:
         for (N, K) in ((3 * d, d), (d, d), (2 * ff, d), (d, ff)):
             X = [torch.randn(M, K, device=dev, generator=g).bfloat16() for _ in range(4)]
             W = [(torch.randn(N, K, device=dev, generator=g) * 0.02).bfloat16() for _ in range(4)]
@@ -20,7 +20,7 @@ for d, ff in ((5120, 13824), (4096, 11008)):
             scratch = torch.empty_like(W[0])
             fl = 2.0 * M * N * K
             line = f"M={M:5d} N={N:6d} K={K:6d}:"
-            for tile in (84, 85):
+            for tile in [int(x) for x in os.environ.get("PROBE_TILES", "84,85").split(",")]:
                 t_b = bench([lambda i=i: ops.gemm_bf16(0, X[i], WD[i], tile_cfg=tile) for i in range(4)], iters=12)
                 t_p = bench([lambda i=i: ops.gemm_bf16(0, X[i], fp8.dequantize_rows(QS[i][0], QS[i][1], out=scratch), tile_cfg=tile) for i in range(4)], iters=12)
                 line += f"  tile{tile}: bf16 {t_b * 1e6:6.1f} us ({fl / t_b / 1e12:5.0f} TF) prepass+bf16 {t_p * 1e6:6.1f}"
