@@ -227,6 +227,11 @@ int nv_decoder_extend(const nv_decoder* p, const void* x_in, const int* pos, con
     auto lin = [&](const Layer& ly, int i, int kind, const void* xin, void* out, const void* R, int N, int K) {
         return pipe.on ? pipe.linear(4 * i + kind, xin, out, R, M) : linear(p, ly, kind, xin, out, R, M, N, K, stream);
     };
+    // Pruned tail (round 4; what LlamaStack does on the training / recompute path since round 1): the caller reads only each sample's LAST
+    // row (nav_model.py:237: the <cls_1> row feeds the action head), so after the last layer's K/V have entered the cache its
+    // o_proj / MLP / final norm run on B rows -- weight-streaming GEMVs -- instead of M.  NV_DECODER_PRUNE_TAIL=0: the full rows.
+    static const bool prune_knob = [] { const char* e = getenv("NV_DECODER_PRUNE_TAIL"); return !e || e[0] != '0'; }();
+    const bool prune_tail = prune_knob && hs_out && !hs_all && !dyn && !fused && !pipe.on && M > 16 && B <= 16;
     for (int i = 0; i < p->L; ++i) {
         const Layer& ly = p->layers[i];
         if (!ly.norm1 || !ly.norm2 || !ly.kv) return NV_ERR_ARG;
@@ -261,6 +266,22 @@ int nv_decoder_extend(const nv_decoder* p, const void* x_in, const int* pos, con
             if (dyn) NV_TRY(nv_attn_fwd_strided_dyn_bf16(ly.kv, attn_buf, lse, kv0, B, cap, p->H, p->hd, dyn, stream));
             else NV_TRY(nv_attn_fwd_strided_bf16(ly.kv, attn_buf, lse, kv0, B, Lmax, cap, p->H, p->hd, q_row_min, stream));
             NV_TRY(nv_gather_rows_bf16(attn_buf, grow, attn, M, (int)d, stream));
+        }
+        if (prune_tail && i == p->L - 1) {
+            // the B last rows only; scratch: the q|k|v block (its rows are in the cache now) holds x_l | attn_l | x1_l
+            char* q8 = (char*)qkv;
+            void* x_l = q8;
+            void* attn_l = q8 + align_up((size_t)B * d * 2);
+            void* x1_l = q8 + 2 * align_up((size_t)B * d * 2);
+            NV_TRY(nv_gather_rows_bf16(x, last, x_l, B, (int)d, stream));
+            NV_TRY(nv_gather_rows_bf16(attn, last, attn_l, B, (int)d, stream));
+            NV_TRY(linear(p, ly, 1, attn_l, x1_l, x_l, B, (int)d, (int)d, stream));           // M = B <= 16: the weight streamers
+            NV_TRY(nv_rmsnorm_fwd_bf16(x1_l, ly.norm2, n, rstd, B, (int)d, p->eps, stream));
+            NV_TRY(linear(p, ly, 2, n, gu, nullptr, B, 2 * (int)ff, (int)d, stream));
+            NV_TRY(nv_swiglu_fwd_bf16(gu, h, B, (int)ff, stream));
+            NV_TRY(linear(p, ly, 3, h, x2, x1_l, B, (int)d, (int)ff, stream));
+            NV_TRY(nv_rmsnorm_fwd_bf16(x2, p->final_norm, hs_out, rstd, B, (int)d, p->eps, stream));
+            return NV_OK;
         }
         NV_TRY(lin(ly, i, 1, attn, x1, x, (int)d, (int)d));                                  // x1 = x + o_proj(attn)
         NV_TRY(nv_rmsnorm_fwd_bf16(x1, ly.norm2, n, rstd, M, (int)d, p->eps, stream));

@@ -96,6 +96,7 @@ class SyntheticEpisodes:
         self.c_collate = os.environ.get("NAVILLM_C_COLLATE", "1") != "0"                   # round 4: the per-step collation in one C call
         self._collator = None
         self._next_x = None
+        self._tok_cache = {}
         self.max_frontier = max_frontier
         self.task = task                  # which agent's prompts: r2r | reverie | soon | cvdn (tasks/agents/*.py)
         self.rng = np.random.RandomState(seed)
@@ -111,6 +112,7 @@ class SyntheticEpisodes:
         B = self.B
         self.t = 0
         self._next_x = None
+        self._tok_cache = {}
         self.instr = [self.rng.randint(3, self.cfg.base_vocab_size, size=self.instr_len).tolist() for _ in range(B)]
         self.pos = [{f"e{b}_n0": self.rng.randn(3) * 2.0} for b in range(B)]
         self.cur = [f"e{b}_n0" for b in range(B)]
@@ -347,7 +349,15 @@ class SyntheticEpisodes:
         seqs = []
         for b in range(self.B):
             p = navigation_prompt(self.task, "{INSTR}", len(self.history[b]), int(cand_nums[b]), cls_token)
-            seqs.append(self.tok.encode(p, self.instr[b]))
+            # the static prefix (task sentence + 512 instruction tokens + history header) is encoded once per episode; per step only
+            # the rest of the prompt goes through the tokenizer (the stub splits on whitespace and the cut sits on one, so the
+            # concatenation equals encode(p): tests/test_host_cpu.py)
+            head = static_prefix(p)
+            key = (b, head)
+            if self._tok_cache.get("key%d" % b) != key:
+                self._tok_cache["key%d" % b] = key
+                self._tok_cache[b] = self.tok.encode(head, self.instr[b])
+            seqs.append(self._tok_cache[b] + self.tok.encode(p[len(head):], self.instr[b])[1:])
         ids, am = self.tok.pad_left(seqs)
         self.S_hist.append(ids.shape[1])
         return ids, am

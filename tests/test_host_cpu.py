@@ -633,3 +633,17 @@ def test_deferred_loss_handles_of_a_teacher_forced_episode():
     # real tensors still take the kernel path (no GPU here: the autograd function is reached and asks for the library / a device)
     with pytest.raises(NotImplementedError):
         CrossEntropyLoss(reduction="mean")
+
+
+def test_stub_tokeniser_prefix_cache_equals_full_encode():
+    """the synthetic driver encodes the static prompt prefix once per episode and only the rest per step: ids == encode(whole prompt)"""
+    from navillm_amd.synthetic import StubTokenizer
+    from navillm_amd.prompts import navigation_prompt, static_prefix
+    cfg = tiny_cfg("bf16")
+    tok = StubTokenizer(cfg)
+    instr = list(range(5, 45))
+    for task in ("r2r", "reverie", "soon", "cvdn"):
+        for t, k in ((0, 2), (3, 7), (11, 30)):
+            p = navigation_prompt(task, "{INSTR}", t, k, "<cls_1>")
+            head = static_prefix(p)
+            assert tok.encode(head, instr) + tok.encode(p[len(head):], instr)[1:] == tok.encode(p, instr), (task, t, k)
