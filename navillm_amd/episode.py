@@ -688,6 +688,9 @@ class PrefixEpisode:
             vis_cat = torch.cat(vis_parts, 0).contiguous() if vis_parts else None
             while len(self.lse_s) < len(recs):
                 self.lse_s.append([torch.zeros((B, H, cap), dtype=F32, device=m.device) for _ in range(L)])
+            last_cat = torch.cat([r["step"]["last"] + (r["r0"] - Mp) for r in recs])
+            prune_top = os.environ.get("NAVILLM_EPISODE_PRUNE_TOP", "1") != "0" and L > 1
+            P.pop("top", None)
             x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_cat, vix_cat, vis_cat, out=self._E[0]["x"][rows])
             for i in range(L):
                 Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
@@ -702,14 +705,27 @@ class PrefixEpisode:
                                          q_row_min=sp["qmin"])
                     ops._lib.check(ops._L().nv_gather_rows_bf16(self.attn_buf[i].data_ptr(), sp["grow"].data_ptr(), E["attn"][sl].data_ptr(),
                                                                 sp["M"], d, ops._st()), "nv_gather_rows_bf16")
+                if i == L - 1 and prune_top:
+                    # the top layer feeds only each sample's LAST row of every step (nav_model.py:237) -- after its K/V projection and
+                    # attention, o_proj / MLP run on those T*B rows instead of on every suffix row (what LlamaStack's pruned last layer
+                    # does on the recompute path); the batched backward mirrors it (`top`)
+                    x_l = ops.gather_rows_bf16(x, last_cat)
+                    attn_l = ops.gather_rows_bf16(E["attn"][rows], last_cat)
+                    x1_l = ops.gemm_bf16(ops.NT, attn_l, Wo, R=x_l, epilogue=ops.EPI_RESID)
+                    n2_l, r2_l = ops.rmsnorm_fwd(x1_l, w2, eps)
+                    gu_l = ops.gemm_bf16(ops.NT, n2_l, Wgu)
+                    h_l = ops.swiglu_fwd(gu_l)
+                    x_last = ops.gemm_bf16(ops.NT, h_l, Wd, R=x1_l, epilogue=ops.EPI_RESID)
+                    P["top"] = dict(idx=last_cat, attn=attn_l, x1=x1_l, n2=n2_l, r2=r2_l, gu=gu_l, h=h_l)
+                    break
                 x1 = ops.gemm_bf16(ops.NT, E["attn"][rows], Wo, out=E["x1"][rows], R=x, epilogue=ops.EPI_RESID)
                 n2, _ = ops.rmsnorm_fwd(x1, w2, eps, out=E["n2"][rows], rstd=E32["r2"][rows])
                 gu = ops.gemm_bf16(ops.NT, n2, Wgu, out=E["gu"][rows])
                 h = ops.swiglu_fwd(gu, out=E["h"][rows])
                 x = ops.gemm_bf16(ops.NT, h, Wd, out=self._E[i + 1]["x"][rows] if i + 1 < L else self._buf("lz.x2", (max(R, self._ecap) - Mp, d))[:R - Mp], R=x1,
                                   epilogue=ops.EPI_RESID)
-            last_cat = torch.cat([r["step"]["last"] + (r["r0"] - Mp) for r in recs])
-            x_last = ops.gather_rows_bf16(x, last_cat)
+            if not (prune_top and "top" in P):
+                x_last = ops.gather_rows_bf16(x, last_cat)
             Hs_all, rstdf = ops.rmsnorm_fwd(x_last, st.p("lang_model.model.norm.weight"), eps)
         # action head + CE on every step (tiny: B rows each), through the same autograd functions the non-lazy path uses
         Hs_leaf = Hs_all.detach().requires_grad_(True)
@@ -789,10 +805,17 @@ class PrefixEpisode:
             dqkv, dgu, dh = self._buf("b.dqkv", (Rc, 3 * d))[:R], self._buf("b.dgu", (Rc, 2 * ff))[:R], self._buf("b.dh", (Rc, ff))[:R]
             # gradient of the stack's output: the final norm's backward on each step's B last-token rows; zero everywhere else (the
             # top layer's prefix rows feed nothing, a step without a backward contributes nothing)
-            dx.zero_()
-            for r in live:
-                dx_last = ops.rmsnorm_bwd(r["dH"], r["x_last"], normw, r["rstdf"], gnormw)
-                ops.scatter_rows_bf16_(dx_last, r["step"]["last"], dx[r["r0"]:r["r0"] + r["step"]["M"]])
+            top = P.pop("top", None)                   # teacher-forced forward with the pruned top layer: its tail ran on T*B rows
+            if top is not None:
+                dxl = torch.zeros((len(recs) * B, d), dtype=BF16, device=m.device)
+                for t, r in enumerate(recs):
+                    if r["dH"] is not None:
+                        dxl[t * B:(t + 1) * B] = ops.rmsnorm_bwd(r["dH"], r["x_last"], normw, r["rstdf"], gnormw)
+            else:
+                dx.zero_()
+                for r in live:
+                    dx_last = ops.rmsnorm_bwd(r["dH"], r["x_last"], normw, r["rstdf"], gnormw)
+                    ops.scatter_rows_bf16_(dx_last, r["step"]["last"], dx[r["r0"]:r["r0"] + r["step"]["M"]])
             Mz = max([r["step"]["M"] for r in recs] or [1])
             zeros_md = self._buf("zeros_md", (Mz, d))
             zeros_md.zero_()
@@ -818,7 +841,22 @@ class PrefixEpisode:
                 # the top layer's prefix rows feed nothing (only their K/V carry gradient): its MLP / o_proj backward covers the steps' rows
                 # only; a segment flush (final=False) never touches the prefix rows
                 lo = Mp if (i == L - 1 or not final) else 0
-                if R > lo:
+                if i == L - 1 and top is not None:
+                    # the pruned tail's backward on the T*B last rows; what flows on into the attention output / the residual stream is
+                    # zero everywhere else
+                    dh_l = ops.gemm_bf16(ops.NN, dxl, Wd)
+                    ops.gemm_bf16(ops.TN, dxl, top["h"], out=gd, epilogue=ops.EPI_ACCUM)
+                    dgu_l = ops.swiglu_bwd(top["gu"], dh_l)
+                    dn_l = ops.gemm_bf16(ops.NN, dgu_l, Wgu)
+                    ops.gemm_bf16(ops.TN, dgu_l, top["n2"], out=ggu, epilogue=ops.EPI_ACCUM)
+                    dx1_l = ops.rmsnorm_bwd(dn_l, top["x1"], w2, top["r2"], gw2, resid_grad=dxl)
+                    dattn_l = ops.gemm_bf16(ops.NN, dx1_l, Wo)
+                    ops.gemm_bf16(ops.TN, dx1_l, top["attn"], out=go, epilogue=ops.EPI_ACCUM)
+                    dattn[Mp:].zero_()
+                    dx1[Mp:].zero_()
+                    ops.scatter_rows_bf16_(dattn_l, top["idx"], dattn[Mp:])
+                    ops.scatter_rows_bf16_(dx1_l, top["idx"], dx1[Mp:])
+                elif R > lo:
                     ops.gemm_bf16(ops.NN, dx[lo:], Wd, out=dh[lo:])
                     ops.gemm_bf16(ops.TN, dx[lo:], E["h"][lo:R], out=gd, epilogue=ops.EPI_ACCUM)
                     ops.swiglu_bwd(E["gu"][lo:R], dh[lo:], out=dgu[lo:])
