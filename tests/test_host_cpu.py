@@ -647,3 +647,29 @@ def test_stub_tokeniser_prefix_cache_equals_full_encode():
             p = navigation_prompt(task, "{INSTR}", t, k, "<cls_1>")
             head = static_prefix(p)
             assert tok.encode(head, instr) + tok.encode(p[len(head):], instr)[1:] == tok.encode(p, instr), (task, t, k)
+
+
+def test_flat_adamw_zero_grad_after_a_fused_step_fills_only_the_gaps():
+    """round 4: FlatAdamW.step() zeroes the gradient segments its update kernel consumes (nv_adamw_zero_grad); the zero_grad() that
+    follows must fill exactly what lies BETWEEN those segments -- and be the plain full fill when no fused step preceded it.  Host
+    logic only (the segment bookkeeping), no kernel."""
+    from navillm_amd.optim import FlatAdamW
+    cfg = tiny_cfg("bf16")
+    m = _ParamModel(cfg)
+    opt = FlatAdamW(m, lr=1e-3)
+    st = m.store
+    for g in st.grad.values():
+        g.fill_(1.0)
+    n_lm = st.grad["lm"].numel()
+    segs = {"lm": [(128, 1024), (4096, n_lm - 64)], "f32": []}
+    opt._zeroed_segs = {k: list(v) for k, v in segs.items()}       # "step() already zeroed these"
+    opt.zero_grad()
+    g = st.grad["lm"].float()
+    assert float(g[:128].abs().max()) == 0 and float(g[1024:4096].abs().max()) == 0 and float(g[n_lm - 64:].abs().max()) == 0
+    assert float(g[128:1024].min()) == 1.0 and float(g[4096:n_lm - 64].min()) == 1.0      # left alone: the kernel's job
+    assert float(st.grad["f32"].abs().max()) == 0                                          # no segment there: whole buffer filled
+    assert opt._zeroed_segs is None
+    for g in st.grad.values():
+        g.fill_(1.0)
+    opt.zero_grad()                                                                        # no fused step before: the full fill
+    assert all(float(g.abs().max()) == 0 for g in st.grad.values())
