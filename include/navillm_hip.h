@@ -75,9 +75,9 @@ int nv_gemv_fp8w(const void* A, const void* Wq, const float* scales, void* C, co
  *   weight tile DMA'd as e4m3fn bytes (half the fabric / LDS bytes of the bf16 operand) and converted on the MFMA fragment path.
  *   Serves the few-hundred-row GEMMs of K/V-reuse steps -- the shapes whose launch plan is a 128 / 160-row cut-off tile; every
  *   other shape returns NV_ERR_SHAPE (-2) and the caller runs nv_fp8_dequant_rows + nv_gemm_bf16.  mode: 0 = default, 7 = operand
- *   bf16(s*q) bit for bit as nv_fp8_dequant_rows writes it, 8 = v_cvt_scalef32_pk_bf16_fp8 with s as its scale operand, 9 = the same
- *   unscaled + s[n] on the fp32 accumulator (one bf16 rounding per weight less than the reference-on-de-quantised-weights
- *   semantics).  tile_cfg 0 | 84 | 85; epilogue 0 (store) | 2 (residual); K % 64 == 0, ldq % 16 == 0; workspace as nv_gemm_bf16_ws */
+ *   bf16(s*q) bit for bit as nv_fp8_dequant_rows writes it, 9 = v_cvt_scalef32_pk_bf16_fp8 unscaled + s[n] on the fp32 accumulator
+ *   (one bf16 rounding per weight less than the reference-on-de-quantised-weights semantics); 8 = the same instruction with s as its
+ *   scale operand: a measurement only -- the hardware uses the operand's exponent alone, the results are WRONG by up to 2x.  tile_cfg 0 | 84 | 85; epilogue 0 (store) | 2 (residual); K % 64 == 0, ldq % 16 == 0; workspace as nv_gemm_bf16_ws */
 int nv_gemm_fp8w(const void* A, const void* codes, const float* scales, void* C, const void* R, int M, int N, int K, int lda, int ldq,
                  int ldc, int ldr, int epilogue, int mode, int tile_cfg, void* workspace, void* stream);
 /*   process-wide default for mode = 0 (7 | 9; 0 = query only); returns the previous default */
