@@ -48,12 +48,58 @@ class DeferredLoss:
     def detach(self):
         return self
 
+    # `cnt_loss = 0.; cnt_loss += criterion(...) * w` and `ml_loss += cnt_loss.detach()` (mp3d_agent.py:750-752) keep working
+    def __add__(self, other):
+        return DeferredSum([self]) + other
+
+    __radd__ = __add__
+
     @property
     def value(self):
         v = self._logits._rec.get("loss_sum")
         if v is None:
             raise RuntimeError("the value of a deferred (teacher-forced) step loss exists after model.finish_episode()")
         return v * self._scale
+
+    def item(self):
+        return float(self.value)
+
+    __float__ = item
+
+
+class DeferredSum:
+    """a sum of deferred step losses (+ plain numbers): the running totals a rollout keeps (`ml_loss += cnt_loss.detach()`)"""
+
+    def __init__(self, terms, const=0.0):
+        self._terms, self._const = list(terms), float(const)
+
+    def __add__(self, other):
+        if isinstance(other, DeferredLoss):
+            return DeferredSum(self._terms + [other], self._const)
+        if isinstance(other, DeferredSum):
+            return DeferredSum(self._terms + other._terms, self._const + other._const)
+        return DeferredSum(self._terms, self._const + float(other))
+
+    __radd__ = __add__
+
+    def __mul__(self, f):
+        return DeferredSum([t * f for t in self._terms], self._const * float(f))
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, f):
+        return self * (1.0 / float(f))
+
+    def backward(self):
+        for t in self._terms:
+            t.backward()
+
+    def detach(self):
+        return self
+
+    @property
+    def value(self):
+        return self._const + sum(float(t.value) for t in self._terms)
 
     def item(self):
         return float(self.value)

@@ -630,6 +630,22 @@ def test_deferred_loss_handles_of_a_teacher_forced_episode():
         lg.argmax(1)
     rec["logits"], rec["loss_sum"] = torch.zeros(3, 4), torch.tensor(6.0)       # what finish_episode() leaves behind
     assert lg.value.shape == (3, 4) and abs(float(loss) - 6.0 * 0.4 / 3 / 2) < 1e-6 and abs(loss.item() - 0.4) < 1e-6
+    # the reference's running totals (mp3d_agent.py:750-752): cnt_loss = 0.; cnt_loss += criterion(...) * w; ml_loss += cnt_loss.detach()
+    ep2, rec2, rec3 = FakeEpisode(), {}, {}
+    cnt = 0.
+    cnt += crit(DeferredLogits(ep2, rec2), tg) * 0.5 / 3
+    ml = 0.
+    ml += cnt.detach()
+    cnt.backward()
+    cnt = 0.
+    cnt += crit(DeferredLogits(ep2, rec3), tg) * 0.5 / 3
+    ml += cnt.detach()
+    cnt.backward()
+    assert [c[0] for c in ep2.calls] == [rec2, rec3] and all(abs(c[2] - 0.5 / 3) < 1e-12 for c in ep2.calls)
+    with pytest.raises(RuntimeError, match="finish_episode"):
+        float(ml)
+    rec2["loss_sum"], rec3["loss_sum"] = torch.tensor(3.0), torch.tensor(9.0)
+    assert abs(float(ml) - 12.0 * 0.5 / 3) < 1e-6 and abs(float(ml * 2) - 24.0 * 0.5 / 3) < 1e-6
     # real tensors still take the kernel path (no GPU here: the autograd function is reached and asks for the library / a device)
     with pytest.raises(NotImplementedError):
         CrossEntropyLoss(reduction="mean")
