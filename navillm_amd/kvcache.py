@@ -113,11 +113,11 @@ class KVCacheLM:
 
     def _key_codes(self, vis_idx, vis_keys):
         """per-token reuse code: 0 = plain token, -1 = visual row that must be recomputed, > 0 = interned key of a constant row"""
-        codes = np.zeros(len(vis_idx), dtype=np.int64)
-        for j, r in enumerate(vis_idx):
-            if r >= 0:
-                k = False if vis_keys is None else vis_keys[r]
-                codes[j] = -1 if k is False else self._key_ids.setdefault(k, len(self._key_ids) + 1)
+        vi = np.asarray(vis_idx, dtype=np.int64)
+        codes = np.zeros(vi.size, dtype=np.int64)
+        for j in np.flatnonzero(vi >= 0):                  # the few visual tokens only (a Python loop over all ~650 tokens of all
+            k = False if vis_keys is None else vis_keys[int(vi[j])]     # 8 prompts was 1 ms of host time per step)
+            codes[j] = -1 if k is False else self._key_ids.setdefault(k, len(self._key_ids) + 1)
         return codes
 
     @torch.no_grad()

@@ -689,3 +689,27 @@ def test_flat_adamw_zero_grad_after_a_fused_step_fills_only_the_gaps():
         g.fill_(1.0)
     opt.zero_grad()                                                                        # no fused step before: the full fill
     assert all(float(g.abs().max()) == 0 for g in st.grad.values())
+
+
+def test_kvcache_key_codes_vectorised_equals_the_token_loop():
+    """KVCacheLM._key_codes (host side of the K/V-reuse step): per-token reuse codes -- 0 plain token, -1 recompute, > 0 interned key of a
+    constant visual row -- with only the visual tokens visited; against the literal per-token loop, same interning order."""
+    from navillm_amd.kvcache import KVCacheLM
+    rng = np.random.RandomState(3)
+    kv = object.__new__(KVCacheLM)
+    kv._key_ids = {}
+    ref_ids = {}
+    for trial in range(20):
+        n, R = int(rng.randint(1, 400)), int(rng.randint(1, 30))
+        vis_idx = np.full(n, -1, np.int64)
+        pos = rng.choice(n, size=min(n, R), replace=False)
+        vis_idx[pos] = rng.permutation(R)[:pos.size]
+        keys = [False if rng.rand() < 0.4 else ("hist", int(rng.randint(3)), int(rng.randint(5)), int(rng.randint(50))) for _ in range(R)]
+        want = np.zeros(n, np.int64)
+        for j, r in enumerate(vis_idx.tolist()):
+            if r >= 0:
+                k = keys[r]
+                want[j] = -1 if k is False else ref_ids.setdefault(k, len(ref_ids) + 1)
+        got = kv._key_codes(vis_idx.tolist(), keys)
+        assert np.array_equal(got, want) and kv._key_ids == ref_ids
+    assert np.array_equal(kv._key_codes([-1, 0, -1], None), np.array([0, -1, 0]))
