@@ -239,6 +239,14 @@ int nv_colsum_f32(const float* x, float* out, int M, int d, int ld, int accumula
 int nv_mha_fwd_f32(const float* qkv, const int* lens, float* out, float* P, int B, int N, int heads, int hd, void* stream);
 int nv_mha_bwd_f32(const float* qkv, const float* P, const float* dout, float* dqkv, int B, int N, int heads, int hd,
                    void* stream);
+/*   the same with nn.MultiheadAttention(dropout=p)'s attention-probability dropout (detr_transformer.py:138; torch drops the
+ *   softmax output before P.V and rescales by 1/(1-p)).  keep (optional): [B,heads,N,N] 0/1 flags injected by parity tests;
+ *   otherwise element e of P keeps iff Philox4x32-10(counter = offset + e, key = seed) word 0 >= p.  P receives the
+ *   probabilities BEFORE dropout; the backward regenerates the mask from the same (keep, p, seed, offset). */
+int nv_mha_fwd_drop_f32(const float* qkv, const int* lens, float* out, float* P, const float* keep, float p,
+                        unsigned long long seed, unsigned long long offset, int B, int N, int heads, int hd, void* stream);
+int nv_mha_bwd_drop_f32(const float* qkv, const float* P, const float* dout, float* dqkv, const float* keep, float p,
+                        unsigned long long seed, unsigned long long offset, int B, int N, int heads, int hd, void* stream);
 int nv_gelu_fwd_f32(const float* x, float* y, long n, void* stream);
 int nv_gelu_bwd_f32(const float* x, const float* dy, float* dx, long n, void* stream);
 int nv_add_f32(const float* a, const float* b, float* out, long n, int d, int b_bcast, void* stream);

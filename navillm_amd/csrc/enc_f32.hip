@@ -301,10 +301,38 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------- multi-head self-attention core
+// Philox4x32-10 (counter-based RNG of the dropout kernels below and of the attention-probability dropout)
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// Attention-probability dropout (nn.MultiheadAttention(dropout=p), detr_transformer.py:138: torch drops the softmax output
+// before P.V and rescales by 1/(1-p)).  Keep factor of probability element e = ((b*heads+hh)*N + a)*N + c: either read from an
+// injected 0/1 mask [B,heads,N,N] (parity tests) or drawn from Philox counter (offset + e), word 0 -- the backward regenerates it.
+struct MhaDrop {
+    const float* keep;      // optional injected keep flags
+    float p, inv_keep;      // p == 0: no dropout
+    uint64_t seed, offset;
+};
+__device__ __forceinline__ float mha_keep_factor(const MhaDrop& d, long e) {
+    if (d.p <= 0.f) return 1.f;
+    if (d.keep) return d.keep[e] != 0.f ? d.inv_keep : 0.f;
+    const uint64_t ctr = d.offset + (uint64_t)e;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)d.seed, (uint32_t)(d.seed >> 32), r);
+    return ((float)(r[0] >> 8) * (1.0f / 16777216.0f)) >= d.p ? d.inv_keep : 0.f;
+}
 // qkv [B*N, 3h] (q|k|v, each h = heads*hd) -> out [B*N, h]; keys >= lens[b] are padding.
-// One block per (b, head); P [B,heads,N,N] is kept for the backward.
+// One block per (b, head); P [B,heads,N,N] (the softmax output BEFORE dropout) is kept for the backward.
 __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
-                                                      float* __restrict__ out, float* __restrict__ P, int N, int heads, int hd) {
+                                                      float* __restrict__ out, float* __restrict__ P, int N, int heads, int hd,
+                                                      MhaDrop drop) {
     extern __shared__ float sm[];
     float* q = sm;                 // [N][hd+1]
     float* k = q + N * (hd + 1);
@@ -341,8 +369,9 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ 
         const float inv = 1.f / sum;
         for (int c = lane; c < N; c += 64) {
             const float pv = s[a * N + c] * inv;
-            s[a * N + c] = pv;
-            P[(((long)b * heads + hh) * N + a) * N + c] = pv;
+            const long e = (((long)b * heads + hh) * N + a) * N + c;
+            P[e] = pv;
+            s[a * N + c] = pv * mha_keep_factor(drop, e);
         }
     }
     __syncthreads();
@@ -356,7 +385,7 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ P,
                                                       const float* __restrict__ dout, float* __restrict__ dqkv, int N, int heads,
-                                                      int hd) {
+                                                      int hd, MhaDrop drop) {
     extern __shared__ float sm[];
     float* q = sm;
     float* k = q + N * (hd + 1);
@@ -386,11 +415,22 @@ __global__ __launch_bounds__(256) void mha_bwd_kernel(const float* __restrict__ 
     }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // with dropout: out = (P*m) V, m = keep/(1-p)  ->  dP = m * (dO V^T), dS = P * (dP - sum_c dP*P), dV = (P*m)^T dO.
+    // ds holds dP, then dS; pp holds P, then P*m (P itself is not needed once dS is formed).
     for (int a = wave; a < N; a += 4) {
         float dot = 0.f;
-        for (int c = lane; c < N; c += 64) dot += ds[a * N + c] * pp[a * N + c];
+        for (int c = lane; c < N; c += 64) {
+            const float m = mha_keep_factor(drop, (((long)b * heads + hh) * N + a) * N + c);
+            const float dp = ds[a * N + c] * m;
+            ds[a * N + c] = dp;
+            dot += dp * pp[a * N + c];
+        }
         dot = wave_sum(dot);
-        for (int c = lane; c < N; c += 64) ds[a * N + c] = pp[a * N + c] * (ds[a * N + c] - dot);
+        for (int c = lane; c < N; c += 64) {
+            const float pv = pp[a * N + c];
+            ds[a * N + c] = pv * (ds[a * N + c] - dot);
+            if (drop.p > 0.f) pp[a * N + c] = pv * mha_keep_factor(drop, (((long)b * heads + hh) * N + a) * N + c);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < N * hd; i += 256) {
@@ -440,16 +480,6 @@ __global__ __launch_bounds__(256) void mul_f32_kernel(const float* __restrict__ 
 // (seed, offset) on the incoming gradient and regenerates the identical mask.  (nav_model.py:91,99-102 drop_env p=0.4;
 // image_embedding.py:73-74 and detr_transformer.py:170-182 p=0.1.)  The reference's mask stream is torch's CUDA Philox
 // generator: a different, equally valid stream (dropout cannot be bit-matched across devices anyway).
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
 __global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ x, float* __restrict__ out, long n, float p,
                                                           float scale, uint64_t seed, uint64_t offset) {
     const long groups = (n + 3) / 4;
@@ -619,27 +649,47 @@ static size_t mha_lds(int N, int hd, int bwd) {
     return (size_t)((bwd ? 4 : 3) * N * (hd + 1) + (bwd ? 2 : 1) * N * N) * sizeof(float);
 }
 
-int nv_mha_fwd_f32(const float* qkv, const int* lens, float* out, float* P, int B, int N, int heads, int hd, void* stream) {
+static bool mha_drop_args(MhaDrop& d, const float* keep, float p, unsigned long long seed, unsigned long long offset) {
+    if (!(p >= 0.f) || !(p < 1.f)) return false;
+    d.keep = keep; d.p = p; d.inv_keep = 1.f / (1.f - p); d.seed = (uint64_t)seed; d.offset = (uint64_t)offset;
+    return true;
+}
+
+// `keep` (optional, [B,heads,N,N] 0/1 flags) overrides the Philox draw; p == 0 is nv_mha_fwd_f32.  P receives the
+// probabilities BEFORE dropout; nv_mha_bwd_drop_f32 must be given the same (keep, p, seed, offset).
+int nv_mha_fwd_drop_f32(const float* qkv, const int* lens, float* out, float* P, const float* keep, float p,
+                        unsigned long long seed, unsigned long long offset, int B, int N, int heads, int hd, void* stream) {
     if (!qkv || !lens || !out || !P) return NV_ERR_ARG;
+    MhaDrop drop;
+    if (!mha_drop_args(drop, keep, p, seed, offset)) return NV_ERR_ARG;
     if (B == 0 || N == 0) return NV_OK;
     const size_t lds = mha_lds(N, hd, 0);
     if (lds > 160 * 1024) return NV_ERR_SHAPE;
     if (hipFuncSetAttribute((const void*)mha_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return NV_ERR_LAUNCH;
-    NV_LAUNCH(mha_fwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, lens, out, P, N, heads, hd);
+    NV_LAUNCH(mha_fwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, lens, out, P, N, heads, hd, drop);
     return nv_check_launch();
 }
+int nv_mha_fwd_f32(const float* qkv, const int* lens, float* out, float* P, int B, int N, int heads, int hd, void* stream) {
+    return nv_mha_fwd_drop_f32(qkv, lens, out, P, nullptr, 0.f, 0ull, 0ull, B, N, heads, hd, stream);
+}
 
-int nv_mha_bwd_f32(const float* qkv, const float* P, const float* dout, float* dqkv, int B, int N, int heads, int hd,
-                   void* stream) {
+int nv_mha_bwd_drop_f32(const float* qkv, const float* P, const float* dout, float* dqkv, const float* keep, float p,
+                        unsigned long long seed, unsigned long long offset, int B, int N, int heads, int hd, void* stream) {
     if (!qkv || !P || !dout || !dqkv) return NV_ERR_ARG;
+    MhaDrop drop;
+    if (!mha_drop_args(drop, keep, p, seed, offset)) return NV_ERR_ARG;
     if (B == 0 || N == 0) return NV_OK;
     const size_t lds = mha_lds(N, hd, 1);
     if (lds > 160 * 1024) return NV_ERR_SHAPE;
     if (hipFuncSetAttribute((const void*)mha_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return NV_ERR_LAUNCH;
-    NV_LAUNCH(mha_bwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, P, dout, dqkv, N, heads, hd);
+    NV_LAUNCH(mha_bwd_kernel, dim3(B * heads), dim3(256), lds, (hipStream_t)stream, qkv, P, dout, dqkv, N, heads, hd, drop);
     return nv_check_launch();
+}
+int nv_mha_bwd_f32(const float* qkv, const float* P, const float* dout, float* dqkv, int B, int N, int heads, int hd,
+                   void* stream) {
+    return nv_mha_bwd_drop_f32(qkv, P, dout, dqkv, nullptr, 0.f, 0ull, 0ull, B, N, heads, hd, stream);
 }
 
 int nv_gelu_fwd_f32(const float* x, float* y, long n, void* stream) {

@@ -231,20 +231,36 @@ class GatherRowsF32(torch.autograd.Function):
 
 
 class MHAF32(torch.autograd.Function):
-    """softmax(q k^T / sqrt(hd) + key_padding) v per head on packed qkv (nn.MultiheadAttention core)."""
+    """dropout_p(softmax(q k^T / sqrt(hd) + key_padding)) v per head on packed qkv (nn.MultiheadAttention core incl. its
+    attention-probability dropout, detr_transformer.py:138).  `drop` = None (eval / p = 0) or (p, seed, offset, keep): keep is an
+    injected [B,heads,N,N] 0/1 mask (parity tests) or None = drawn in the kernel from Philox(seed, offset + element) and
+    regenerated by the backward."""
 
     @staticmethod
-    def forward(ctx, qkv, lens_i32, B, N, heads, hd):
+    def forward(ctx, qkv, lens_i32, B, N, heads, hd, drop=None):
         qkv = _c(qkv)
-        out, P = ops.mha_fwd(qkv, lens_i32, B, N, heads, hd)
+        p, seed, off, keep = drop if drop is not None else (0.0, 0, 0, None)
+        out, P = ops.mha_fwd(qkv, lens_i32, B, N, heads, hd, p, seed, off, keep)
         ctx.save_for_backward(qkv, P)
         ctx.dims = (B, N, heads, hd)
+        ctx.drop = (p, seed, off, keep)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, P = ctx.saved_tensors
-        return ops.mha_bwd(qkv, P, _c(dout), *ctx.dims), None, None, None, None, None
+        return ops.mha_bwd(qkv, P, _c(dout), *ctx.dims, *ctx.drop), None, None, None, None, None, None
+
+
+def mha(qkv, lens_i32, B, N, heads, hd, p, training, mask=None):
+    """nn.MultiheadAttention's core with its dropout on the attention probabilities (training only)."""
+    if not training or p == 0.0:
+        return MHAF32.apply(qkv, lens_i32, B, N, heads, hd, None)
+    if mask is not None:
+        return MHAF32.apply(qkv, lens_i32, B, N, heads, hd, (p, 0, 0, mask.to(torch.float32).contiguous()))
+    n = B * heads * N * N
+    seed, off = _philox_take(qkv.device, 4 * n)        # one Philox counter per probability element
+    return MHAF32.apply(qkv, lens_i32, B, N, heads, hd, (p, seed, off, None))
 
 
 def linear(x, W, b):

@@ -76,6 +76,8 @@ SIGNATURES = {
     "nv_colsum_f32": (i, [fp, fp, i, i, i, i, vp]),
     "nv_mha_fwd_f32": (i, [fp, ip, fp, fp, i, i, i, i, vp]),
     "nv_mha_bwd_f32": (i, [fp, fp, fp, fp, i, i, i, i, vp]),
+    "nv_mha_fwd_drop_f32": (i, [fp, ip, fp, fp, fp, f, C.c_ulonglong, C.c_ulonglong, i, i, i, i, vp]),
+    "nv_mha_bwd_drop_f32": (i, [fp, fp, fp, fp, fp, f, C.c_ulonglong, C.c_ulonglong, i, i, i, i, vp]),
     "nv_gelu_fwd_f32": (i, [fp, fp, l, vp]),
     "nv_gelu_bwd_f32": (i, [fp, fp, fp, l, vp]),
     "nv_add_f32": (i, [fp, fp, fp, l, i, i, vp]),

@@ -485,7 +485,8 @@ class NavModel(nn.Module):
             p = f"{e}.pano_encoder.layers.{i}"
             y = self._ln(x, p + ".norm1", 1e-5)
             qkv = Fn.linear(y, self.P(p + ".self_attn.in_proj_weight"), self.P(p + ".self_attn.in_proj_bias"))
-            a = Fn.MHAF32.apply(qkv.view(B * N, 3 * h), lens_i32, B, N, heads, hd).view(B, N, h)
+            am = None if self.injected_dropout is None else self.injected_dropout.get(f"l{i}.attn")
+            a = Fn.mha(qkv.view(B * N, 3 * h), lens_i32, B, N, heads, hd, cfg.enc_dropout, self.training, am).view(B, N, h)
             a = self._lin(a, p + ".self_attn.out_proj")
             x = Fn.add(x, self._drop(a, cfg.enc_dropout, f"l{i}.drop1"))
             y = self._ln(x, p + ".norm2", 1e-5)

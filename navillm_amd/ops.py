@@ -470,19 +470,28 @@ def colsum_f32(x, out=None, accumulate=False):
     return out
 
 
-def mha_fwd(qkv, lens_i32, B, N, heads, hd):
+def _keep_ptr(keep, B, N, heads):
+    if keep is None:
+        return None
+    assert keep.dtype == F32 and keep.is_contiguous() and tuple(keep.shape) == (B, heads, N, N), (keep.shape, keep.dtype)
+    return keep.data_ptr()
+
+
+def mha_fwd(qkv, lens_i32, B, N, heads, hd, p=0.0, seed=0, offset=0, keep=None):
+    """-> (out [B*N, h], P [B,heads,N,N] = the probabilities before dropout).  p > 0: attention-probability dropout, mask from
+    `keep` (0/1 flags) or from Philox(seed, offset + element)."""
     h = heads * hd
     out = torch.empty((B * N, h), dtype=F32, device=qkv.device)
     P = torch.empty((B, heads, N, N), dtype=F32, device=qkv.device)
-    _lib.check(_L().nv_mha_fwd_f32(qkv.data_ptr(), lens_i32.data_ptr(), out.data_ptr(), P.data_ptr(), B, N, heads, hd, _st()),
-               "nv_mha_fwd_f32")
+    _lib.check(_L().nv_mha_fwd_drop_f32(qkv.data_ptr(), lens_i32.data_ptr(), out.data_ptr(), P.data_ptr(), _keep_ptr(keep, B, N, heads),
+                                        float(p), int(seed) & (2 ** 64 - 1), int(offset), B, N, heads, hd, _st()), "nv_mha_fwd_drop_f32")
     return out, P
 
 
-def mha_bwd(qkv, P, dout, B, N, heads, hd):
+def mha_bwd(qkv, P, dout, B, N, heads, hd, p=0.0, seed=0, offset=0, keep=None):
     dqkv = torch.empty_like(qkv)
-    _lib.check(_L().nv_mha_bwd_f32(qkv.data_ptr(), P.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, N, heads, hd, _st()),
-               "nv_mha_bwd_f32")
+    _lib.check(_L().nv_mha_bwd_drop_f32(qkv.data_ptr(), P.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), _keep_ptr(keep, B, N, heads),
+                                        float(p), int(seed) & (2 ** 64 - 1), int(offset), B, N, heads, hd, _st()), "nv_mha_bwd_drop_f32")
     return dqkv
 
 

@@ -66,14 +66,15 @@ def _dropout(x, p, training, masks, key):
     if not training or p == 0.0:
         return x
     if masks is not None and key in masks:
-        return x * masks[key].to(x.dtype) / (1.0 - p)
+        return x * (masks[key].to(x.dtype) / (1.0 - p))      # torch: noise = bernoulli(1-p) / (1-p); x * noise
     return F.dropout(x, p, True)
 
 
 # --------------------------------------------------------------------------- scene encoder
-def mha_self(x, key_pad, P, prefix, num_heads):
-    """nn.MultiheadAttention (packed in_proj, key_padding_mask) on batch-first x [B,N,h].
-    detr_transformer.py:173-175"""
+def mha_self(x, key_pad, P, prefix, num_heads, drop_p=0.0, training=False, dmasks=None, key=None):
+    """nn.MultiheadAttention (packed in_proj, key_padding_mask, dropout=drop_p ON THE ATTENTION PROBABILITIES --
+    detr_transformer.py:138 constructs it with dropout=0.1, torch applies it to the softmax output before P.V) on batch-first
+    x [B,N,h].  detr_transformer.py:173-175.  dmasks[key]: injected keep flags [B,heads,N,N]."""
     B, N, h = x.shape
     hd = h // num_heads
     qkv = F.linear(x, P[prefix + ".in_proj_weight"], P[prefix + ".in_proj_bias"])
@@ -84,6 +85,7 @@ def mha_self(x, key_pad, P, prefix, num_heads):
     s = (q * (1.0 / math.sqrt(hd))) @ k.transpose(-1, -2)
     s = s.masked_fill(key_pad[:, None, None, :], float("-inf"))
     p = torch.softmax(s, dim=-1)
+    p = _dropout(p, drop_p, training, dmasks, key)
     o = (p @ v).transpose(1, 2).reshape(B, N, h)
     return F.linear(o, P[prefix + ".out_proj.weight"], P[prefix + ".out_proj.bias"])
 
@@ -95,7 +97,8 @@ def pano_encoder(x, masks, P, cfg, prefix="img_embeddings.pano_encoder", trainin
     for i in range(cfg.num_pano_layers):
         p = f"{prefix}.layers.{i}"
         y = _ln(x, P, p + ".norm1", 1e-5)
-        x = x + _dropout(mha_self(y, key_pad, P, p + ".self_attn", cfg.enc_num_heads),
+        x = x + _dropout(mha_self(y, key_pad, P, p + ".self_attn", cfg.enc_num_heads, cfg.enc_dropout, training, dmasks,
+                                  f"l{i}.attn"),
                          cfg.enc_dropout, training, dmasks, f"l{i}.drop1")
         y = _ln(x, P, p + ".norm2", 1e-5)
         y = F.gelu(_lin(y, P, p + ".linear1"))
@@ -139,6 +142,19 @@ def scene_encoder(P, cfg, view_img_fts, view_lens, loc_fts=None, nav_types=None,
         assert oe.shape[:2] == obj_loc_fts.shape[:2]
         ret.update(obj_embeds=oe, obj_loc_fts=obj_loc_fts, obj_masks=gen_seq_masks(obj_lens))
     return ret
+
+
+def panorama(P, cfg, batch, training=False, dmasks=None):
+    """NavModel.forward(mode='panorama'), nav_model.py:96-111: `drop_env` (nn.Dropout(feat_dropout), :91) on the raw view
+    features, and on the object features when the batch carries them (:99-102), then the scene encoder.  Dropout keys (the
+    order the reference calls them in one training panorama): drop_env.view, drop_env.obj, emb.drop, then per encoder layer
+    l{i}.attn (attention probabilities), l{i}.drop1, l{i}.drop (FFN), l{i}.drop2."""
+    v = _dropout(batch["view_img_fts"], cfg.feat_dropout, training, dmasks, "drop_env.view")
+    o = batch.get("obj_img_fts")
+    if o is not None:
+        o = _dropout(o, cfg.feat_dropout, training, dmasks, "drop_env.obj")
+    return scene_encoder(P, cfg, v, batch["view_lens"], batch.get("loc_fts"), batch.get("nav_types"), o,
+                         batch.get("obj_lens"), batch.get("obj_loc_fts"), training=training, dmasks=dmasks)
 
 
 # --------------------------------------------------------------------------- Llama

@@ -26,6 +26,12 @@ Outputs (all small, committed):
                        step, the chosen slot's fuse_embeds appended to the history (mp3d_agent.py:683-778), gradients
                        ACCUMULATED over the steps (train.py:86-89 steps the optimizer only afterwards): per-step logits,
                        losses, history rows and the accumulated parameter gradients
+    g14_train_*.npz    (round 5) the TRAINING-MODE path: the reference model in .train(), torch.nn.functional.dropout replaced
+                       (from outside the reference tree) by a recorder that draws every keep mask from a seeded CPU generator and
+                       stores it -- all dropout sites of a training step: drop_env on view / object features (nav_model.py:91,
+                       99-102), the embedding dropout (image_embedding.py:73-74), and per encoder layer the ATTENTION-PROBABILITY
+                       dropout of nn.MultiheadAttention (detr_transformer.py:138) + dropout1 / dropout / dropout2 (:141,146-147,
+                       170-182): panorama (with objects) -> navigation -> CE -> backward, then object_grounding -> CE -> backward
     g13_optimizer_bf16.npz  (round 3) the `optimizer` entry of a reference checkpoint (torch.optim.AdamW.state_dict(), tools/optims.py:73)
                        after two optimizer steps (navigation, then object grounding) + the named_parameters() order its keys index
 
@@ -671,6 +677,125 @@ def gen_episode(prec, seed=11, T_steps=3):
     save(f"g12_episode_{tag}.npz", **arrs, meta=np.array(json.dumps(meta)))
 
 
+class DropoutRecorder:
+    """stand-in for torch.nn.functional.dropout while the reference runs in .train(): same arithmetic as torch's
+    (input * (keep / (1 - p))), the keep flags drawn from a seeded CPU generator and recorded in call order."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.rec = []
+
+    def __call__(self, input, p=0.5, training=True, inplace=False):
+        if not training or p == 0.0:
+            return input
+        keep = torch.rand(input.shape, generator=self.g) >= p
+        self.rec.append((float(p), keep))
+        return input * (keep.to(input.dtype) / (1.0 - p))
+
+
+def gen_train_mode(prec, seed=11):
+    """G14 (round 5): one TRAINING-mode step of the rollout's calls (mp3d_agent.py:683,726,750-757,791-824): `model.train()`,
+    panorama with objects -> navigation -> CE * w / B -> backward(), then object_grounding on the same panorama's objects ->
+    CE * w / B -> backward() (gradients accumulate).  Every dropout mask the reference consumed is stored batch-first under the
+    key names navillm_amd.NavModel.injected_dropout / the oracle's `dmasks` use."""
+    import torch.nn.functional as F_
+    from tasks.agents.r2r import R2RAgent
+    from tasks.agents.reverie import REVERIEAgent
+    cfg = nvcfg.tiny(precision=prec)
+    tag = "bf16" if cfg.lm_is_bf16 else "fp32"
+    print(f"[{tag}] G14 training-mode step")
+    model = build_reference(cfg, seed)
+    model.train()
+    lm = model.lang_model
+    g = torch.Generator().manual_seed(1414)
+    B, N = 3, 8
+    heads, h, ff = cfg.enc_num_heads, cfg.enc_hidden_size, cfg.enc_intermediate_size
+    crit = torch.nn.CrossEntropyLoss(ignore_index=-100, reduction="sum")
+    pin, cand_k = pano_inputs(cfg, g, B, N, with_obj=True)
+    O = pin["obj_img_fts"].shape[1]
+    rec = DropoutRecorder(9090)
+    real_dropout = F_.dropout
+    F_.dropout = rec
+    try:
+        model.zero_grad()
+        pano = model("panorama", dict(pin))
+        n_pano_calls = len(rec.rec)
+        hist_t = [1, 0, 2]
+        nin = nav_inputs(cfg, g, pano["pano_embeds"], pano["pano_masks"], cand_k, hist_t)
+        cand_nums = (nin["gmap_masks"] & ~nin["gmap_visited_masks"]).sum(-1)
+        prompts = [R2RAgent.get_navigation_prompt(None, INSTR[b], hist_t[b], int(cand_nums[b]), lm.cls_token[0]) for b in range(B)]
+        nin["prompts"] = prompts
+        nin["instruction"] = INSTR
+        tok = lm.tokenize(prompts)
+        torch.manual_seed(1415)
+        perms = [torch.randperm(int(cand_nums[b]) - 1) for b in range(B)]
+        torch.manual_seed(1415)
+        nout = model("navigation", nin)
+        targets = torch.tensor([3, 0, -100])
+        loss = crit(nout["fuse_logits"], targets) * 0.7 / B / 1
+        loss.backward(retain_graph=True)
+        nav_grads = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in grad_fixture(model, G14_NAV).items()}   # .grad keeps accumulating below
+        # object grounding on the same panorama's object tokens (the rollout calls panorama again at :791; one panorama keeps
+        # the mask bookkeeping to ONE set of encoder masks and still sends a second gradient through drop_env.obj)
+        ocn = pano["obj_masks"].sum(1) + 1
+        oprompts = [REVERIEAgent.get_object_grounding_prompt(None, INSTR[b], hist_t[b], int(ocn[b]), lm.cls_token[0]) for b in range(B)]
+        ob = dict(obj_embeds=pano["obj_embeds"], obj_masks=pano["obj_masks"], obj_loc_fts=pano["obj_loc_fts"],
+                  hist_vis=nin["hist_vis"], history=nin["history"], instruction=INSTR, data_type=["reverie"] * B, prompts=oprompts)
+        oo = model("object_grounding", ob)
+        otok = lm.tokenize(oprompts)
+        og_targets = torch.tensor([1, 2, -100])
+        og_loss = crit(oo["obj_logits"], og_targets) * 0.5 / B / 1
+        og_loss.backward()
+        acc_grads = grad_fixture(model, G14_NAV + G10_OG)
+    finally:
+        F_.dropout = real_dropout
+    # ---- the masks, in the order the reference drew them, renamed and laid out batch-first
+    assert len(rec.rec) == n_pano_calls, "a dropout fired outside the panorama call"
+    names = ["drop_env.view", "drop_env.obj", "emb.drop"]
+    for i in range(cfg.num_pano_layers):
+        names += [f"l{i}.attn", f"l{i}.drop1", f"l{i}.drop", f"l{i}.drop2"]
+    assert len(rec.rec) == len(names), (len(rec.rec), names)
+    masks = {}
+    for nm, (p_, keep) in zip(names, rec.rec):
+        if nm.startswith("drop_env"):
+            assert abs(p_ - cfg.feat_dropout) < 1e-9
+        else:
+            assert abs(p_ - cfg.enc_dropout) < 1e-9
+        if nm.endswith(".attn"):
+            assert tuple(keep.shape) == (B * heads, N, N), keep.shape      # torch: index = b * heads + head
+            keep = keep.view(B, heads, N, N)
+        elif nm.startswith("l"):
+            assert tuple(keep.shape) in ((N, B, h), (N, B, ff)), keep.shape  # the encoder runs sequence-first (detr_transformer.py:76-77)
+            keep = keep.transpose(0, 1).contiguous()
+        masks["mask/" + nm] = keep.to(torch.uint8)
+    flat = {k: v for k, v in pin.items()}
+    for k in ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_visited_masks", "gmap_masks", "vp_pos_fts"):
+        flat[k] = nin[k]
+    flat["nav_pano_masks"] = nin["pano_masks"]
+    flat["hist_vis_flat"] = torch.stack([v for vis in nin["hist_vis"] for v in vis], 0)
+    meta = dict(gmap_vpids=nin["gmap_vpids"], vp_cand_vpids=nin["vp_cand_vpids"], hist_t=hist_t, prompts=prompts, og_prompts=oprompts,
+                targets=targets.tolist(), og_targets=og_targets.tolist(), perms=[p_.tolist() for p_ in perms], seed_before_nav=1415,
+                nav_coef=0.7, og_coef=0.5, mask_order=names)
+    save(f"g14_train_{tag}.npz", **flat, **masks, input_ids=tok["input_ids"], attention_mask=tok["attention_mask"],
+         og_input_ids=otok["input_ids"], og_attention_mask=otok["attention_mask"],
+         pano_embeds=pano["pano_embeds"], obj_embeds=pano["obj_embeds"], fuse_logits=nout["fuse_logits"],
+         fuse_embeds=nout["fuse_embeds"], loss=loss, obj_logits=oo["obj_logits"], og_loss=og_loss,
+         **{"nav/" + k: v for k, v in nav_grads.items()}, **{"acc/" + k: v for k, v in acc_grads.items()},
+         meta=np.array(json.dumps(meta)))
+
+
+G14_NAV = ["out_head.0.weight", "out_head.0.bias", "img_embeddings.img_linear.weight", "img_embeddings.img_linear.bias",
+           "img_embeddings.mapper.weight", "vp_pos_embeddings.0.weight", "vp_pos_embeddings.1.weight",
+           "gmap_pos_embeddings.0.weight", "gmap_step_embeddings.weight", "token_type_embeddings.weight",
+           "lang_model.model.layers.0.self_attn.q_proj.weight", "lang_model.model.layers.1.mlp.down_proj.weight",
+           "lang_model.model.layers.0.input_layernorm.weight", "lang_model.model.norm.weight",
+           "img_embeddings.pano_encoder.layers.0.self_attn.in_proj_weight", "img_embeddings.pano_encoder.layers.0.self_attn.in_proj_bias",
+           "img_embeddings.pano_encoder.layers.0.self_attn.out_proj.weight", "img_embeddings.pano_encoder.layers.1.self_attn.in_proj_weight",
+           "img_embeddings.pano_encoder.layers.0.linear2.weight", "img_embeddings.pano_encoder.layers.1.linear1.weight",
+           "img_embeddings.pano_encoder.layers.1.norm1.weight", "img_embeddings.pano_encoder.norm.weight",
+           "img_embeddings.layer_norm.weight", "img_embeddings.loc_linear.weight", "img_embeddings.nav_type_embedding.weight"]
+
+
 def gen_optimizer_state(seed=11):
     """G13: the `optimizer` entry of a reference checkpoint (tools/optims.py:65-78) after two optimizer steps of the training loop
     (train.py:86-89: clip_grad_norm_(40) + AdamW.step + zero_grad) on the tiny amp_bf16 model: step 1 after a navigation
@@ -868,6 +993,10 @@ def main():
         for prec in ("fp32", "amp_bf16"):
             gen_episode(prec)
         return
+    if "--only-train-mode" in sys.argv:          # add G14 without touching the other fixtures
+        for prec in ("fp32", "amp_bf16"):
+            gen_train_mode(prec)
+        return
     if "--only-optimizer" in sys.argv:           # add G13 without touching the other fixtures
         gen_optimizer_state()
         return
@@ -890,6 +1019,8 @@ def main():
     for prec in ("fp32", "amp_bf16"):
         gen_episode(prec)
     gen_optimizer_state()
+    for prec in ("fp32", "amp_bf16"):
+        gen_train_mode(prec)
 
 
 if __name__ == "__main__":

@@ -139,3 +139,14 @@ def bf16_ulps_at_scale(a, ref):
     scale = ref[fin].abs().max().item()
     ulp = 2.0 ** (int(np.floor(np.log2(max(scale, 1e-30)))) - 7)
     return (a[fin] - ref[fin]).abs().max().item() / ulp
+
+
+def dropout_masks_from_gold(z, device=None):
+    """keep masks of fixture G14 (stored batch-first as uint8 under `mask/<site>`) -> {site: float tensor}; sites are the keys of
+    `NavModel.injected_dropout` and of the oracle's `dmasks` (drop_env.view, drop_env.obj, emb.drop, l{i}.attn / drop1 / drop / drop2)"""
+    out = {}
+    for k in z:
+        if k.startswith("mask/"):
+            t = torch.from_numpy(np.ascontiguousarray(z[k])).float()
+            out[k[5:]] = t.to(device) if device is not None else t
+    return out
