@@ -324,6 +324,7 @@ def mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed):
         pre = {"seconds": round(dt, 3), "ms_per_meta_step": per_task, "nav_steps_per_s_per_gpu": round(nav_steps / dt, 2),
                "episodes_per_s_per_gpu": round((4 * a.batch + a.batch) / dt, 2)}
     model.episode_abort()
+    model.zero_grad()
     for rep in range(2):
         model.flop_log = []
         nav_steps = 0
@@ -423,6 +424,63 @@ def long_horizon_extra(a, cfg, model, wrapped, crit, device, seed, T=64):
         model.episode_abort()
         model.zero_grad()
     model.episode_release()                      # the long episode's buffers (up to 30 % of the card): the next extra loads a 13B model
+    return out
+
+
+def reference_launch_extra(a, cfg, model, opt, crit, device, seed):
+    """The reference's own launch line (scripts/multi_wo_pretrain.sh:16: `--batch_size 1 --gradient_accumulation_step 8`, one rank of
+    its 8): B = 1 episode per meta-step, the loss scaled by 1 / B / 8, `clip + AdamW + zero_grad` every 8th episode (train.py:68,86-89).
+    Every GEMM of a step then has M ~ 650 (recompute) / ~100 (suffix steps) / ~1 150 (a teacher-forced episode's batched backward)
+    rows instead of 8 x that -- the regime the cut-off tiles exist for.  Measured for the three training forms, each over ONE whole
+    accumulation window (8 episodes x 6 steps = 48 nav steps + 1 optimizer step) after a warm window, with the GEMM roofline of the
+    window.  NOT `value`: BASELINE config 2 is B = 8.  The same 8 episodes as ONE batch (`--batch_size 8 --gradient_accumulation_step
+    1`: same loss scale 1/8, same gradient -- tests/test_parity_r5_gpu.py) is the headline line above."""
+    from navillm_amd import ops
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step
+    ACC = 8
+    ep1 = SyntheticEpisodes(cfg, 1, seed=seed, instr_len=a.instr_len, device=device)
+    out = {"batch_per_gpu": 1, "gradient_accumulation_step": ACC, "steps_per_window": ACC * STEPS_PER_EPISODE,
+           "what": "scripts/multi_wo_pretrain.sh:16 on one rank: 8 episodes of B = 1, 6 nav steps each, loss / 1 / 8, one clip + AdamW per window"}
+
+    def window(form):
+        for e in range(ACC):
+            ep1.reset()
+            if form != "recompute":
+                model.begin_episode(ep1.prefix_ids(), teacher_forced=(form == "prefix_reuse_teacher_forced"))
+            for t in range(STEPS_PER_EPISODE):
+                nav_step(model, crit, ep1, train=True, last=(t == STEPS_PER_EPISODE - 1), accum=ACC)
+            if form != "recompute":
+                model.finish_episode()
+        opt.clip_grad_norm_(40.0)
+        opt.step()
+        opt.zero_grad()
+
+    for form in ("recompute", "prefix_reuse", "prefix_reuse_teacher_forced"):
+        try:
+            model.episode_abort()
+            model.zero_grad()
+            window(form)                                   # warm: buffers sized, kernels' attributes set
+            tm = GemmTimer()
+            tm.install(ops)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            window(form)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            tm.uninstall()
+            g = tm.summary(layouts=(0, 1, 2))
+            n = ACC * STEPS_PER_EPISODE
+            out[form] = {"nav_steps_per_s_per_gpu": round(n / dt, 2), "ms_per_step": round(dt / n * 1e3, 2),
+                         "roofline": None if g is None else {
+                             "bound": "mfma", "achieved": round(g["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(g["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4), "launches": g["launches"],
+                             "avg_launch_ms": round(g["avg_launch_ms"], 4), "gemm_share_of_window": round(g["gemm_seconds"] / dt, 3)}}
+        except Exception as e:
+            out[form] = {"error": f"{type(e).__name__}: {e}"}
+    model.episode_abort()
+    model.zero_grad()
+    model.episode_release()
+    model.episode = None                                   # the B = 1 caches: the next begin_episode() builds its own
     return out
 
 
@@ -702,6 +760,7 @@ def main():
         outside the timed region."""
         one_step = make_step(mode)
         model.episode_abort()
+        model.zero_grad()
         ep.reset()
         setup = prewarm + (-(prewarm + warmup)) % STEPS_PER_EPISODE
         for i in range(setup):          # setup, not part of the protocol's W/K accounting
@@ -709,6 +768,8 @@ def main():
         for i in range(setup, setup + warmup):
             one_step(i)
         base = setup + warmup           # a multiple of 6: step `base` opens an episode
+        if getattr(wrapped, "profile", False):
+            wrapped.exchange_stats(reset=True)      # the exchange events of the setup / warmup steps (first one: RCCL channel setup) do not count
         tm = GemmTimer()
         if not a.no_profile:
             tm.install(ops)
@@ -734,10 +795,24 @@ def main():
         return float(tmax.item()), tm, loss
 
     phase("model built")
+    if world > 1 and hasattr(wrapped, "exchange_stats"):
+        wrapped.profile = True           # HIP events around the exchange of every optimizer step (side stream + the join): `dp.exchange`
     dt, timer, loss = run_mode(a.mode, a.steps, a.warmup, a.prewarm, True)
     seq_len_main = int(max(ep.S_hist)) if ep.S_hist else None
     main_stats = dict(model.episode.stats) if (a.mode == "prefix_reuse" and model.episode is not None) else None
 
+    # ---- N > 1: what the gradient exchange cost inside the timed region, and which RCCL every rank bound
+    dp_exchange, rccl_versions = None, None
+    if world > 1:
+        try:
+            dp_exchange = wrapped.exchange_stats()
+            wrapped.profile = False
+            from navillm_amd import lib as _nvlib
+            mine = int(_nvlib.load().nv_comm_rccl_version()) if wrapped.comm is not None else None
+            rccl_versions = [None] * world
+            dist.all_gather_object(rccl_versions, mine)
+        except Exception as e:
+            dp_exchange = {"error": f"{type(e).__name__}: {e}"}
     phase(f"timed region done: {dt:.2f} s")
     # ---- the same mode over WHOLE 6-step episodes (steady state; reported aside, never `value`): the K-step window above ends with a
     # short episode whenever K is not a multiple of 6
@@ -756,6 +831,13 @@ def main():
                     globals()["TF_BATCH"] = False
                     p_dt, _, _ = run_mode(a.mode, w_steps, 0, 0, world > 1)
                     whole["per_step_forward_nav_steps_per_s"] = round(a.batch * world * w_steps / p_dt, 2)
+                    # what a fine-tune sees: the multi-task stage alternates teacher forcing with DAgger sampling meta-step by
+                    # meta-step (mp3d_agent.py:509-525: `step % 2 == 0` -> feedback="teacher", else "sample"); a sampled step needs
+                    # its logits at once, so only the teacher-forced half may batch its forward -> harmonic mean of the two rates
+                    tf_r, ps_r = whole["nav_steps_per_s"], whole["per_step_forward_nav_steps_per_s"]
+                    whole["finetune_blend_nav_steps_per_s"] = round(2.0 / (1.0 / tf_r + 1.0 / ps_r), 2)
+                    whole["finetune_blend_what"] = ("harmonic mean of the teacher-forced (batched forward) and per-step-forward rates: the "
+                                                    "50/50 teacher / sample schedule of fine-tuning, mp3d_agent.py:509-525; pre-training is all teacher-forced")
                 finally:
                     globals()["TF_BATCH"] = global_tf
         except Exception as e:
@@ -800,6 +882,7 @@ def main():
     if not a.no_extras and (a.model != "tiny" or a.extras_on_tiny):
         for name, fn in (("mixed_task_training_config3", lambda: mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed + 100)),
                          ("long_horizon_config4", lambda: long_horizon_extra(a, cfg, model, wrapped, crit, device, seed + 200)),
+                         ("reference_launch_line", lambda: reference_launch_extra(a, cfg, model, opt, crit, device, seed + 400) if world == 1 else None),
                          ("fp8_weight_only_13b_config5", lambda: fp8_13b_extra(a, device, seed + 300) if world == 1 else None)):
             phase(name)
             try:        # never take the headline line (or a rank) down
@@ -845,9 +928,15 @@ def main():
             line["other_mode"] = other
         if REHEARSAL:
             line["rehearsal"] = "all ranks shared GPU 0 over gloo: control-flow check only, the numbers are meaningless"
+        if whole is not None and "finetune_blend_nav_steps_per_s" in whole:
+            line["finetune_blend"] = {"nav_steps_per_s": whole["finetune_blend_nav_steps_per_s"], "teacher_forced": whole["nav_steps_per_s"],
+                                      "per_step_forward": whole["per_step_forward_nav_steps_per_s"],
+                                      "recompute_reference_formulation": (other or {}).get("nav_steps_per_s_per_gpu") if (other or {}).get("mode") == "recompute" else None,
+                                      "what": whole["finetune_blend_what"]}
         if world > 1:
             line["dp"] = {"transport": "nv_comm (RCCL, C ABI)" if wrapped.comm is not None else "torch.distributed",
                           "reduce": wrapped.reduce, "algo": wrapped.algo, "calibration": wrapped.calibration,
+                          "rccl_version_per_rank": rccl_versions, "exchange": dp_exchange,
                           "what": "gradients averaged once per optimizer step, per-layer slices exchanged from inside the "
                                   "episode's last backward on a side stream"}
         if infer is not None:

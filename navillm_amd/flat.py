@@ -43,6 +43,8 @@ class FlatStore:
         self.offsets = {}
         self.sizes = {}
         self.alloc_sizes = {}     # size incl. alignment padding: offsets[n] + alloc_sizes[n] == offset of the next tensor
+        self.grad_writes = 0      # bumped whenever a backward writes (or is about to write) into .grad -- see FlatAdamW.zero_grad
+        self.tainted = None       # set by NavModel.episode_abort() when the aborted episode had already written PART of its gradients
         self.touched = set()      # names that have received a gradient at least once (navillm_amd/optim.py: which tensors AdamW updates)
         self.names = {"lm": lm_names, "f32": f32_names}
         self.shape_of = shape_of
@@ -127,14 +129,17 @@ class FlatStore:
 
     # ---- "this tensor has a gradient now" (torch: p.grad is no longer None); reported by the backward functions
     def touch(self, *names):
+        self.grad_writes += 1           # a gradient was (or is about to be) written: FlatAdamW's fused zero-grad bookkeeping is stale
         self.touched.update(names)
 
     def touch_layers(self):
         """every decoder-layer tensor + the final norm (LlamaStack.backward accumulates into all of them)"""
+        self.grad_writes += 1
         if "lang_model.model.norm.weight" not in self.touched:
             self.touched.update(n for n in self.names["lm"] if n.startswith("lang_model.model.layers.") or n == "lang_model.model.norm.weight")
 
     def zero_grad(self):
+        self.tainted = None
         if self.grad is not None:
             for g in self.grad.values():
                 g.zero_()

@@ -310,10 +310,18 @@ class NavModel(nn.Module):
             self.episode.release_buffers()
 
     def episode_abort(self):
-        """drop an episode that was begun but will not be finished (its deferred gradients are discarded)"""
-        if self.episode is not None:
-            self.episode.prefix = None
-            self.episode._cursor = 0
+        """drop an episode that was begun but will not be finished.  Its deferred gradients are discarded -- but whatever the
+        episode has ALREADY written into `.grad` is not undone: flushed segments of a long episode (`flush_segment`: LM weight,
+        embedding and encoder gradients of those steps), steps that ran their backward at once (the non-deferred forms, truncated
+        prompts), while the prefix's own backward never runs.  `.grad` then holds a partial, inconsistent sum, so the gradient
+        store is marked tainted: `FlatAdamW.clip_grad_norm_` / `step` raise until `zero_grad()`."""
+        ep = self.episode
+        if ep is not None:
+            P = ep.prefix
+            if P is not None and (P.get("segments", 0) > 0 or P.get("kv_steps", 0) > 0 or ep.stats.get("recomputed_steps", 0) > 0):
+                self.store.tainted = "episode_abort() after part of the episode's gradients had been written to .grad"
+            ep.prefix = None
+            ep._cursor = 0
 
     def parameters(self, recurse=True):
         """nn.Module.parameters, except that asking for the parameters while a prefix-reuse episode still HOLDS gradients (its steps

@@ -157,6 +157,9 @@ class FlatAdamW(torch.optim.Optimizer):
     def _no_open_episode(self):
         """prefix-reuse training (navillm_amd/episode.py) hands over its gradients -- in the default form ALL of the LM's -- at
         `finish_episode()`: an update in front of it would silently train on the encoder's gradients alone"""
+        if self.store.tainted:
+            raise RuntimeError(f"the gradient buffers are inconsistent ({self.store.tainted}): call zero_grad() before the next "
+                               "clip_grad_norm_ / step")
         ep = getattr(self.model, "episode", None)
         if ep is not None and ep.has_pending_gradients():
             raise RuntimeError("optimizer step inside an open prefix-reuse episode: call model.finish_episode() (under "
@@ -201,12 +204,16 @@ class FlatAdamW(torch.optim.Optimizer):
                            self.step_count - born, lr, b1, b2, eps, wd, clip=clip, zero_grad=self.fused_zero_grad)
         self._clip_valid = False
         self._zeroed_segs = {grp: [(s, e) for s, e, _ in segs] for grp, segs in self._segs.items()} if self.fused_zero_grad else None
+        self._zeroed_at = st.grad_writes
 
     def zero_grad(self, set_to_none=False):
         z, self._zeroed_segs = self._zeroed_segs, None
-        if z is None or self.store.grad is None:
+        # the fused form is only valid when nothing wrote a gradient since step() zeroed the updated segments (with
+        # step(); backward(); zero_grad() only the gaps were cleared and the new gradients survived into the next step)
+        if z is None or self.store.grad is None or self.store.grad_writes != self._zeroed_at:
             self.store.zero_grad()
             return
+        self.store.tainted = None
         # step() already zeroed every updated segment: fill only what lies between them
         for grp, g in self.store.grad.items():
             pos = 0

@@ -198,6 +198,10 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
         self._comm_stream = torch.cuda.Stream() if on_gpu else None
         self._queued = False
         self.calibration = None
+        # measurement (bench.py `dp` block): HIP events around every slice's collective on the side stream and around the join of
+        # the compute stream with it -> exchange time per optimizer step and the part of it the backward did NOT hide
+        self.profile = False
+        self._prof_slices, self._prof_joins = [], []
         # back-reference WITHOUT module registration: `module._dp = self` would make the wrapper a child module of the model
         # it wraps (a cycle: .train()/.eval()/.state_dict() then recurse forever)
         object.__setattr__(module, "_dp", self)
@@ -333,9 +337,47 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
             for e in events:
                 self._comm_stream.wait_event(e)
             with torch.cuda.stream(self._comm_stream):
-                self._reduce(t)
+                if self.profile:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    self._reduce(t)
+                    e1.record()
+                    self._prof_slices.append((e0, e1, t.numel() * t.element_size()))
+                else:
+                    self._reduce(t)
         else:
             self._reduce(t)
+
+    def _join(self):
+        """the compute stream waits for the side stream's collectives (end of an exchange)"""
+        if self._comm_stream is None:
+            return
+        if self.profile:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            b.record()
+            self._prof_joins.append((a, b))
+        else:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    def exchange_stats(self, reset=True):
+        """(profile = True) per exchange = per optimizer step: time the collectives were busy on the side stream, the bytes they
+        moved per rank, and the EXPOSED part -- how long the compute stream sat at the join waiting for them (what the overlap with
+        the backward did not hide)."""
+        if not self._prof_joins:
+            return None
+        torch.cuda.synchronize()
+        n = len(self._prof_joins)
+        busy = sum(a.elapsed_time(b) for a, b, _ in self._prof_slices)
+        byts = sum(x for _, _, x in self._prof_slices)
+        exposed = sum(a.elapsed_time(b) for a, b in self._prof_joins)
+        out = {"exchanges": n, "slices_per_exchange": round(len(self._prof_slices) / n, 1), "bytes_per_exchange": int(byts / n),
+               "collective_busy_ms_per_exchange": round(busy / n, 3), "exposed_ms_per_exchange": round(exposed / n, 3),
+               "busbw_GBps": (round(byts / (busy * 1e-3) / 1e9 * 2 * (self._world() - 1) / max(self._world(), 1), 1) if busy > 0 else None)}
+        if reset:
+            self._prof_slices, self._prof_joins = [], []
+        return out
 
     def _finalize(self):
         """end of the autograd pass: exchange what is left, then join the side stream."""
@@ -343,8 +385,7 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
         todo = self.slices.rest if self.overlap else self.slices.all_slices()
         for t in todo:
             self._launch(t)
-        if self._comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._join()
         self._pending = False
 
     @torch.no_grad()
@@ -384,8 +425,7 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
         if self._world() > 1 or self.force_sync:
             for t in self.slices.all_slices():
                 self._launch(t)
-            if self._comm_stream is not None:
-                torch.cuda.current_stream().wait_stream(self._comm_stream)
+            self._join()
         self._pending = False
 
 

@@ -177,10 +177,12 @@ def _rot_half(x):
     return torch.cat([-x[..., h:], x[..., :h]], -1)
 
 
-def llama_decoder(P, cfg, inputs_embeds, attention_mask, prefix="lang_model.model"):
+def llama_decoder(P, cfg, inputs_embeds, attention_mask, prefix="lang_model.model", layers=None, final_norm=True, collect=None):
     """LlamaModel.forward with inputs_embeds + attention_mask only: positions are
     arange(S) INCLUDING left padding, causal + key-padding additive mask,
-    eager attention with fp32 softmax."""
+    eager attention with fp32 softmax.
+    Test instruments: `layers` (iterable of layer indices, default all) runs a sub-range, `final_norm=False` returns the last
+    layer's output before the final RMSNorm, `collect` (a dict) receives every executed layer's INPUT under its index."""
     x = inputs_embeds
     B, S, d = x.shape
     H, hd = cfg.num_heads, cfg.head_dim
@@ -190,8 +192,10 @@ def llama_decoder(P, cfg, inputs_embeds, attention_mask, prefix="lang_model.mode
     allowed = torch.tril(torch.ones(S, S, dtype=torch.bool))[None] & attention_mask.bool()[:, None, :]
     amask = torch.zeros(B, 1, S, S, dtype=dt).masked_fill(allowed.logical_not()[:, None], neg)
     scaling = hd ** -0.5
-    for i in range(cfg.num_layers):
+    for i in (range(cfg.num_layers) if layers is None else layers):
         p = f"{prefix}.layers.{i}"
+        if collect is not None:
+            collect[i] = x
         n = rms_norm(x, P[p + ".input_layernorm.weight"], cfg.rms_norm_eps)
         q = F.linear(n, P[p + ".self_attn.q_proj.weight"]).view(B, S, H, hd).transpose(1, 2)
         k = F.linear(n, P[p + ".self_attn.k_proj.weight"]).view(B, S, H, hd).transpose(1, 2)
@@ -206,6 +210,8 @@ def llama_decoder(P, cfg, inputs_embeds, attention_mask, prefix="lang_model.mode
         g = F.linear(n, P[p + ".mlp.gate_proj.weight"])
         u = F.linear(n, P[p + ".mlp.up_proj.weight"])
         x = x + F.linear(F.silu(g) * u, P[p + ".mlp.down_proj.weight"])
+    if not final_norm:
+        return x
     return rms_norm(x, P[prefix + ".norm.weight"], cfg.rms_norm_eps)
 
 
