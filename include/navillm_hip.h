@@ -311,6 +311,8 @@ int nv_decoder_set_shared(nv_decoder* p, const void* rope_cos, const void* rope_
 /*   weight-only fp8 without resident bf16 operands: two bf16 panels (each >= the largest operand) + a side stream; nv_decoder_extend
  *   then de-quantises the NEXT Linear's operand on the side stream while the current GEMM runs (steps of > 16 rows) */
 int nv_decoder_set_fp8_overlap(nv_decoder* p, void* panel_a, void* panel_b, void* side_stream);
+/*   nv_gemm_fp8w mode of THIS decoder's few-hundred-row GEMMs on fp8 codes: 7 | 9, 0 = the process default */
+int nv_decoder_set_fp8_gemm_mode(nv_decoder* p, int mode);
 size_t nv_decoder_workspace_bytes(const nv_decoder* p, int max_rows);
 /*   x_in [M,d] new-row embeddings; pos/crow/grow [M] (position, cache row written, cache row read back); kv0 [B] zeros; attn_buf
  *   [B*cap,d]; lse [B,H,cap]; last [B] -> hs_out [B,d] final-norm hidden states of those block rows; hs_all optional [M,d] */

@@ -41,6 +41,7 @@ struct nv_decoder {
     const void *rope_cos = nullptr, *rope_sin = nullptr, *final_norm = nullptr;
     void* gemm_ws = nullptr;        // zero-filled split-K workspace of nv_gemm_bf16_ws (may be NULL)
     void* fp8_scratch = nullptr;    // bf16 panel for de-quantised operands (needed when a layer carries codes)
+    int fp8_gemm_mode = 0;          // nv_gemm_fp8w mode of THIS decoder's few-hundred-row GEMMs (7 | 9; 0 = the process default)
     // weight-only fp8, memory-lean AND overlapped (round 3): two panels; the NEXT Linear's operand is de-quantised on a side stream
     // while the current GEMM runs (the GEMM is MFMA-bound and leaves most of the HBM bandwidth idle; the pre-pass is pure bandwidth)
     void* panel[2] = {nullptr, nullptr};
@@ -84,6 +85,15 @@ int nv_decoder_set_fp8_overlap(nv_decoder* p, void* panel_a, void* panel_b, void
     return NV_OK;
 }
 
+// how this decoder's tile GEMMs on fp8 codes form their operands: 7 = bf16(s*q) (bit-identical to the pre-pass), 9 = codes converted
+// unscaled + s[n] on the fp32 accumulator, 0 = the process default (nv_gemm_fp8w_default_mode).  Per object: two models with
+// different modes in one process keep their own.
+int nv_decoder_set_fp8_gemm_mode(nv_decoder* p, int mode) {
+    if (!p || !(mode == 0 || mode == 7 || mode == 9)) return NV_ERR_ARG;
+    p->fp8_gemm_mode = mode;
+    return NV_OK;
+}
+
 // weights of layer i.  kind: 0 qkv, 1 o, 2 gate|up, 3 down.  Either `w` (bf16 [N,K]) or `codes` + `scales` (weight-only fp8).
 int nv_decoder_set_weight(nv_decoder* p, int i, int kind, const void* w, const void* codes, const float* scales) {
     if (!p || i < 0 || i >= p->L || kind < 0 || kind > 3) return NV_ERR_ARG;
@@ -124,7 +134,7 @@ static int linear(const nv_decoder* p, const Layer& ly, int kind, const void* x,
         // fragment path); NV_ERR_SHAPE = not a cut-off-tile shape -> the de-quantisation pre-pass + the bf16 GEMM
         static const bool tile_fp8 = [] { const char* e = getenv("NAVILLM_FP8_TILE_GEMM"); return !e || e[0] != '0'; }();
         if (tile_fp8) {
-            const int rc8 = nv_gemm_fp8w(x, ly.q[kind], ly.s[kind], out, R, M, N, K, K, K, N, N, epi, 0, 0, p->gemm_ws, stream);
+            const int rc8 = nv_gemm_fp8w(x, ly.q[kind], ly.s[kind], out, R, M, N, K, K, K, N, N, epi, p->fp8_gemm_mode, 0, p->gemm_ws, stream);
             if (rc8 != NV_ERR_SHAPE) return rc8;
         }
         if (!p->fp8_scratch) return NV_ERR_ARG;

@@ -1423,12 +1423,16 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
 // two-kernel path, not a fallback to another backend.  mode: 0 = default (nv_gemm_fp8w_default_mode / NV_GEMM_FP8_MODE, else 7), 7 = operands bf16(s*q)
 // bit-exact (what the pre-pass writes), 8 = v_cvt_scalef32 with the scale as its operand, 9 = v_cvt_scalef32 unscaled + s[n] on
 // the fp32 accumulator.  tile_cfg: 0 = planned, 84 / 85 = force the 128 / 160-row tile (tests).  epilogue: EPI_STORE | EPI_RESID.
-static int g_fp8_default_mode = [] { const char* e = getenv("NV_GEMM_FP8_MODE"); const int m = e ? atoi(e) : 0; return (m >= 7 && m <= 9) ? m : 7; }();
-// process-wide default of nv_gemm_fp8w's `mode` (what callers that pass 0 get, e.g. the native decoder loop): 7 | 8 | 9; returns the
-// previous one, mode = 0 only queries.  A deployment choice like the NV_GEMM_* environment knobs, not per-call state.
+// (mode 8 is a MEASUREMENT form whose results are wrong by up to 2x -- the hardware uses only the exponent of the scale operand -- so it
+// can be asked for per call, never become a default: ADVICE r4)
+static int g_fp8_default_mode = [] { const char* e = getenv("NV_GEMM_FP8_MODE"); const int m = e ? atoi(e) : 0; return (m == 7 || m == 9) ? m : 7; }();
+// process-wide default of nv_gemm_fp8w's `mode` (what callers that pass 0 get): 7 | 9; returns the previous one; any other value only
+// queries.  A deployment choice like the NV_GEMM_* environment knobs; a model's own choice travels per object instead
+// (Fp8DecoderWeights.gemm_mode per call, nv_decoder_set_fp8_gemm_mode for the native layer loop), so two models with different modes
+// in one process do not override each other.
 extern "C" int nv_gemm_fp8w_default_mode(int mode) {
     const int prev = g_fp8_default_mode;
-    if (mode >= 7 && mode <= 9) g_fp8_default_mode = mode;
+    if (mode == 7 || mode == 9) g_fp8_default_mode = mode;
     return prev;
 }
 

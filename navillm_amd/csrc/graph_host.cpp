@@ -36,6 +36,9 @@ struct nv_graph {
     std::vector<double> pos;       // [cap, 3]
     std::vector<uint8_t> has_pos;
     std::vector<int> step_id;      // [cap]  GraphMap.node_step_ids (0 = never stood on)
+    std::vector<int> pos_order;    // nodes in the order their position was FIRST set = the insertion order of the reference's
+                                   // `node_positions` dict, which is the order mp3d_agent.py:316-321 lists the map slots in.  (Not the
+                                   // node-id order: add_edge / a step-id write / an adopted pre-built graph intern ids earlier.)
 
     void grow(int need) {
         if (need <= cap) return;
@@ -76,6 +79,7 @@ int nv_graph_num_nodes(const nv_graph* g) { return g ? g->n : NV_ERR_ARG; }
 int nv_graph_set_position(nv_graph* g, int node, const double* xyz) {
     if (!g || !xyz || node < 0 || node >= g->n) return NV_ERR_ARG;
     memcpy(&g->pos[(size_t)node * 3], xyz, 3 * sizeof(double));
+    if (!g->has_pos[node]) g->pos_order.push_back(node);
     g->has_pos[node] = 1;
     return NV_OK;
 }
@@ -197,7 +201,8 @@ int nv_graph_set_step_id(nv_graph* g, int node, int step) {
 // Per sample b (map graphs[b], agent at node cur[b] with heading / elevation, episode start node start[b], the current panorama's
 // candidate nodes cand_ids[cand_off[b] .. cand_off[b+1])):
 //   map slots = [stop] + visited nodes + unvisited nodes (enc_full_graph) or [stop] + unvisited nodes, each group in the order the
-//   nodes entered `node_positions` (= node-id order: the Python shell interns a node when its position is first set);
+//   nodes entered `node_positions` (the order their position was first set: nv_graph::pos_order -- equal to the node-id order only
+//   while every node is interned by its position write);
 //   G = the longest slot list of the batch; every output row is padded to G (zeros / -1 / false), rows are G apart:
 //     gmap_ids [B,G] i32 (-1 = stop slot / padding)      gmap_step_ids [B,G] i64       gmap_visited [B,G] u8      gmap_masks [B,G] u8
 //     gmap_pos_fts [B,G,afs+3] f32 (GraphMap.get_pos_fts of every slot)               gmap_lens [B] i32          no_vp_left [B] u8
@@ -220,7 +225,7 @@ int nv_nav_collate(nv_graph* const* graphs, int B, const int* cur, const int* st
         const nv_graph* g = graphs[b];
         if (!g || cur[b] < 0 || cur[b] >= g->n || start[b] < 0 || start[b] >= g->n) return NV_ERR_ARG;
         int len = 1;
-        for (int v = 0; v < g->n; ++v) len += (g->has_pos[v] && (enc_full_graph || !g->visited[v])) ? 1 : 0;
+        for (int v : g->pos_order) len += (enc_full_graph || !g->visited[v]) ? 1 : 0;
         gmap_lens[b] = len;
         G = len > G ? len : G;
         const int K = cand_off[b + 1] - cand_off[b];
@@ -240,10 +245,10 @@ int nv_nav_collate(nv_graph* const* graphs, int B, const int* cur, const int* st
         for (int j = 0; j < G; ++j) ids[j] = -1;
         int j = 1, n_unvis = 0;
         if (enc_full_graph)
-            for (int v = 0; v < g->n; ++v)
-                if (g->has_pos[v] && g->visited[v]) { gmap_visited[(size_t)b * G + j] = 1; ids[j++] = v; }
-        for (int v = 0; v < g->n; ++v)
-            if (g->has_pos[v] && !g->visited[v]) { ids[j++] = v; ++n_unvis; }
+            for (int v : g->pos_order)
+                if (g->visited[v]) { gmap_visited[(size_t)b * G + j] = 1; ids[j++] = v; }
+        for (int v : g->pos_order)
+            if (!g->visited[v]) { ids[j++] = v; ++n_unvis; }
         const int len = gmap_lens[b];
         if (j != len) return NV_ERR_ARG;
         no_vp_left[b] = n_unvis == 0;

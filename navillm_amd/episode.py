@@ -95,9 +95,12 @@ class _SuffixLM(torch.autograd.Function):
 
 
 class PrefixEpisode:
-    def __init__(self, model, batch_size, capacity=1024):
+    def __init__(self, model, batch_size, capacity=1024, max_length=1024):
         cfg = model.cfg
         self.m, self.B, self.cap = model, batch_size, capacity
+        # the tokenizer's `max_length` (modified_lm.py:57,77-87: left truncation at 1024): a prompt that reaches it was cut from the LEFT
+        # and no longer starts with the episode's prefix -- independent of how many rows per sample the K/V cache holds
+        self.max_length = int(max_length)
         d, L, H = cfg.hidden_size, cfg.num_layers, cfg.num_heads
         dev = model.device
         rows = batch_size * capacity
@@ -350,7 +353,7 @@ class PrefixEpisode:
             lp = int(P["lens"][b])
             if ids_list[b][:lp] == P["ids"][b] and lp < len(ids_list[b]) <= self.cap:
                 continue
-            if len(ids_list[b]) >= self.cap:
+            if len(ids_list[b]) >= min(self.cap, self.max_length):      # truncated at the tokenizer's limit, or longer than the cache
                 self.stats["recomputed_steps"] += 1
                 return False
             raise AssertionError("the prompt does not start with the prefix registered for this episode")

@@ -100,7 +100,8 @@ class Fp8DecoderWeights:
             gemm_mode = int(os.environ.get("NAVILLM_FP8_GEMM_MODE", "7"))
         assert gemm_mode in (7, 9), gemm_mode
         self.gemm_mode = gemm_mode
-        ops._L().nv_gemm_fp8w_default_mode(gemm_mode)          # the native K/V-cache layer loop passes mode 0
+        # (per object: `linear()` passes the mode per call, KVCacheLM hands it to its native layer loop with nv_decoder_set_fp8_gemm_mode;
+        # the process-wide default is left alone -- two models with different modes must not override each other)
         self.codes, self.scales = [], []
         self.resident = [] if resident_bf16 else None          # per layer: the bf16 operands holding bf16(s*q) (views of the flat store)
         with torch.no_grad():

@@ -128,6 +128,16 @@ class _StepIds(dict):
         g = self._owner._graph
         _lib.check(_L().nv_graph_set_step_id(g._g, g._id(k), int(v)), "nv_graph_set_step_id")
 
+    # dict's bulk writers do not go through __setitem__: mirror them too
+    def update(self, *a, **k):
+        for key, v in dict(*a, **k).items():
+            self[key] = v
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            self[key] = default
+        return self[key]
+
 
 class GraphMap:
     """graph_utils.py:99-165 (node embeddings kept as running sums of detached device tensors)."""

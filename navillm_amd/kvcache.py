@@ -103,6 +103,8 @@ class KVCacheLM:
                     rc = L.nv_decoder_set_weight(dec, i, k, m.lm_w(i, kind).data_ptr(), None, None)
                 _lib.check(rc, "nv_decoder_set_weight")
         scratch = m.fp8._scratch.data_ptr() if (m.fp8 is not None and m.fp8._scratch is not None) else None
+        if m.fp8 is not None:
+            _lib.check(L.nv_decoder_set_fp8_gemm_mode(dec, int(m.fp8.gemm_mode)), "nv_decoder_set_fp8_gemm_mode")
         _lib.check(L.nv_decoder_set_shared(dec, m.rope_cos.data_ptr(), m.rope_sin.data_ptr(), st.p("lang_model.model.norm.weight").data_ptr(),
                                            ops._gemm_ws(m.device) if ops.SPLITK_TAIL else None, scratch), "nv_decoder_set_shared")
         if m.fp8 is not None and m.fp8.overlap:

@@ -110,6 +110,7 @@ SIGNATURES = {
     "nv_decoder_set_layer": (i, [vp, i, vp, vp, vp]),
     "nv_decoder_set_shared": (i, [vp, vp, vp, vp, vp, vp]),
     "nv_decoder_set_fp8_overlap": (i, [vp, vp, vp, vp]),
+    "nv_decoder_set_fp8_gemm_mode": (i, [vp, i]),
     "nv_decoder_workspace_bytes": (sz, [vp, i]),
     "nv_decoder_extend": (i, [vp, vp, ip, ip, ip, ip, vp, fp, ip, vp, vp, i, i, i, i, i, ip, vp, sz, vp]),
     "nv_gemv_pre": (i, [vp, ip, vp, fp, vp, vp, i, i, i, i, i, i, i, i, vp, f, i, vp]),

@@ -51,13 +51,14 @@ class LangModelShell(nn.Module):
         self.hidden_size = cfg.hidden_size
         self.model_type = BF16 if cfg.lm_is_bf16 else F32
         self.tokenizer = tokenizer
+        self.max_length = 1024          # modified_lm.py:57,77-87: prompts are LEFT-truncated at this many tokens
 
     def tokenize(self, text, add_special_tokens=True):
         """modified_lm.py:77-87 (left pad, left truncation at 1024, token_type_ids)."""
         if self.tokenizer is None:
             raise RuntimeError("no tokenizer attached: pass pre-tokenised batch['input_ids'] / "
                                "batch['attention_mask'] or build the model from a tokenizer directory")
-        return self.tokenizer(text, max_length=1024, padding=True, truncation=True, return_tensors="pt",
+        return self.tokenizer(text, max_length=self.max_length, padding=True, truncation=True, return_tensors="pt",
                               add_special_tokens=add_special_tokens, return_token_type_ids=True)
 
 
@@ -274,7 +275,7 @@ class NavModel(nn.Module):
         return self.kv
 
     # ---- optional training mode: the prompt's static prefix is computed once per episode (navillm_amd/episode.py)
-    def begin_episode(self, prefix_ids, capacity=1024, teacher_forced=False):
+    def begin_episode(self, prefix_ids, capacity=1024, teacher_forced=False, max_length=None):
         """prefix_ids: B lists of token ids -- the part of every navigation prompt of the coming episode that never changes
         (everything up to "### History:").  Until `finish_episode()`, training-mode `model('navigation')` calls push only the rest
         of each prompt through the LM, over the cached prefix (every other mode -- object_grounding included -- takes the full `_lm`
@@ -292,8 +293,11 @@ class NavModel(nn.Module):
         if self.episode is not None:
             # a begin before the previous episode's finish would silently drop that episode's deferred gradients
             self.episode.assert_no_pending_gradients("begin_episode()")
+        if max_length is None:         # the tokenizer's left-truncation limit (modified_lm.py:57); the stub tokenizer of the synthetic driver: 1024
+            max_length = int(getattr(self.lang_model, "max_length", 1024))
         if self.episode is None or self.episode.B != B or self.episode.cap != capacity:
-            self.episode = PrefixEpisode(self, B, capacity)
+            self.episode = PrefixEpisode(self, B, capacity, max_length)
+        self.episode.max_length = int(max_length)
         self.episode.begin(prefix_ids, teacher_forced=teacher_forced)
         return self.episode
 

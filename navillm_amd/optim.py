@@ -148,6 +148,7 @@ class FlatAdamW(torch.optim.Optimizer):
         # the buffer).  NAVILLM_ADAMW_ZERO_GRAD=0: separate full fill as before.
         self.fused_zero_grad = os.environ.get("NAVILLM_ADAMW_ZERO_GRAD", "1") != "0"
         self._zeroed_segs = None
+        self._zeroed_at = -1            # FlatStore.grad_writes when step() zeroed them: any gradient write since invalidates the fused form
 
     # `lr` as an attribute mirrors the single param group (tests / callers that poke it directly)
     @property

@@ -679,6 +679,7 @@ def test_flat_adamw_zero_grad_after_a_fused_step_fills_only_the_gaps():
     n_lm = st.grad["lm"].numel()
     segs = {"lm": [(128, 1024), (4096, n_lm - 64)], "f32": []}
     opt._zeroed_segs = {k: list(v) for k, v in segs.items()}       # "step() already zeroed these"
+    opt._zeroed_at = st.grad_writes                                 # ... and nothing has written a gradient since
     opt.zero_grad()
     g = st.grad["lm"].float()
     assert float(g[:128].abs().max()) == 0 and float(g[1024:4096].abs().max()) == 0 and float(g[n_lm - 64:].abs().max()) == 0
@@ -689,6 +690,45 @@ def test_flat_adamw_zero_grad_after_a_fused_step_fills_only_the_gaps():
         g.fill_(1.0)
     opt.zero_grad()                                                                        # no fused step before: the full fill
     assert all(float(g.abs().max()) == 0 for g in st.grad.values())
+    # step(); backward(); zero_grad() -- a gradient written AFTER the fused step (FlatStore.touch bumps grad_writes) makes
+    # the bookkeeping stale: everything is cleared, not only the gaps
+    for g in st.grad.values():
+        g.fill_(1.0)
+    opt._zeroed_segs = {k: list(v) for k, v in segs.items()}
+    opt._zeroed_at = st.grad_writes
+    st.touch("out_head.0.weight")
+    opt.zero_grad()
+    assert all(float(g.abs().max()) == 0 for g in st.grad.values())
+    # a tainted store (episode_abort() after part of the episode's gradients were written) refuses clip / step until zero_grad()
+    st.tainted = "test"
+    with pytest.raises(RuntimeError, match="inconsistent"):
+        opt._no_open_episode()
+    opt.zero_grad()
+    assert st.tainted is None
+    opt._no_open_episode()
+
+
+def test_nav_collate_slot_order_is_position_insertion_order_not_node_id_order():
+    """the reference lists the map slots in `node_positions` insertion order (mp3d_agent.py:316-321).  Node ids in the C graph
+    are interned by whatever touches a viewpoint first -- an edge, a step-id write (also through dict.update / setdefault) -- so the
+    side-car keeps the order of FIRST POSITION WRITES itself; here the ids are interned in one order and the positions set in another."""
+    from navillm_amd.graph import GraphMap, NavCollator
+    gm = GraphMap("a")
+    gm.graph.add_edge("a", "z", 1.0)                       # interns a, z
+    gm.graph.add_edge("z", "m", 1.5)                       # m
+    gm.node_step_ids.update({"q": 3})                      # q gets an id (and its step id reaches the C graph through update())
+    gm.node_step_ids.setdefault("a", 1)
+    order = ["m", "a", "q", "z"]                           # position (= node_positions) insertion order: NOT the id order a, z, m, q
+    for i, k in enumerate(order):
+        gm.node_positions[k] = np.array([float(i), 0.5 * i, 0.0])
+    gm.graph.add_edge("a", "q", 2.0)
+    gm.graph.update("a")
+    col = NavCollator(1, 4, Gcap=16, enc_full_graph=True, pair_dists=False, pin=False)
+    out = col.collate([gm], ["a"], [0.3], [0.0], [["z", "m"]], device=torch.device("cpu"))
+    want = [None] + [k for k in gm.node_positions if gm.graph.visited(k)] + [k for k in gm.node_positions if not gm.graph.visited(k)]
+    assert list(gm.node_positions) == order and want == [None, "a", "m", "q", "z"]
+    assert col.vpids([gm], out["host"]) == [want]
+    assert out["host"]["gmap_step_ids"][0][:5].tolist() == [0, 1, 0, 3, 0]
 
 
 def test_kvcache_key_codes_vectorised_equals_the_token_loop():
