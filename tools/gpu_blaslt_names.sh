@@ -2,7 +2,7 @@
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_bl
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bl -o bl -- python tools/blaslt_names.py > gpurun_out/bl.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bl -o bl -- python tools/blaslt_names.py ${1:-4744} > gpurun_out/bl.log 2>&1
 DB=$(find gpurun_out/prof_bl -name "*.db" | head -1)
 python - "$DB" <<'P'
 import sqlite3, sys, collections
