@@ -177,6 +177,13 @@ int nv_attn_bwd_strided_kvacc_bf16(const void* qkv, const void* out, const void*
  *   cache position prefix_len + j).  Writes dqkv rows [Mp, R) (dQ and the steps' own dK|dV, through RoPE^T when the tables are given,
  *   position = prefix_len + j) and STORES the fp32 sum over the steps of the prefix rows' dK|dV in kv_acc [B*cap, 2*H*head_dim]
  *   (row b*cap + key).  workspace: (R - Mp) * H floats; at most 128 steps, at most 1536 rows per sample and step */
+/*   round 5: the FORWARD attention of all T steps of a prefix-reuse episode in one launch, reading the episode row buffers in place
+ *   (no scatter into the K/V-cache layout and back): qkv [rows, 3*H*128] post-RoPE -- prefix rows of sample b at [cu[b], cu[b+1]), step
+ *   t's rows of sample b at [tab[t*B+b], + tab[T*B+t*B+b]) --, out [rows, H*128] written at the steps' rows, lse_ptrs = device array of T
+ *   pointers to fp32 [B, H, cap] (step t's log2-domain lse at cache position prefix_len + j).  n_max = longest per-sample row count of a
+ *   step.  Bit-identical to scatter + nv_attn_fwd_strided_bf16 + gather per step. */
+int nv_attn_fwd_episode_bf16(const void* qkv, void* out, const void* lse_ptrs, const int* cu, const int* tab, int T, int B, int H,
+                             int head_dim, int cap, int n_max, long rows, void* stream);
 int nv_attn_bwd_episode_bf16(const void* qkv, const void* out, const void* dout, void* dqkv, void* workspace, const void* lse_ptrs,
                              const int* cu, const int* tab, float* kv_acc, const void* rope_cos, const void* rope_sin, int T, int B, int H,
                              int head_dim, int cap, int Mp, long R, int Lp_max, int N_max, void* stream);

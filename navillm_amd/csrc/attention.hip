@@ -469,6 +469,179 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     }
 }
 
+// =========================================================================== episode forward (round 5)
+// The forward twin of the episode backward kernels below: the steps of a prefix-reuse episode (navillm_amd/episode.py) keep their
+// q|k|v rows in per-layer episode buffers -- prefix rows of sample b at [cu[b], cu[b+1]), step t's rows of sample b at
+// [off[t,b], off[t,b] + n[t,b]) -- and a step's queries see their sample's whole prefix and the step's own earlier rows.  Round 4 ran
+// the batched (teacher-forced) forward's attention per step through the K/V-cache layout: scatter the step's rows into the cache,
+// one strided forward launch, gather the outputs back -- 18 launches per layer for six steps.  This kernel reads the row buffers in
+// place, ALL steps in one launch: grid (B*H, T * query blocks); key tile kt covers the VIRTUAL keys [64 kt, 64 kt + 64) of the
+// (sample, step) -- virtual key v is prefix row v for v < lp, the step's row v - lp otherwise -- i.e. exactly the cache positions
+// of the round-4 form, so every query row sees the same key tiles in the same order: bit-identical outputs and lse.
+struct EpiFwdArgs {
+    const bf16_t* qkv; bf16_t* out;
+    float* const* lse;              // [T] device pointers: lse2 [B, H, cap] of each step, written at cache position lp + j
+    const int* cu;                  // [B + 1] prefix rows
+    const int* tab;                 // [T * B] off | [T * B] n
+    int T, B, H, ld, cap, QB;       // QB = query blocks (128 rows) per (step, sample)
+    uint32_t span;                  // bytes addressable from qkv (rows of the episode buffer * ld * 2)
+    float scale2;
+};
+
+__global__ __launch_bounds__(256, 2) void epi_fwd_kernel(EpiFwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    LDS_PTR(char) smem = (LDS_PTR(char))smem_raw;
+    constexpr int TILE = 64 * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    // y walks the (step, query block) pairs with the LAST query block of every step first (the longest key ranges)
+    const int yy = (int)(gridDim.y - 1 - blockIdx.y);
+    const int t = yy % p.T, qb = yy / p.T;
+    const int cub = p.cu[b], lp = p.cu[b + 1] - cub;
+    const int off = p.tab[t * p.B + b], n = p.tab[p.T * p.B + t * p.B + b];
+    const int q0 = qb * 128;                                   // step-local index of this block's first query
+    if (q0 >= n) return;
+    const int ld = p.ld;
+    const int qi = lane & 15, g = lane >> 4;
+    const u32x4 rs = make_desc(p.qkv, p.span);
+    const int kcol = p.H * HD + h * HD, vcol = 2 * p.H * HD + h * HD;
+    const int Sv = lp + n;                                     // virtual sequence length of (sample, step)
+
+    bf16x8 qf[2][4];
+    int qpos[2];                                               // VIRTUAL positions of this lane's two queries
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int jl = q0 + wave * 32 + j * 16 + qi;
+        qpos[j] = lp + jl;
+        const long row = off + (jl < n ? jl : n - 1);
+        const bf16_t* qp = p.qkv + row * ld + h * HD + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[j][kk] = *(const bf16x8*)(qp + kk * 32);
+    }
+    f32x4 o[8][2];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) o[dt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m2[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+
+    const int q_hi = lp + ((q0 + 127 < n - 1) ? q0 + 127 : n - 1);       // last (virtual) query of this block
+    const int kt_end = q_hi / 64;
+    // DMA of one 64-key tile of K and of V: per lane the PHYSICAL row of its virtual key (clamped to the last valid one: such keys
+    // lie behind every query of the block and are masked)
+    auto stage = [&](int kt, int buf) {
+        const uint32_t lk = lds_addr_of(smem + buf * 2 * TILE), lv = lk + TILE;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int chunk = it * 4 + wave;
+            const int row = chunk * 4 + (lane >> 4);
+            int vk = kt * 64 + row;
+            vk = vk < Sv ? vk : Sv - 1;
+            const long prow = vk < lp ? (long)cub + vk : (long)off + (vk - lp);
+            const int slot = (lane & 15) ^ key4(row);
+            const uint32_t vo = (uint32_t)((prow * ld + slot * 8) * 2);
+            dma16(rs, __builtin_amdgcn_readfirstlane(lk + chunk * 1024), vo + (uint32_t)(kcol * 2));
+            dma16(rs, __builtin_amdgcn_readfirstlane(lv + chunk * 1024), vo + (uint32_t)(vcol * 2));
+        }
+    };
+    stage(0, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) pin(qf[j][kk]);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt <= kt_end; ++kt) {
+        if (kt < kt_end) stage(kt + 1, cur ^ 1);
+        LDS_PTR(char) sk = smem + cur * 2 * TILE;
+        LDS_PTR(char) sv = sk + TILE;
+        f32x4 s[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) s[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 kf = frag_rm(sk, i * 16, kk, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) s[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[j][kk], s[i][j], 0, 0, 0);
+            }
+        }
+        const bool interior = kt * 64 + 63 <= lp + q0 + wave * 32;      // (same test as attn_fwd_kernel, in virtual positions)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float mx = -INFINITY;
+            if (interior) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[i][j][r]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 64 + i * 16 + g * 4 + r;
+                        const float v = key <= qpos[j] ? s[i][j][r] : -INFINITY;
+                        s[i][j][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            }
+            mx = grp_max(mx) * p.scale2;
+            const float mn = fmaxf(m2[j], mx);
+            const float msafe = (mn == -INFINITY) ? 0.f : mn;
+            const float alpha = fast_exp2(m2[j] - msafe);
+            m2[j] = mn;
+            float rs_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = fast_exp2(fmaf(s[i][j][r], p.scale2, -msafe));
+                    s[i][j][r] = e;
+                    rs_ += e;
+                }
+            l[j] = l[j] * alpha + rs_;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) o[dt][j] *= alpha;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            bf16x8 pf[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pf[j] = pack_frag(s[2 * a][j], s[2 * a + 1][j]);
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                const bf16x8 vf = frag_tr(sv, a * 32, a * 32 + 16, dt * 16, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) o[dt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[j], o[dt][j], 0, 0, 0);
+            }
+        }
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+    }
+    float* lse2 = p.lse[t] + ((long)b * p.H + h) * p.cap;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float lt = grp_sum(l[j]);
+        const int jl = qpos[j] - lp;
+        if (jl < n) {
+            const float inv = lt > 0.f ? 1.f / lt : 0.f;
+            bf16_t* op = p.out + ((long)off + jl) * (p.H * HD) + h * HD + g * 4;
+#pragma unroll
+            for (int dt = 0; dt < 8; ++dt) {
+                u32x2 w = {pack2bf(o[dt][j][0] * inv, o[dt][j][1] * inv), pack2bf(o[dt][j][2] * inv, o[dt][j][3] * inv)};
+                *(u32x2*)(op + dt * 16) = w;
+            }
+            if (g == 0) lse2[qpos[j]] = lt > 0.f ? m2[j] + log2f(lt) : INFINITY;
+        }
+    }
+}
+
 // =========================================================================== backward prep
 // dsum[b,h,q] = sum_d dO[q,d] * O[q,d]   (16 lanes per (row, head): 16-B loads, 4 items per wave)
 // rows = B*S (padded layout) or cu[B] (packed layout: the sample of a row is found by walking cu, B is small)
@@ -1236,6 +1409,29 @@ int nv_attn_fwd_strided_bf16(const void* qkv, void* out, float* lse2, const int*
     p.B = B; p.S = S; p.Sst = S_stride; p.H = H; p.ld = 3 * H * HD; p.q_row_min = q_row_min;
     p.scale = 1.f / sqrtf((float)HD); p.scale2 = p.scale * 1.4426950408889634f;
     NV_LAUNCH(attn_fwd_kernel<false>, dim3(B * H, (S - q_row_min + 127) / 128), dim3(256), 65536, (hipStream_t)stream, p);
+    return nv_check_launch();
+}
+
+// Forward attention of ALL steps of a prefix-reuse episode in one launch, reading the episode row buffers in place (see
+// epi_fwd_kernel): qkv [rows, 3*H*128] post-RoPE (prefix rows of sample b at [cu[b], cu[b+1]), step t's rows of sample b at
+// [tab[t*B+b], + tab[T*B + t*B + b])), out [rows, H*128] written at the steps' rows, lse_ptrs[t] -> fp32 [B, H, cap] of step t written
+// at cache position prefix_len + j.  n_max = the longest per-sample row count of a step.  Bit-identical to scattering each step
+// into the K/V-cache layout + nv_attn_fwd_strided_bf16 + gathering back.
+int nv_attn_fwd_episode_bf16(const void* qkv, void* out, const void* lse_ptrs, const int* cu, const int* tab, int T, int B, int H,
+                             int head_dim, int cap, int n_max, long rows, void* stream) {
+    if (!qkv || !out || !lse_ptrs || !cu || !tab || T < 0 || B <= 0 || H <= 0 || cap <= 0 || rows <= 0) return NV_ERR_ARG;
+    if (head_dim != HD) return NV_ERR_SHAPE;
+    if (T == 0 || n_max <= 0) return NV_OK;
+    const long bytes = rows * 3L * H * HD * 2;
+    if (bytes > 0xffffffffL) return NV_ERR_SHAPE;
+    static bool once = false;
+    if (!once) { if (set_lds((const void*)epi_fwd_kernel, 65536)) return NV_ERR_LAUNCH; once = true; }
+    EpiFwdArgs p{};
+    p.qkv = (const bf16_t*)qkv; p.out = (bf16_t*)out; p.lse = (float* const*)lse_ptrs; p.cu = cu; p.tab = tab;
+    p.T = T; p.B = B; p.H = H; p.ld = 3 * H * HD; p.cap = cap; p.QB = (n_max + 127) / 128;
+    p.span = (uint32_t)bytes;
+    p.scale2 = (1.f / sqrtf((float)HD)) * 1.4426950408889634f;
+    NV_LAUNCH(epi_fwd_kernel, dim3(B * H, T * p.QB), dim3(256), 65536, (hipStream_t)stream, p);
     return nv_check_launch();
 }
 

@@ -694,13 +694,26 @@ class PrefixEpisode:
             last_cat = torch.cat([r["step"]["last"] + (r["r0"] - Mp) for r in recs])
             prune_top = os.environ.get("NAVILLM_EPISODE_PRUNE_TOP", "1") != "0" and L > 1
             P.pop("top", None)
+            # round 5: the attention of ALL steps in one launch per layer, reading the episode buffers in place (nv_attn_fwd_episode_bf16;
+            # NAVILLM_EPISODE_ATTN_FWD=steps: round 4's scatter -> strided forward -> gather per step, bit-identical)
+            epi_fwd = os.environ.get("NAVILLM_EPISODE_ATTN_FWD", "episode") != "steps" and len(recs) <= 4096
+            if epi_fwd:
+                T = len(recs)
+                tab = np.concatenate([np.array([[r["r0"] + o for o in r["step"]["off"]] for r in recs], np.int32).reshape(-1),
+                                      np.array([r["step"]["n"] for r in recs], np.int32).reshape(-1)])
+                ptrs = np.array([[self.lse_s[r["k"]][i].data_ptr() for r in recs] for i in range(L)], dtype=np.int64)
+                f_tab = ops.h2d(torch.from_numpy(tab), m.device)
+                f_lse = ops.h2d(torch.from_numpy(ptrs), m.device)
+                f_nmax = max(r["step"]["N"] for r in recs)
             x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_cat, vix_cat, vis_cat, out=self._E[0]["x"][rows])
             for i in range(L):
                 Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
                 E, E32 = self._E[i], self._E32[i]
                 n1, _ = ops.rmsnorm_fwd(x, w1, eps, out=E["n1"][rows], rstd=E32["r1"][rows])
                 ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, cap, 2 * H * hd, out=E["qkv"][rows], pos_i32=pos_cat)
-                for r in recs:                      # attention: per step over the K/V cache (prefix rows + this step's rows)
+                if epi_fwd:
+                    ops.attn_fwd_episode(E["qkv"][:R], E["attn"][:R], f_lse[i], P["cu"], f_tab, T, B, H, hd, cap, f_nmax)
+                for r in (() if epi_fwd else recs):  # round 4 form: per step over the K/V cache (prefix rows + this step's rows)
                     sp = r["step"]
                     sl = slice(r["r0"], r["r0"] + sp["M"])
                     ops.scatter_rows_bf16_(E["qkv"][sl], sp["crow"], self.cache[i])

@@ -53,6 +53,7 @@ SIGNATURES = {
     "nv_attn_fwd_hfround_bf16": (i, [vp, vp, fp, ip, ip, i, i, i, i, i, vp]),
     "nv_attn_bwd_strided_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, i, i, i, i, i, i, vp]),
     "nv_attn_bwd_strided_kvacc_bf16": (i, [vp, vp, vp, fp, ip, vp, vp, fp, ip, i, i, i, i, i, i, i, vp]),
+    "nv_attn_fwd_episode_bf16": (i, [vp, vp, vp, ip, ip, i, i, i, i, i, i, l, vp]),
     "nv_attn_bwd_episode_bf16": (i, [vp, vp, vp, vp, vp, vp, ip, ip, fp, vp, vp, i, i, i, i, i, i, l, i, i, vp]),
     "nv_attn_bwd_episode_acc_bf16": (i, [vp, vp, vp, vp, vp, vp, ip, ip, fp, vp, vp, i, i, i, i, i, i, l, i, i, i, vp]),
     "nv_attn_bwd_varlen_bf16": (i, [vp, vp, vp, fp, ip, ip, vp, vp, vp, vp, i, i, l, i, i, i, vp]),

@@ -299,6 +299,17 @@ def attn_bwd_strided(qkv, out, dout, lse2, kv_start_i32, B, S, S_stride, H, hd, 
     return dqkv
 
 
+def attn_fwd_episode(qkv, out, lse_ptrs_i64, cu_i32, tab_i32, T, B, H, hd, cap, N_max):
+    """forward attention of all T steps of a prefix-reuse episode for one layer, in one launch over the episode row buffers
+    (nv_attn_fwd_episode_bf16): the steps' rows of `out` and each step's lse (lse_ptrs[t] -> [B, H, cap]) are written"""
+    R = qkv.shape[0]
+    assert out.shape[0] == R and lse_ptrs_i64.numel() == T and tab_i32.numel() == 2 * T * B and qkv.shape[1] == 3 * H * hd
+    assert qkv.is_contiguous() and out.is_contiguous()
+    _lib.check(_L().nv_attn_fwd_episode_bf16(qkv.data_ptr(), out.data_ptr(), lse_ptrs_i64.data_ptr(), cu_i32.data_ptr(), tab_i32.data_ptr(),
+                                             T, B, H, hd, cap, N_max, R, _st()), "nv_attn_fwd_episode_bf16")
+    return out
+
+
 def attn_bwd_episode(qkv, out, dout, dqkv, lse_ptrs_i64, cu_i32, tab_i32, kv_acc, T, B, H, hd, cap, Mp, Lp_max, N_max, rope=None, accumulate=False):
     """attention backward of all T steps of a prefix-reuse episode for one layer (nv_attn_bwd_episode_acc_bf16): rows [Mp, R) of dqkv and
     the fp32 prefix K/V gradient sums in kv_acc are written (accumulate: added to what an earlier segment of the episode left there);

@@ -419,3 +419,38 @@ def test_teacher_forced_episode_batches_the_forward_and_matches(size, monkeypatc
         lg.argmax(1)
     m.finish_episode()
     assert torch.isfinite(lg.value[torch.isfinite(lg.value)]).all() and float(loss) > 0
+
+
+@pytest.mark.parametrize("size", ["mid", "7b-width"])
+def test_episode_forward_attention_one_launch_equals_the_per_step_cache_form(size, monkeypatch):
+    """round 5: `nv_attn_fwd_episode_bf16` (the attention of ALL steps of a teacher-forced episode in one launch per layer, reading the
+    episode row buffers in place) against round 4's form (scatter each step's q|k|v rows into the K/V-cache layout, one strided forward
+    per step, gather the outputs back): every query row sees the same 64-key tiles in the same order, so logits and every gradient
+    buffer must be bit-identical -- also when a long episode is flushed in segments."""
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd import config as nvcfg
+    cfg = _mid_cfg() if size == "mid" else nvcfg.vicuna_7b(image_feat_size=768, num_layers=2, base_vocab_size=2000)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
+    m.eval()
+    steps = 5
+    _episode(m, cfg, steps, use_prefix=True, teacher_forced=True)          # (cold start: buffers sized)
+    monkeypatch.setenv("NAVILLM_EPISODE_ATTN_FWD", "steps")
+    l_old, g_old, st_old = _episode(m, cfg, steps, use_prefix=True, teacher_forced=True)
+    monkeypatch.setenv("NAVILLM_EPISODE_ATTN_FWD", "episode")
+    l_new, g_new, st_new = _episode(m, cfg, steps, use_prefix=True, teacher_forced=True)
+    assert st_new["segments_flushed"] == 0 and st_old["suffix_rows"] == st_new["suffix_rows"]
+    for t in range(steps):
+        assert torch.equal(l_new[t], l_old[t]), f"step {t}"
+    for g in g_old:
+        assert torch.equal(g_new[g], g_old[g]), g
+    # segmented: the same two forms with the episode buffers capped
+    monkeypatch.setenv("NAVILLM_EPISODE_MAX_ROWS", str(st_new["prefix_rows"] + 2 * max(st_new["suffix_rows"])))
+    l_seg_new, g_seg_new, st_seg = _episode(m, cfg, steps, use_prefix=True, teacher_forced=True)
+    monkeypatch.setenv("NAVILLM_EPISODE_ATTN_FWD", "steps")
+    l_seg_old, g_seg_old, _ = _episode(m, cfg, steps, use_prefix=True, teacher_forced=True)
+    monkeypatch.delenv("NAVILLM_EPISODE_MAX_ROWS")
+    assert st_seg["segments_flushed"] >= 1
+    for t in range(steps):
+        assert torch.equal(l_seg_new[t], l_seg_old[t]), f"segmented, step {t}"
+    for g in g_old:
+        assert torch.equal(g_seg_new[g], g_seg_old[g]), ("segmented", g)
