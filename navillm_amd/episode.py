@@ -300,13 +300,52 @@ class PrefixEpisode:
             # made the first 64-step runs die with 24 GiB reserved-but-unusable.
             want = max(self._last_rows, Mp)
             budget = self._budget_bytes()
-            while want > 4096 and (self._row_bytes() * (int((Mp + want) * 1.1) + 64) > budget or not self._rows_fit(int((Mp + want) * 1.1) + 64)):
+            # (round 5: only when the buffers would have to GROW -- `_rows_fit` asks the driver for the free memory, and that query waits
+            # for the device to drain: called at every begin() it serialised the host's preparation of the next episode's steps with the
+            # previous episode's backward, 2-4 % of GPU idle time once the prefix forward no longer covered it)
+            while (self._E is None or Mp + want > self._ecap) and want > 4096 and \
+                    (self._row_bytes() * (int((Mp + want) * 1.1) + 64) > budget or not self._rows_fit(int((Mp + want) * 1.1) + 64)):
                 want = int(want * 0.6)
             if self._E is not None and self._ecap > 2.5 * (Mp + want) + 4096:
                 self.release_buffers()                           # a much longer episode ran before: give its rows back
             self._ensure_rows(Mp + want)
             self._seg_total = 0
             self._cursor = Mp
+        lazy = bool(teacher_forced) and allm and defer
+        # round 5: in a teacher-forced episode the PREFIX's forward is deferred too -- `_forward_lazy` pushes the prefix rows and all the
+        # steps' rows through the decoder as ONE batch (~8 300 rows per GEMM instead of 4 272 + ~4 200: the forward layout runs 7 % faster
+        # at that size, profiles/r05_gemm_vs_blaslt.txt, and every row kernel / GEMM of the forward is launched once instead of twice);
+        # only the index tables are built here.  NAVILLM_EPISODE_LAZY_PREFIX: 0 = the prefix forward runs now, as in round 4; 1 = always
+        # deferred; auto (default) = deferred while the GPU still has queued work (the host is ahead: steady state of a training run),
+        # run NOW when the stream is empty (first episode, or right after a synchronisation): an idle GPU is better off with 45 ms of
+        # prefix forward under the host's preparation of the six steps than with nothing (profiles/r05_episode_gaps_lazy*.txt: the
+        # first episode after a sync idles 30 ms with the prefix deferred, 16 ms without)
+        lz = os.environ.get("NAVILLM_EPISODE_LAZY_PREFIX", "auto")
+        pending = lazy and lz != "0"
+        if pending and lz == "auto" and dev.type == "cuda" and torch.cuda.current_stream(dev).query():
+            pending = False
+        self.prefix = dict(ids=[list(p) for p in prefix_ids], ids_np=ids, lens=lens, cu=cu_d, pos=pos_d, crow=crow_d, pos0=zero_pos0,
+                           Lmax=Lmax, Mp=Mp, layers=None, steps=0, kv_steps=0, defer=defer, lens_dev=lens_d, recs=[], segments=0,
+                           lazy=lazy, pending=pending, cache_valid=not pending, ids_dev=ids_d, vix_dev=vix)
+        self.stats = {"prefix_rows": Mp, "suffix_rows": [], "segments_flushed": 0, "recomputed_steps": 0}
+        if pending:
+            # what finish() reads of the prefix's saved state: views of the episode buffers (filled by `_forward_lazy`) + the lse slabs
+            self.prefix["layers"] = [dict(lse=self._buf(f"p{i}.lse", (B, H, Lmax), F32)) for i in range(L)]
+            return
+        self._prefix_forward()
+
+    @torch.no_grad()
+    def _prefix_forward(self):
+        """the prefix rows through the decoder (activations kept, post-RoPE K/V into the per-layer cache): at begin(), or -- a
+        teacher-forced episode whose prefix is still pending -- when a step that cannot be deferred needs the cache"""
+        m, cfg, st = self.m, self.m.cfg, self.m.store
+        P = self.prefix
+        B, cap, H, hd, eps, L = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers
+        d, ff = cfg.hidden_size, cfg.intermediate_size
+        Mp, Lmax, defer = P["Mp"], P["Lmax"], P["defer"]
+        allm = self.mode == "all"
+        ids_d, vix, pos_d, crow_d, cu_d, zero_pos0 = P["ids_dev"], P["vix_dev"], P["pos"], P["crow"], P["cu"], P["pos0"]
+        layers = []
         x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_d, vix, None,
                           out=self._E[0]["x"][:Mp] if allm else self._buf("pE", (Mp, d)))
         for i in range(L):
@@ -336,10 +375,20 @@ class PrefixEpisode:
             x2 = ops.gemm_bf16(ops.NT, h, Wd, out=t("x2", d), R=x1, epilogue=ops.EPI_RESID)
             layers.append(dict(x=x, n1=n1, rstd1=rstd1, qkv=qkv, attn=attn, lse=lse, x1=x1, n2=n2, rstd2=rstd2, gu=gu, h=h))
             x = x2                                     # (dkv_acc needs no zero-fill: the first step SETS the prefix rows)
-        self.prefix = dict(ids=[list(p) for p in prefix_ids], ids_np=ids, lens=lens, cu=cu_d, pos=pos_d, crow=crow_d, pos0=zero_pos0,
-                           Lmax=Lmax, Mp=Mp, layers=layers, steps=0, kv_steps=0, defer=defer, lens_dev=lens_d, recs=[], segments=0,
-                           lazy=bool(teacher_forced) and allm and defer)
-        self.stats = {"prefix_rows": Mp, "suffix_rows": [], "segments_flushed": 0, "recomputed_steps": 0}
+        P["layers"] = layers
+        P["pending"] = False
+        P["cache_valid"] = True
+
+    def _need_prefix_cache(self):
+        """a step that runs NOW (not deferred) reads the prefix's K/V from the per-layer cache: compute the prefix if it is still
+        pending, or -- it went through `_forward_lazy` with the in-place attention -- copy its K/V rows into the cache"""
+        P = self.prefix
+        if P.get("pending"):
+            self._prefix_forward()
+        elif not P.get("cache_valid", True):
+            for i in range(self.m.cfg.num_layers):
+                ops.scatter_rows_bf16_(self._E[i]["qkv"][:P["Mp"]], P["crow"], self.cache[i])
+            P["cache_valid"] = True
 
     def fits(self, ids_list):
         """can this step's prompts run over the cached prefix?  False: at least one prompt was LEFT-TRUNCATED by the tokenizer side
@@ -439,6 +488,7 @@ class PrefixEpisode:
                        lazy=True, targets=None, scale=None)
             P["recs"].append(rec)
             return rec
+        self._need_prefix_cache()          # (a step that runs now: the prefix's K/V must be in the cache)
         if self.mode == "all" and P["defer"] and torch.is_grad_enabled():
             # the LM sees a detached copy; the live tensor keeps this step's scene-encoder / fusion graph alive until finish()
             step["vis_live"] = vis_all
@@ -673,7 +723,11 @@ class PrefixEpisode:
         B, cap, H, hd, eps, L, d, ff = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers, cfg.hidden_size, \
             cfg.intermediate_size
         Mp, R = P["Mp"], self._cursor
-        rows = slice(Mp, R)
+        # round 5: a prefix that has not gone through the decoder yet (begin() of a teacher-forced episode only builds its tables) joins
+        # the batch: rows [0, R) instead of [Mp, R)
+        pend = bool(P.get("pending"))
+        r_lo = 0 if pend else Mp
+        rows = slice(r_lo, R)
         assert recs[0]["r0"] == Mp and recs[-1]["r0"] + recs[-1]["step"]["M"] == R
         with torch.no_grad():
             vis_parts, vix_parts, off = [], [], 0
@@ -685,13 +739,14 @@ class PrefixEpisode:
                 if nv:
                     vis_parts.append(v.detach())
                 off += nv
-            ids_cat = torch.cat([r["step"]["ids"] for r in recs])
-            pos_cat = torch.cat([r["step"]["pos"] for r in recs])
-            vix_cat = torch.cat(vix_parts)
+            ids_cat = torch.cat(([P["ids_dev"]] if pend else []) + [r["step"]["ids"] for r in recs])
+            pos_cat = torch.cat(([P["pos"]] if pend else []) + [r["step"]["pos"] for r in recs])
+            vix_cat = torch.cat(([P["vix_dev"]] if pend else []) + vix_parts)
             vis_cat = torch.cat(vis_parts, 0).contiguous() if vis_parts else None
             while len(self.lse_s) < len(recs):
                 self.lse_s.append([torch.zeros((B, H, cap), dtype=F32, device=m.device) for _ in range(L)])
-            last_cat = torch.cat([r["step"]["last"] + (r["r0"] - Mp) for r in recs])
+            last_cat = torch.cat([r["step"]["last"] + (r["r0"] - Mp) for r in recs])      # each step's last rows, relative to row Mp
+            last_x = last_cat + Mp if pend else last_cat                                   # ... relative to the first row of this batch
             prune_top = os.environ.get("NAVILLM_EPISODE_PRUNE_TOP", "1") != "0" and L > 1
             P.pop("top", None)
             # round 5: the attention of ALL steps in one launch per layer, reading the episode buffers in place (nv_attn_fwd_episode_bf16;
@@ -711,6 +766,12 @@ class PrefixEpisode:
                 E, E32 = self._E[i], self._E32[i]
                 n1, _ = ops.rmsnorm_fwd(x, w1, eps, out=E["n1"][rows], rstd=E32["r1"][rows])
                 ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, cap, 2 * H * hd, out=E["qkv"][rows], pos_i32=pos_cat)
+                if pend:
+                    # the prefix rows' own causal attention (the top layer's is never read: only its K/V are, by the steps' queries)
+                    if i < L - 1 or not prune_top:
+                        ops.attn_fwd_varlen(E["qkv"][:Mp], P["cu"], P["pos0"], B, P["Lmax"], H, hd, out=E["attn"][:Mp], lse2=P["layers"][i]["lse"])
+                    if not epi_fwd:
+                        ops.scatter_rows_bf16_(E["qkv"][:Mp], P["crow"], self.cache[i])
                 if epi_fwd:
                     ops.attn_fwd_episode(E["qkv"][:R], E["attn"][:R], f_lse[i], P["cu"], f_tab, T, B, H, hd, cap, f_nmax)
                 for r in (() if epi_fwd else recs):  # round 4 form: per step over the K/V cache (prefix rows + this step's rows)
@@ -725,8 +786,8 @@ class PrefixEpisode:
                     # the top layer feeds only each sample's LAST row of every step (nav_model.py:237) -- after its K/V projection and
                     # attention, o_proj / MLP run on those T*B rows instead of on every suffix row (what LlamaStack's pruned last layer
                     # does on the recompute path); the batched backward mirrors it (`top`)
-                    x_l = ops.gather_rows_bf16(x, last_cat)
-                    attn_l = ops.gather_rows_bf16(E["attn"][rows], last_cat)
+                    x_l = ops.gather_rows_bf16(x, last_x)
+                    attn_l = ops.gather_rows_bf16(E["attn"][rows], last_x)
                     x1_l = ops.gemm_bf16(ops.NT, attn_l, Wo, R=x_l, epilogue=ops.EPI_RESID)
                     n2_l, r2_l = ops.rmsnorm_fwd(x1_l, w2, eps)
                     gu_l = ops.gemm_bf16(ops.NT, n2_l, Wgu)
@@ -738,10 +799,13 @@ class PrefixEpisode:
                 n2, _ = ops.rmsnorm_fwd(x1, w2, eps, out=E["n2"][rows], rstd=E32["r2"][rows])
                 gu = ops.gemm_bf16(ops.NT, n2, Wgu, out=E["gu"][rows])
                 h = ops.swiglu_fwd(gu, out=E["h"][rows])
-                x = ops.gemm_bf16(ops.NT, h, Wd, out=self._E[i + 1]["x"][rows] if i + 1 < L else self._buf("lz.x2", (max(R, self._ecap) - Mp, d))[:R - Mp], R=x1,
+                x = ops.gemm_bf16(ops.NT, h, Wd, out=self._E[i + 1]["x"][rows] if i + 1 < L else self._buf("lz.x2", (max(R, self._ecap), d))[:R - r_lo], R=x1,
                                   epilogue=ops.EPI_RESID)
             if not (prune_top and "top" in P):
-                x_last = ops.gather_rows_bf16(x, last_cat)
+                x_last = ops.gather_rows_bf16(x, last_x)
+            if pend:
+                P["pending"] = False
+                P["cache_valid"] = not epi_fwd
             Hs_all, rstdf = ops.rmsnorm_fwd(x_last, st.p("lang_model.model.norm.weight"), eps)
         # action head + CE on every step (tiny: B rows each), through the same autograd functions the non-lazy path uses
         Hs_leaf = Hs_all.detach().requires_grad_(True)

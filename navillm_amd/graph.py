@@ -241,7 +241,12 @@ class NavCollator:
     reference's batch keys: gmap_step_ids [B,G] i64, gmap_pos_fts [B,G,7] f32, gmap_visited_masks / gmap_masks [B,G] bool,
     vp_pos_fts [B,Nv,14] f32; plus gmap_ids / vp_cand_ids (int32 node ids for `match_tables`), gmap_lens, no_vp_left."""
 
-    RING = 4
+    # staging buffers in the ring.  Round 5: 4 -> 32.  A slot is reused once the copy that read it has RUN, and that copy is ordered
+    # behind everything queued before it -- under teacher forcing the whole deferred backward of the previous episode (~270 ms at 7B):
+    # with 4 slots the host blocked on its 5th step of every episode until the GPU had drained (tools/episode_host_probe.py: step 4
+    # took 278 ms of host time), then the GPU idled while the host caught up -- 2-4 % of every episode.  32 slots (a few MB of pinned
+    # memory) let the host run five episodes ahead.
+    RING = 32
 
     def __init__(self, B, Nv, Gcap=128, angle_feat_size=4, enc_full_graph=True, pair_dists=False, pin=None):
         import torch

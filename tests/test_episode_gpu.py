@@ -400,7 +400,10 @@ def test_teacher_forced_episode_batches_the_forward_and_matches(size, monkeypatc
     rel = {g: tuple(round(((a[g] - b[g]).norm() / (b[g].norm() + 1e-20)).item(), 4) for a, b in ((g_tf, g_ps), (g_tf, g_ref), (g_sg, g_tf))) for g in g_ref}
     print(f"[teacher-forced {size}] logits, worst bf16 spacings: batched vs per-step forward {w_ps:.2f}, vs recompute {w_ref:.2f}, segmented vs one batch "
           f"{w_sg:.2f}; gradient rel err (vs per-step forward, vs recompute, segmented vs one batch): {rel}")
-    assert w_ps <= 2.0 and w_ref <= max_ulps and w_sg <= 2.0
+    # (round 5: the prefix joins the batch of whichever segment runs first, so the segmented and the one-batch run push the prefix rows
+    # through GEMMs of different row counts -- other split-K tails, other last bits: 2.25 spacings at 7B width where round 4, with the
+    # prefix computed on its own in both runs, measured <= 2.0)
+    assert w_ps <= 2.0 and w_ref <= max_ulps and w_sg <= (2.0 if size == "mid" else 3.0)
     for g, (a, b, c) in rel.items():
         assert a < 1.5e-2 and b < max_rel and c < 1.5e-2, (g, a, b, c)
     # the handle is all a rollout gets before finish_episode(): reading the logits early is an error, not a silent zero
