@@ -365,6 +365,12 @@ class PrefixEpisode:
             n1, rstd1 = ops.rmsnorm_fwd(x, w1, eps, out=t("n1", d), rstd=t("r1", 0, F32))
             qkv = ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, Lmax, 2 * H * hd, out=t("qkv", 3 * d), pos_i32=pos_d)
             ops.scatter_rows_bf16_(qkv, crow_d, self.cache[i])
+            if i == L - 1 and os.environ.get("NAVILLM_EPISODE_PRUNE_TOP", "1") != "0":
+                # round 5: the TOP layer's prefix rows feed nothing but their K/V (no head reads a prefix row, and the steps read a layer's
+                # K/V, i.e. its INPUT): attention, o_proj and the MLP of these rows were computed and never read -- the backward has
+                # always skipped them (`lo = Mp`)
+                layers.append(dict(x=x, n1=n1, rstd1=rstd1, qkv=qkv, attn=None, lse=None, x1=None, n2=None, rstd2=None, gu=None, h=None))
+                break
             attn = t("attn", d)
             lse = self._buf(f"p{i}.lse", (B, H, Lmax), F32)
             ops.attn_fwd_varlen(qkv, cu_d, zero_pos0, B, Lmax, H, hd, out=attn, lse2=lse)

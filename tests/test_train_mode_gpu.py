@@ -184,3 +184,57 @@ def test_training_panorama_draws_fresh_attention_masks_from_torchs_generator():
         torch.manual_seed(3)
         c = m("panorama", _pano_batch(zb))["pano_embeds"]
     assert torch.equal(a, c) and not torch.equal(a, b)
+
+
+def test_training_mode_scene_encoder_at_real_size_vs_oracle_forward_and_backward():
+    """the training-mode scene encoder at its REAL size (h = 1024, 16 heads x 64, ff = 4096, 36 ragged views, objects) against the oracle
+    (pinned in training mode by G14 at the fixture size): both consume the same randomly drawn masks at all eleven dropout sites --
+    forward values and the gradient of every encoder parameter, fp32 on both sides"""
+    from navillm_amd import config as nvcfg
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.params import synth_state_dict
+    from util import load_oracle
+    O = load_oracle()
+    cfg = nvcfg.tiny(precision="amp_bf16", enc_hidden_size=1024, enc_num_heads=16, enc_intermediate_size=4096, image_feat_size=768, obj_feat_size=768)
+    seed = 17
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=seed)
+    m.train()
+    P = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 else v) for k, v in synth_state_dict(cfg, seed).items()}
+    g = torch.Generator().manual_seed(4)
+    B, N, Ob = 4, 36, 6
+    lens, ol = torch.tensor([36, 29, 33, 21]), torch.tensor([6, 2, 4, 1])
+    x, loc = torch.randn(B, N, 768, generator=g), torch.randn(B, N, 7, generator=g)
+    of, olf = torch.randn(B, Ob, 768, generator=g), torch.randn(B, Ob, 7, generator=g)
+    nav = torch.zeros(B, N, dtype=torch.long)
+    for b, k in enumerate((5, 2, 8, 3)):
+        nav[b, :k] = 1
+        x[b, lens[b]:] = 0
+        loc[b, lens[b]:] = 0
+        of[b, ol[b]:] = 0
+        olf[b, ol[b]:] = 0
+    h, ff, heads = cfg.enc_hidden_size, cfg.enc_intermediate_size, cfg.enc_num_heads
+    shapes = {"drop_env.view": (B, N, 768), "drop_env.obj": (B, Ob, 768), "emb.drop": (B, N, h)}
+    for i in range(cfg.num_pano_layers):
+        shapes.update({f"l{i}.attn": (B, heads, N, N), f"l{i}.drop1": (B, N, h), f"l{i}.drop": (B, N, ff), f"l{i}.drop2": (B, N, h)})
+    dm = {k: (torch.rand(s, generator=g) >= (cfg.feat_dropout if k.startswith("drop_env") else cfg.enc_dropout)).float() for k, s in shapes.items()}
+    batch = dict(view_img_fts=x, view_lens=lens, loc_fts=loc, nav_types=nav, obj_img_fts=of, obj_lens=ol, obj_loc_fts=olf)
+    ref = O.panorama(P, cfg, batch, training=True, dmasks=dm)
+    G1, G2 = torch.randn(ref["pano_embeds"].shape, generator=g), torch.randn(ref["obj_embeds"].shape, generator=g)
+    ((ref["pano_embeds"] * G1).sum() + (ref["obj_embeds"] * G2).sum()).backward()
+    m.injected_dropout = {k: v.to(DEV) for k, v in dm.items()}
+    m.zero_grad()
+    out = m("panorama", {k: v.to(DEV) for k, v in batch.items()})
+    e_p, e_o = maxerr(out["pano_embeds"], ref["pano_embeds"].detach()), maxerr(out["obj_embeds"], ref["obj_embeds"].detach())
+    ((out["pano_embeds"] * G1.to(DEV)).sum() + (out["obj_embeds"] * G2.to(DEV)).sum()).backward()
+    torch.cuda.synchronize()
+    worst, n = 0.0, 0
+    for name, p in P.items():
+        if p.dtype != torch.float32 or p.grad is None or not name.startswith("img_embeddings."):
+            continue
+        gh, gr = m.store.g(name).float().cpu(), p.grad
+        rel = ((gh - gr).norm() / (gr.norm() + 1e-20)).item()
+        worst, n = max(worst, rel), n + 1
+        assert rel < 2e-4, (name, rel)
+    print(f"[train-mode encoder, real size] max|pano - oracle| = {e_p:.2e} (scale {ref['pano_embeds'].abs().max().item():.2f}), max|obj - oracle| = {e_o:.2e}; "
+          f"worst gradient rel err over {n} encoder tensors {worst:.2e}")
+    assert e_p < 3e-5 and e_o < 3e-5 and n >= 30
