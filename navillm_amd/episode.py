@@ -878,6 +878,11 @@ class PrefixEpisode:
         if not live and not (final and seg_before):
             return
         with torch.no_grad():
+            # round 5: nothing has written a decoder-layer gradient since zero_grad() (FlatStore.layers_zero) -> the weight-gradient GEMMs of this walk
+            # are the first writers of their buffers and STORE: `0 + bf16(dW)` without reading 13.5 GB of zeros (each of the four
+            # matrices of a layer is written exactly once per walk).  Later segments of a long episode / a second accumulation read-add.
+            wacc = ops.EPI_STORE if (getattr(st, "layers_zero", False) and seg_before == 0
+                                     and os.environ.get("NAVILLM_WGRAD_STORE", "1") != "0") else ops.EPI_ACCUM
             st.touch_layers()
             dp0 = getattr(m, "_dp", None)
             if dp0 is not None and final:
@@ -931,26 +936,26 @@ class PrefixEpisode:
                     # the pruned tail's backward on the T*B last rows; what flows on into the attention output / the residual stream is
                     # zero everywhere else
                     dh_l = ops.gemm_bf16(ops.NN, dxl, Wd)
-                    ops.gemm_bf16(ops.TN, dxl, top["h"], out=gd, epilogue=ops.EPI_ACCUM)
+                    ops.gemm_bf16(ops.TN, dxl, top["h"], out=gd, epilogue=wacc)
                     dgu_l = ops.swiglu_bwd(top["gu"], dh_l)
                     dn_l = ops.gemm_bf16(ops.NN, dgu_l, Wgu)
-                    ops.gemm_bf16(ops.TN, dgu_l, top["n2"], out=ggu, epilogue=ops.EPI_ACCUM)
+                    ops.gemm_bf16(ops.TN, dgu_l, top["n2"], out=ggu, epilogue=wacc)
                     dx1_l = ops.rmsnorm_bwd(dn_l, top["x1"], w2, top["r2"], gw2, resid_grad=dxl)
                     dattn_l = ops.gemm_bf16(ops.NN, dx1_l, Wo)
-                    ops.gemm_bf16(ops.TN, dx1_l, top["attn"], out=go, epilogue=ops.EPI_ACCUM)
+                    ops.gemm_bf16(ops.TN, dx1_l, top["attn"], out=go, epilogue=wacc)
                     dattn[Mp:].zero_()
                     dx1[Mp:].zero_()
                     ops.scatter_rows_bf16_(dattn_l, top["idx"], dattn[Mp:])
                     ops.scatter_rows_bf16_(dx1_l, top["idx"], dx1[Mp:])
                 elif R > lo:
                     ops.gemm_bf16(ops.NN, dx[lo:], Wd, out=dh[lo:])
-                    ops.gemm_bf16(ops.TN, dx[lo:], E["h"][lo:R], out=gd, epilogue=ops.EPI_ACCUM)
+                    ops.gemm_bf16(ops.TN, dx[lo:], E["h"][lo:R], out=gd, epilogue=wacc)
                     ops.swiglu_bwd(E["gu"][lo:R], dh[lo:], out=dgu[lo:])
                     ops.gemm_bf16(ops.NN, dgu[lo:], Wgu, out=dn[lo:])
-                    ops.gemm_bf16(ops.TN, dgu[lo:], E["n2"][lo:R], out=ggu, epilogue=ops.EPI_ACCUM)
+                    ops.gemm_bf16(ops.TN, dgu[lo:], E["n2"][lo:R], out=ggu, epilogue=wacc)
                     ops.rmsnorm_bwd(dn[lo:], E["x1"][lo:R], w2, E32["r2"][lo:R], gw2, resid_grad=dx[lo:], out=dx1[lo:])
                     ops.gemm_bf16(ops.NN, dx1[lo:], Wo, out=dattn[lo:])
-                    ops.gemm_bf16(ops.TN, dx1[lo:], E["attn"][lo:R], out=go, epilogue=ops.EPI_ACCUM)
+                    ops.gemm_bf16(ops.TN, dx1[lo:], E["attn"][lo:R], out=go, epilogue=wacc)
                 # attention backward.  The prefix rows' own causal attention (packed rows) ...
                 if final:
                     if lo == 0:
@@ -976,7 +981,7 @@ class PrefixEpisode:
                     q0 = Mp
                 if R > q0:
                     ops.gemm_bf16(ops.NN, dqkv[q0:], Wqkv, out=dn[q0:])
-                    ops.gemm_bf16(ops.TN, dqkv[q0:], E["n1"][q0:R], out=gqkv, epilogue=ops.EPI_ACCUM)
+                    ops.gemm_bf16(ops.TN, dqkv[q0:], E["n1"][q0:R], out=gqkv, epilogue=wacc)
                     ops.rmsnorm_bwd(dn[q0:], E["x"][q0:R], w1, E32["r1"][q0:R], gw1, resid_grad=dx1[q0:], out=other[q0:])
                 dx, other = other, dx
                 if final:

@@ -43,6 +43,8 @@ class FlatStore:
         self.offsets = {}
         self.sizes = {}
         self.alloc_sizes = {}     # size incl. alignment padding: offsets[n] + alloc_sizes[n] == offset of the next tensor
+        self.layers_zero = False  # True from a zero_grad() (the buffers hold zeros) until a backward writes DECODER-LAYER gradients: the first
+                                  # writer may then STORE instead of read-accumulate (navillm_amd/episode.py: the episode's wgrad GEMMs)
         self.grad_writes = 0      # bumped whenever a backward writes (or is about to write) into .grad -- see FlatAdamW.zero_grad
         self.tainted = None       # set by NavModel.episode_abort() when the aborted episode had already written PART of its gradients
         self.touched = set()      # names that have received a gradient at least once (navillm_amd/optim.py: which tensors AdamW updates)
@@ -129,11 +131,14 @@ class FlatStore:
 
     # ---- "this tensor has a gradient now" (torch: p.grad is no longer None); reported by the backward functions
     def touch(self, *names):
+        if self.layers_zero and any(n.startswith("lang_model.model.layers.") for n in names):
+            self.layers_zero = False
         self.grad_writes += 1           # a gradient was (or is about to be) written: FlatAdamW's fused zero-grad bookkeeping is stale
         self.touched.update(names)
 
     def touch_layers(self):
         """every decoder-layer tensor + the final norm (LlamaStack.backward accumulates into all of them)"""
+        self.layers_zero = False
         self.grad_writes += 1
         if "lang_model.model.norm.weight" not in self.touched:
             self.touched.update(n for n in self.names["lm"] if n.startswith("lang_model.model.layers.") or n == "lang_model.model.norm.weight")
@@ -143,6 +148,7 @@ class FlatStore:
         if self.grad is not None:
             for g in self.grad.values():
                 g.zero_()
+            self.layers_zero = True
 
     def release_decoder_layers_and_grads(self, named_params):
         """Inference deployment with weight-only fp8 decoder weights (navillm_amd/fp8.py): drop the bf16 copies of the decoder's

@@ -463,6 +463,9 @@ class LlamaStack(torch.autograd.Function):
 
         H, hd, L = cfg.num_heads, cfg.head_dim, cfg.num_layers
         sc = {k: v[:M] for k, v in ar.scratch.items()}
+        # round 5: the first backward after a zero_grad() (FlatStore.layers_zero) STORES its weight gradients -- every matrix is written
+        # exactly once per backward -- instead of read-accumulating zeros; every later backward of the optimizer step read-adds
+        WACC = ops.EPI_STORE if (getattr(st, "layers_zero", False) and os.environ.get("NAVILLM_WGRAD_STORE", "1") != "0") else ops.EPI_ACCUM
         st.touch_layers()
         model._dp_begin_backward()
         L_full = L
@@ -479,14 +482,14 @@ class LlamaStack(torch.autograd.Function):
             dx2_r = ops.rmsnorm_bwd(_c(dH), x2_r, st.p("lang_model.model.norm.weight"), ctx.rstdf,
                                     st.g("lang_model.model.norm.weight"))
             dh_r = ops.gemm_bf16(ops.NN, dx2_r, st.p(p + "mlp.down_proj.weight"))
-            ops.gemm_bf16(ops.TN, dx2_r, h_r, out=st.g(p + "mlp.down_proj.weight"), epilogue=ops.EPI_ACCUM)
+            ops.gemm_bf16(ops.TN, dx2_r, h_r, out=st.g(p + "mlp.down_proj.weight"), epilogue=WACC)
             dgu_r = ops.swiglu_bwd(gu_r, dh_r)
             dn2_r = ops.gemm_bf16(ops.NN, dgu_r, st.gate_up(i))
-            ops.gemm_bf16(ops.TN, dgu_r, n2_r, out=st.gate_up(i, grad=True), epilogue=ops.EPI_ACCUM)
+            ops.gemm_bf16(ops.TN, dgu_r, n2_r, out=st.gate_up(i, grad=True), epilogue=WACC)
             dx1_r = ops.rmsnorm_bwd(dn2_r, x1_r, st.p(p + "post_attention_layernorm.weight"), rstd2_r,
                                     st.g(p + "post_attention_layernorm.weight"), resid_grad=dx2_r)
             dattn_r = ops.gemm_bf16(ops.NN, dx1_r, st.p(p + "self_attn.o_proj.weight"))
-            ops.gemm_bf16(ops.TN, dx1_r, attn_r, out=st.g(p + "self_attn.o_proj.weight"), epilogue=ops.EPI_ACCUM)
+            ops.gemm_bf16(ops.TN, dx1_r, attn_r, out=st.g(p + "self_attn.o_proj.weight"), epilogue=WACC)
             dattn = sc["dattn"]
             dattn.zero_()
             ops.scatter_rows_bf16_(dattn_r, rows, dattn)
@@ -494,7 +497,7 @@ class LlamaStack(torch.autograd.Function):
             dqkv.zero_()                       # dQ rows below qmin are not written by the kernel
             attention_bwd(qkv, attn, dattn, lse, dqkv, qmin)
             dn1 = ops.gemm_bf16(ops.NN, dqkv, st.qkv(i), out=sc["dn1"])
-            ops.gemm_bf16(ops.TN, dqkv, n1, out=st.qkv(i, grad=True), epilogue=ops.EPI_ACCUM)
+            ops.gemm_bf16(ops.TN, dqkv, n1, out=st.qkv(i, grad=True), epilogue=WACC)
             resid = sc["dx1"]
             resid.zero_()
             ops.scatter_rows_bf16_(dx1_r, rows, resid)
@@ -532,12 +535,12 @@ class LlamaStack(torch.autograd.Function):
 
         def wgrad(dy_name, dy, act, gout, pre=None):
             if side is None:
-                ops.gemm_bf16(ops.TN, dy, act, out=gout, epilogue=ops.EPI_ACCUM)
+                ops.gemm_bf16(ops.TN, dy, act, out=gout, epilogue=WACC)
                 return None
             if pair:
                 side.wait_event(pre)
                 with torch.cuda.stream(side):
-                    ops.gemm_bf16(ops.TN, dy, act, out=gout, epilogue=ops.EPI_ACCUM)
+                    ops.gemm_bf16(ops.TN, dy, act, out=gout, epilogue=WACC)
                     done = torch.cuda.Event()
                     done.record(side)
                 main.wait_event(done)                          # the chain's next kernel starts after BOTH GEMMs
@@ -546,7 +549,7 @@ class LlamaStack(torch.autograd.Function):
             e.record(main)
             side.wait_event(e)
             with torch.cuda.stream(side):
-                ops.gemm_bf16(ops.TN, dy, act, out=gout, epilogue=ops.EPI_ACCUM)
+                ops.gemm_bf16(ops.TN, dy, act, out=gout, epilogue=WACC)
                 done = torch.cuda.Event()
                 done.record(side)
             last_read[dy_name] = done

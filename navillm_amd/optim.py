@@ -224,6 +224,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 pos = max(pos, e)
             if pos < g.numel():
                 g[pos:].zero_()
+        self.store.layers_zero = True          # every element is zero now: step() zeroed the updated segments, the gaps were filled here
 
     def state_dict(self):
         """flat-layout state (copies); not a torch.optim.AdamW state dict"""

@@ -457,3 +457,40 @@ def test_episode_forward_attention_one_launch_equals_the_per_step_cache_form(siz
         assert torch.equal(l_seg_new[t], l_seg_old[t]), f"segmented, step {t}"
     for g in g_old:
         assert torch.equal(g_seg_new[g], g_seg_old[g]), ("segmented", g)
+
+
+def test_first_writer_wgrad_store_equals_accumulate_into_zeros(monkeypatch):
+    """round 5: when nothing has written a decoder-layer gradient since zero_grad() (`FlatStore.layers_zero`), the batched backward's
+    weight-gradient GEMMs STORE instead of read-accumulating 13.5 GB of zeros: bit-identical; and a SECOND episode accumulated on top
+    (no zero_grad in between) read-adds as before"""
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step
+    from navillm_amd.losses import CrossEntropyLoss
+    cfg = _mid_cfg()
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
+    m.eval()
+    res = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("NAVILLM_WGRAD_STORE", form)
+        _, g1, _ = _episode(m, cfg, 4, use_prefix=True, teacher_forced=True)       # (zero_grad inside: first writer)
+        # a second episode on top of the first one's gradients: must ADD
+        ep = SyntheticEpisodes(cfg, 3, seed=77, instr_len=120, device=torch.device(DEV))
+        m.begin_episode(ep.prefix_ids(), teacher_forced=True)
+        for t in range(3):
+            torch.manual_seed(900 + t)
+            nav_step(m, CrossEntropyLoss(), ep, train=True, last=(t == 2))
+        assert not m.store.layers_zero
+        m.finish_episode()
+        torch.cuda.synchronize()
+        res[form] = (g1, {g: t.detach().float().clone() for g, t in m.store.grad.items()})
+    # the per-step recompute path (LlamaStack.backward): the first backward after zero_grad() stores, the later ones read-add
+    rc = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("NAVILLM_WGRAD_STORE", form)
+        _, rc[form], _ = _episode(m, cfg, 3, use_prefix=False)
+    for g in rc["0"]:
+        assert torch.equal(rc["1"][g], rc["0"][g]), ("recompute", g)
+    for g in res["0"][0]:
+        assert torch.equal(res["1"][0][g], res["0"][0][g]), ("first episode", g)
+        assert torch.equal(res["1"][1][g], res["0"][1][g]), ("accumulated second episode", g)
+        assert not torch.equal(res["1"][1][g], res["1"][0][g])
