@@ -69,6 +69,7 @@ def test_dp_wrapper_world1_matches_plain_run(transport, reduce, algo, monkeypatc
     assert (ddp.comm is None) == (transport == "torch")
     # the back-reference must not register the wrapper as a child of the model it wraps
     ddp.train(); model.train(); model.state_dict(); ddp.state_dict()
+    ddp.profile = True                           # round 5: HIP events around every slice's collective and around the join (bench.py `dp.exchange`)
     got = _step(model, ddp, 17, final=not flush)
     if flush:
         assert ddp._pending                      # nothing exchanged yet: the optimizer's flush does it, once
@@ -77,6 +78,12 @@ def test_dp_wrapper_world1_matches_plain_run(transport, reduce, algo, monkeypatc
         torch.cuda.synchronize()
         got = {k: v.clone() for k, v in model.store.grad.items()}
     assert not ddp._pending
+    xs = ddp.exchange_stats()
+    n_slices = model.cfg.num_layers + 3          # one per decoder layer + embeddings | norm + heads | the fp32 group
+    total_bytes = sum(t.numel() * t.element_size() for t in ddp.slices.all_slices())
+    assert xs is not None and xs["exchanges"] == 1 and xs["slices_per_exchange"] == n_slices and xs["bytes_per_exchange"] == total_bytes, xs
+    assert xs["collective_busy_ms_per_exchange"] > 0 and xs["exposed_ms_per_exchange"] >= 0, xs
+    assert ddp.exchange_stats() is None          # (reset)
     object.__setattr__(model, "_dp", None)
     for k in base:
         assert torch.equal(base[k], got[k]), f"{transport}/{reduce}/{algo}: gradient buffer {k} differs from the plain run"
