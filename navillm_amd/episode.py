@@ -315,12 +315,13 @@ class PrefixEpisode:
         # round 5: in a teacher-forced episode the PREFIX's forward is deferred too -- `_forward_lazy` pushes the prefix rows and all the
         # steps' rows through the decoder as ONE batch (~8 300 rows per GEMM instead of 4 272 + ~4 200: the forward layout runs 7 % faster
         # at that size, profiles/r05_gemm_vs_blaslt.txt, and every row kernel / GEMM of the forward is launched once instead of twice);
-        # only the index tables are built here.  NAVILLM_EPISODE_LAZY_PREFIX: 0 = the prefix forward runs now, as in round 4; 1 = always
-        # deferred; auto (default) = deferred while the GPU still has queued work (the host is ahead: steady state of a training run),
-        # run NOW when the stream is empty (first episode, or right after a synchronisation): an idle GPU is better off with 45 ms of
-        # prefix forward under the host's preparation of the six steps than with nothing (profiles/r05_episode_gaps_lazy*.txt: the
-        # first episode after a sync idles 30 ms with the prefix deferred, 16 ms without)
-        lz = os.environ.get("NAVILLM_EPISODE_LAZY_PREFIX", "auto")
+        # only the index tables are built here.  NAVILLM_EPISODE_LAZY_PREFIX: 1 (default) = always deferred; 0 = the prefix forward runs
+        # now, as in round 4; auto = deferred while the GPU still has queued work, run NOW when the stream is empty (first episode, right
+        # after a synchronisation: an idle GPU then gets 45 ms of prefix forward under the host's preparation of the six steps --
+        # profiles/r05_episode_gaps_lazy*.txt: the first episode after a sync idles 30 ms with the prefix deferred, 16 ms without).
+        # `auto` is NOT the default: which GEMM shapes an episode runs -- hence the last bits of its gradients -- would depend on GPU
+        # timing, and in the driver's 20-step window it measured the same as 1 (ABAB 136.4-137.1 vs 136.4-137.2 nav-steps/s)
+        lz = os.environ.get("NAVILLM_EPISODE_LAZY_PREFIX", "1")
         pending = lazy and lz != "0"
         if pending and lz == "auto" and dev.type == "cuda" and torch.cuda.current_stream(dev).query():
             pending = False
