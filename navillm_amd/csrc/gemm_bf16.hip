@@ -60,6 +60,7 @@ struct GemmArgs {
     const int* rope_pos;    // optional: position of row m (packed rows); nullptr -> m % rope_S
     // weight-only fp8 B operand (PIPE 7 / 8, nv_gemm_fp8w): B = e4m3fn codes [N][K] (ldb in bytes), one fp32 scale per output channel n
     const float* b_scales;
+    int epi_preload;        // 1 (default): the reading epilogues issue their global loads eight passes ahead (NV_GEMM_EPI_PRELOAD=0: one pass at a time)
     int fp8_epi;            // PIPE 8 only: 1 = the codes are converted unscaled and s[n] multiplies the fp32 accumulator in the epilogue
 };
 
@@ -1029,6 +1030,76 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& p, const int item, con
         if (n < p.N) {
             // rows of the band: fragment rows [j_lo*WGM, j_hi*WGM) of the tile (interleaved wave rows) = a contiguous row range
             const int pass_lo = IL ? (j_lo * WGM * 16) / ROWS_PER_PASS : 0, pass_hi = IL ? (j_hi * WGM * 16) / ROWS_PER_PASS : BM_EFF / ROWS_PER_PASS;
+            // Round 5: the epilogues that READ global memory per C row -- the residual / the gradient being accumulated into, the RoPE
+            // position and its cos / sin rows -- issue those loads for EIGHT passes up front and only then walk the passes.  C, R and
+            // the tables are plain pointers of one struct: hipcc has to assume that a store to C may alias the next pass's load, so the
+            // one-pass-at-a-time loop below paid a full memory latency per pass (measured through the accumulate epilogue: the same
+            // weight-gradient GEMMs ran 1 249 TF accumulating into zeros and 1 320 TF storing; in the forward, the plain-store gate|up
+            // GEMM 1 403 TF against 1 240 / 1 267 for the residual / RoPE ones).  Same arithmetic, same order per element.
+            if constexpr (EPI == EPI_ACCUM || EPI == EPI_RESID || EPI == EPI_ROPE) if (p.epi_preload) {
+                constexpr int CH = 8;
+                const bool roped = (EPI == EPI_ROPE) && (n < p.rope_cols);
+                const int c = n & 127;                                 // (RoPE) 8 columns c .. c+7 inside one half of a head
+                const bool lo = c < 64;
+                const int pc16 = (c16 + (lo ? 8 : -8));                 // partner 16-B slot (64 columns away)
+                const float sgn = lo ? -1.f : 1.f;
+                for (int p0 = pass_lo; p0 < pass_hi; p0 += CH) {
+                    u32x4 ra[CH], rb[CH];
+                    if (EPI == EPI_ROPE) {
+                        if (roped) {
+                            int posq[CH];
+#pragma unroll
+                            for (int q = 0; q < CH; ++q) {
+                                const int m = m0 + (p0 + q) * ROWS_PER_PASS + r_in;
+                                const bool ok = (p0 + q < pass_hi) && (m < p.M);
+                                posq[q] = ok ? (p.rope_pos ? p.rope_pos[m] : m % p.rope_S) : 0;
+                            }
+#pragma unroll
+                            for (int q = 0; q < CH; ++q) {
+                                ra[q] = *(const u32x4*)(p.R + (long)posq[q] * 128 + (c & 63));
+                                rb[q] = *(const u32x4*)(p.rope_sin + (long)posq[q] * 128 + (c & 63));
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < CH; ++q) {
+                            const int m = m0 + (p0 + q) * ROWS_PER_PASS + r_in;
+                            if ((p0 + q < pass_hi) && (m < p.M))
+                                ra[q] = *(const u32x4*)((EPI == EPI_ACCUM) ? p.C + (long)m * p.ldc + n : p.R + (long)m * p.ldr + n);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        const int pass = p0 + q;
+                        const int ml = pass * ROWS_PER_PASS + r_in, m = m0 + ml;
+                        if (pass >= pass_hi || m >= p.M) break;
+                        u32x4 t = *(LDS_PTR(u32x4))(smem + ml * (BN * 2) + ((c16 ^ (ml & 15)) << 4));
+                        bf16_t* cp = p.C + (long)m * p.ldc + n;
+                        if (EPI == EPI_ROPE) {
+                            // head_dim 128, rotate-half: column c of a head pairs with c +- 64 -- the same row of the LDS image
+                            // (a 256-wide tile holds two whole heads).  Arithmetic = rope_kernel (lm_rowops.hip), bit for bit.
+                            if (roped) {
+                                const u32x4 pr = *(LDS_PTR(u32x4))(smem + ml * (BN * 2) + ((pc16 ^ (ml & 15)) << 4));
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float x0 = __uint_as_float(t[e] << 16), x1 = __uint_as_float(t[e] & 0xffff0000u);
+                                    const float y0 = __uint_as_float(pr[e] << 16), y1 = __uint_as_float(pr[e] & 0xffff0000u);
+                                    const float c0 = __uint_as_float(ra[q][e] << 16), c1 = __uint_as_float(ra[q][e] & 0xffff0000u);
+                                    const float s0 = __uint_as_float(rb[q][e] << 16), s1 = __uint_as_float(rb[q][e] & 0xffff0000u);
+                                    t[e] = pack2bf(rbf(x0 * c0) + rbf(sgn * y0 * s0), rbf(x1 * c1) + rbf(sgn * y1 * s1));
+                                }
+                            }
+                        } else {                                       // torch: out = resid + bf16(acc)  /  grad += bf16(dW)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                t[e] = pack2bf(__uint_as_float(ra[q][e] << 16) + __uint_as_float(t[e] << 16),
+                                               __uint_as_float(ra[q][e] & 0xffff0000u) + __uint_as_float(t[e] & 0xffff0000u));
+                        }
+                        store_c(cp, t, p.c_nt);
+                    }
+                }
+                return;
+            }
 #pragma unroll 4
             for (int pass = pass_lo; pass < pass_hi; ++pass) {
                 const int ml = pass * ROWS_PER_PASS + r_in, m = m0 + ml;
@@ -1394,6 +1465,8 @@ static int gemm_entry(int layout, const void* A, const void* B, void* C, const v
         p.persist = env_persist;
         static const int env_band = [] { const char* e = getenv("NV_GEMM_BAND_REDUCE"); return e ? atoi(e) : 1; }();
         p.band_reduce = env_band;
+        static const int env_pre = [] { const char* e = getenv("NV_GEMM_EPI_PRELOAD"); return e ? atoi(e) : 1; }();
+        p.epi_preload = env_pre;
         static const int env_cst = [] { const char* e = getenv("NV_GEMM_C_STORE"); return e ? atoi(e) : 1; }();   // nt: +0.3 % on the step (ABAB: 43.40 / 43.50 / 43.41 / 43.57)
         p.c_nt = env_cst;
         p.group_m = env_group < 1 ? 1 : env_group;
@@ -1469,7 +1542,7 @@ extern "C" int nv_gemm_fp8w(const void* A, const void* codes, const float* scale
     p.slabs = workspace ? (float*)((char*)workspace + 4096) : nullptr;
     p.full_blocks = 0; p.rem = 1; p.split = 1;
     p.rope_sin = nullptr; p.rope_S = 1; p.rope_cols = 0; p.rope_pos = nullptr;
-    p.debug = 0; p.persist = 0; p.band_reduce = 1; p.c_nt = 1; p.group_m = 4;
+    p.debug = 0; p.persist = 0; p.band_reduce = 1; p.c_nt = 1; p.group_m = 4; p.epi_preload = 1;
     p.col_strips = (long)N > (long)M ? 1 : 0;
     p.b_scales = scales; p.fp8_epi = mode == 9 ? 1 : 0;
     p.a_bytes = span_bytes(M, K, lda);
