@@ -431,22 +431,23 @@ def reference_launch_extra(a, cfg, model, opt, crit, device, seed):
     """The reference's own launch line (scripts/multi_wo_pretrain.sh:16: `--batch_size 1 --gradient_accumulation_step 8`, one rank of
     its 8): B = 1 episode per meta-step, the loss scaled by 1 / B / 8, `clip + AdamW + zero_grad` every 8th episode (train.py:68,86-89).
     Every GEMM of a step then has M ~ 650 (recompute) / ~100 (suffix steps) / ~1 150 (a teacher-forced episode's batched backward)
-    rows instead of 8 x that -- the regime the cut-off tiles exist for.  Measured for the three training forms, each over ONE whole
-    accumulation window (8 episodes x 6 steps = 48 nav steps + 1 optimizer step) after a warm window, with the GEMM roofline of the
-    window.  NOT `value`: BASELINE config 2 is B = 8.  The same 8 episodes as ONE batch (`--batch_size 8 --gradient_accumulation_step
+    rows instead of 8 x that -- the regime the cut-off tiles exist for.  Measured for the four training forms, each over FOUR consecutive whole
+    accumulation windows (8 episodes x 6 steps = 48 nav steps + 1 optimizer step each) after a warm window, with the GEMM roofline of
+    the timed region.  NOT `value`: BASELINE config 2 is B = 8.  The same 8 episodes as ONE batch (`--batch_size 8 --gradient_accumulation_step
     1`: same loss scale 1/8, same gradient -- tests/test_parity_r5_gpu.py) is the headline line above."""
     from navillm_amd import ops
     from navillm_amd.synthetic import SyntheticEpisodes, nav_step
     ACC = 8
     ep1 = SyntheticEpisodes(cfg, 1, seed=seed, instr_len=a.instr_len, device=device)
     out = {"batch_per_gpu": 1, "gradient_accumulation_step": ACC, "steps_per_window": ACC * STEPS_PER_EPISODE,
-           "what": "scripts/multi_wo_pretrain.sh:16 on one rank: 8 episodes of B = 1, 6 nav steps each, loss / 1 / 8, one clip + AdamW per window"}
+           "windows_timed": 4, "what": "scripts/multi_wo_pretrain.sh:16 on one rank: 8 episodes of B = 1, 6 nav steps each, loss / 1 / 8, one clip + AdamW per window"}
 
     def window(form):
         for e in range(ACC):
             ep1.reset()
             if form != "recompute":
-                model.begin_episode(ep1.prefix_ids(), teacher_forced=(form == "prefix_reuse_teacher_forced"))
+                model.begin_episode(ep1.prefix_ids(), teacher_forced=form.startswith("prefix_reuse_teacher_forced"),
+                                    accumulate=ACC if form.endswith("_window") else 1)
             for t in range(STEPS_PER_EPISODE):
                 nav_step(model, crit, ep1, train=True, last=(t == STEPS_PER_EPISODE - 1), accum=ACC)
             if form != "recompute":
@@ -455,18 +456,22 @@ def reference_launch_extra(a, cfg, model, opt, crit, device, seed):
         opt.step()
         opt.zero_grad()
 
-    for form in ("recompute", "prefix_reuse", "prefix_reuse_teacher_forced"):
+    # `..._window` (round 5): begin_episode(..., accumulate=8) -- the eight teacher-forced episodes of the window run as ONE batch at the
+    # eighth finish_episode(): the rows of a B = 8 episode, on the reference's own launch line
+    for form in ("recompute", "prefix_reuse", "prefix_reuse_teacher_forced", "prefix_reuse_teacher_forced_window"):
         try:
             model.episode_abort()
             model.zero_grad()
             window(form)                                   # warm: buffers sized, kernels' attributes set
             best = None
-            for rep in range(2):                           # two timed windows, the faster one reported (the first one after a form
-                tm = GemmTimer()                           # change now and then still meets the allocator: 59 vs 76 nav-steps/s seen)
-                tm.install(ops)
+            NW = 4                                         # consecutive windows per timed region: the host prepares window k + 1 while
+            for rep in range(2):                           # the GPU runs window k, as in a training run (the windowed form does ALL its GPU
+                tm = GemmTimer()                           # work at the window's end).  Two regions, the faster one reported (the first one
+                tm.install(ops)                            # after a form change now and then still meets the allocator: 59 vs 76 seen)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                window(form)
+                for _ in range(NW):
+                    window(form)
                 torch.cuda.synchronize()
                 dt_ = time.perf_counter() - t0
                 tm.uninstall()
@@ -474,7 +479,7 @@ def reference_launch_extra(a, cfg, model, opt, crit, device, seed):
                     best = (dt_, tm)
             dt, tm = best
             g = tm.summary(layouts=(0, 1, 2))
-            n = ACC * STEPS_PER_EPISODE
+            n = NW * ACC * STEPS_PER_EPISODE
             out[form] = {"nav_steps_per_s_per_gpu": round(n / dt, 2), "ms_per_step": round(dt / n * 1e3, 2),
                          "roofline": None if g is None else {
                              "bound": "mfma", "achieved": round(g["tflops"], 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -485,7 +490,7 @@ def reference_launch_extra(a, cfg, model, opt, crit, device, seed):
     model.episode_abort()
     model.zero_grad()
     model.episode_release()
-    model.episode = None                                   # the B = 1 caches: the next begin_episode() builds its own
+    model.episode = model._window = model._episode_plain = None      # the B = 1 caches: the next begin_episode() builds its own
     return out
 
 

@@ -95,9 +95,13 @@ class _SuffixLM(torch.autograd.Function):
 
 
 class PrefixEpisode:
-    def __init__(self, model, batch_size, capacity=1024, max_length=1024):
+    def __init__(self, model, batch_size, capacity=1024, max_length=1024, samples_per_episode=None):
         cfg = model.cfg
         self.m, self.B, self.cap = model, batch_size, capacity
+        # round 5, accumulation window (`begin(..., window=True)`): `batch_size` prefix slots hold the samples of SEVERAL successive
+        # episodes of `samples_per_episode` prompts each -- see `_begin_window`
+        self.Bs = int(samples_per_episode or batch_size)
+        assert self.B % self.Bs == 0
         # the tokenizer's `max_length` (modified_lm.py:57,77-87: left truncation at 1024): a prompt that reaches it was cut from the LEFT
         # and no longer starts with the episode's prefix -- independent of how many rows per sample the K/V cache holds
         self.max_length = int(max_length)
@@ -266,9 +270,14 @@ class PrefixEpisode:
 
     # ------------------------------------------------------------------ prefix forward, once per episode
     @torch.no_grad()
-    def begin(self, prefix_ids, teacher_forced=False):
+    def begin(self, prefix_ids, teacher_forced=False, window=False):
         """prefix_ids: B python lists of token ids (no visual tokens) -- the part of every prompt of this episode that never changes.
-        teacher_forced (round 4; mode "all" only): the steps' LM FORWARD is deferred to finish() too -- see `_forward_lazy`."""
+        teacher_forced (round 4; mode "all" only): the steps' LM FORWARD is deferred to finish() too -- see `_forward_lazy`.
+        window (round 5; teacher-forced only): the episode joins the open accumulation window -- see `_begin_window`."""
+        if window:
+            assert teacher_forced, "an accumulation window batches teacher-forced episodes only"
+            return self._begin_window(prefix_ids)
+        assert self.Bs == self.B, "this PrefixEpisode was built for accumulation windows"
         m, cfg, st = self.m, self.m.cfg, self.m.store
         B, cap, H, hd, eps, L = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers
         self.assert_no_pending_gradients("begin_episode()")
@@ -334,6 +343,121 @@ class PrefixEpisode:
             self.prefix["layers"] = [dict(lse=self._buf(f"p{i}.lse", (B, H, Lmax), F32)) for i in range(L)]
             return
         self._prefix_forward()
+
+    # ------------------------------------------------------------------ accumulation window (round 5)
+    # The reference's launch line is `--batch_size 1 --gradient_accumulation_step 8` (scripts/multi_wo_pretrain.sh:16): eight episodes
+    # of ONE prompt each between two optimizer steps (train.py:68,86-89).  The weights are frozen for the whole window and nothing reads
+    # `.grad` inside it, so -- exactly as the steps of one episode are batched -- the teacher-forced episodes of a window can be
+    # batched with one another: every `begin()` adds its samples to the window's prefix slots, every step only RESERVES its rows,
+    # `finish()` of the first n - 1 episodes returns at once, and the n-th (or anything that needs the gradients: the optimizer's clip /
+    # step, `model.parameters()`, a non-windowed `begin_episode`) pushes ALL prefixes and ALL steps of the window through the decoder as
+    # one batch: forward, heads + losses, batched backward -- the GEMMs of a B = 1 launch line then see the rows of a B = 8 episode.
+    # The kernels do not change: sample slot b of the window is sample b - sb of its episode, and table-step k of the one-launch
+    # attention kernels is the k-th step of EVERY episode (a shorter episode has 0 rows there).
+    def _begin_window(self, prefix_ids):
+        m, cfg = self.m, self.m.cfg
+        Bs, cap = self.Bs, self.cap
+        assert self.mode == "all" and self.defer_wgrad, "accumulation windows need NAVILLM_EPISODE_DEFER=all"
+        for k in ("NAVILLM_EPISODE_ATTN_FWD", "NAVILLM_EPISODE_ATTN_BWD"):
+            assert os.environ.get(k, "episode") != "steps", f"{k}=steps shares the K/V-cache rows between episodes: not inside a window"
+        assert len(prefix_ids) == Bs
+        lens = np.array([len(p) for p in prefix_ids], dtype=np.int32)
+        assert lens.min() > 0 and lens.max() < cap
+        special = set(cfg.special_token_ids)
+        assert not any(t in special for p in prefix_ids for t in p), "the static prefix must not contain visual tokens"
+        P = self.prefix
+        if P is not None and not P.get("window"):
+            self.assert_no_pending_gradients("begin_episode()")
+            P = self.prefix = None
+        if P is not None:
+            if P["finished"] < P["episodes"]:
+                if any(r.get("targets") is not None for r in P["recs"][P["ep_rec0"]:]):
+                    raise RuntimeError("begin_episode() before the previous episode of the accumulation window was finished: its steps "
+                                       "already ran backward() -- call model.finish_episode() first, or model.episode_abort()")
+                self._drop_open_episode()
+            # the window is full, or its rows would outgrow the budget: hand over what it holds first
+            rows = P["prows"] + P["srows"]
+            per_ep = rows // max(P["episodes"], 1)
+            if P["nb"] + Bs > self.B or self._row_bytes() * int((rows + max(per_ep, 2 * int(lens.sum()))) * 1.1 + 64) > self._budget_bytes():
+                self.flush_window()
+                P = None
+        if P is None:
+            self._cursor, self._seg_total = 0, 0
+            P = self.prefix = dict(window=True, ids=[], lens=np.zeros(0, np.int32), nb=0, sb=0, episodes=0, finished=0, t=0, steps=0,
+                                   kv_steps=0, defer=True, recs=[], segments=0, lazy=True, pending=True, cache_valid=False, prows=0,
+                                   srows=0, ep_rec0=0, layers=None, Mp=None)
+            self.stats = {"prefix_rows": 0, "suffix_rows": [], "segments_flushed": 0, "recomputed_steps": 0, "window_episodes": 0}
+        P["sb"], P["t"], P["ep_rec0"], P["ep_srows0"] = P["nb"], 0, len(P["recs"]), P["srows"]
+        P["ids"] += [list(p) for p in prefix_ids]
+        P["lens"] = np.concatenate([P["lens"], lens])
+        P["nb"] += Bs
+        P["episodes"] += 1
+        P["prows"] += int(lens.sum())
+        self.stats["prefix_rows"] = P["prows"]
+        self.stats["window_episodes"] = P["episodes"]
+
+    def _drop_open_episode(self):
+        """the window's current episode was begun but never finished, and none of its steps carries a loss: forget it"""
+        P = self.prefix
+        Bs = self.Bs
+        for r in P["recs"][P["ep_rec0"]:]:
+            r["step"]["vis_live"] = None
+        del P["recs"][P["ep_rec0"]:]
+        P["srows"] = P["ep_srows0"]
+        P["prows"] -= int(P["lens"][P["sb"]:].sum())
+        P["ids"], P["lens"] = P["ids"][:P["sb"]], P["lens"][:P["sb"]]
+        P["nb"] -= Bs
+        P["episodes"] -= 1
+
+    def window_open(self):
+        P = self.prefix
+        return P is not None and bool(P.get("window"))
+
+    @torch.no_grad()
+    def _seal_window(self):
+        """all the window's samples are known: the prefix index tables over every slot (what begin() builds for one episode), the
+        episode buffers sized once for prefixes + steps, every step's block placed behind the prefixes"""
+        P, m, cfg = self.prefix, self.m, self.m.cfg
+        nb, cap, H, L = P["nb"], self.cap, cfg.num_heads, cfg.num_layers
+        lens = P["lens"]
+        Mp = int(lens.sum())
+        cu = np.zeros(nb + 1, np.int32)
+        cu[1:] = np.cumsum(lens)
+        ids = np.concatenate([np.asarray(p, np.int32) for p in P["ids"]])
+        pos = np.concatenate([np.arange(n, dtype=np.int32) for n in lens])
+        crow = np.concatenate([b * cap + np.arange(n, dtype=np.int32) for b, n in enumerate(lens)])
+        dev = m.device
+        ids_d, pos_d, crow_d, cu_d, lens_d = (ops.h2d(torch.from_numpy(a), dev) for a in (ids, pos, crow, cu, lens))
+        Lmax = int(lens.max())
+        P.update(ids_np=ids, cu=cu_d, pos=pos_d, crow=crow_d, pos0=torch.zeros((nb,), dtype=I32, device=dev), Lmax=Lmax, Mp=Mp,
+                 lens_dev=lens_d, ids_dev=ids_d, vix_dev=torch.full((Mp,), -1, dtype=I32, device=dev))
+        total = Mp + P["srows"]
+        self._cursor = 0                                   # (nothing is in the buffers yet: growing them copies nothing)
+        if self._E is not None and self._ecap > 2.5 * total + 4096:
+            self.release_buffers()
+        self._ensure_rows(total)
+        self._cursor = total
+        for r in P["recs"]:
+            r["r0"] = Mp + r["r0_rel"]
+        P["layers"] = [dict(lse=self._buf(f"p{i}.lse", (nb, H, Lmax), F32)) for i in range(L)]
+
+    def flush_window(self):
+        """run the open accumulation window NOW (fewer episodes than it was sized for: the last window of an epoch, an optimizer step
+        that comes early): all its gradients land in `.grad`"""
+        P = self.prefix
+        if P is None or not P.get("window"):
+            return
+        if P["finished"] < P["episodes"]:
+            if any(r.get("targets") is not None for r in P["recs"][P["ep_rec0"]:]):
+                raise RuntimeError("the accumulation window must hand over its gradients, but its current episode is still open: call "
+                                   "model.finish_episode() after the episode's last backward() (or model.episode_abort())")
+            self._drop_open_episode()
+        if not P["recs"]:
+            self.prefix = None
+            self._cursor = 0
+            return
+        self._seal_window()
+        self._finish_batched()
 
     @torch.no_grad()
     def _prefix_forward(self):
@@ -405,11 +529,13 @@ class PrefixEpisode:
         backward into the same `.grad` buffers; the episode stays open for its deferred part).  A prompt that is NOT at the length
         limit and does not start with its prefix is a caller error and raises."""
         P = self.prefix
-        for b in range(self.B):
-            lp = int(P["lens"][b])
-            if ids_list[b][:lp] == P["ids"][b] and lp < len(ids_list[b]) <= self.cap:
+        sb = P["sb"] if P.get("window") else 0             # (accumulation window: this episode's samples sit in slots [sb, sb + Bs))
+        assert len(ids_list) == self.Bs
+        for j in range(self.Bs):
+            lp = int(P["lens"][sb + j])
+            if ids_list[j][:lp] == P["ids"][sb + j] and lp < len(ids_list[j]) <= self.cap:
                 continue
-            if len(ids_list[b]) >= min(self.cap, self.max_length):      # truncated at the tokenizer's limit, or longer than the cache
+            if len(ids_list[j]) >= min(self.cap, self.max_length):      # truncated at the tokenizer's limit, or longer than the cache
                 self.stats["recomputed_steps"] += 1
                 return False
             raise AssertionError("the prompt does not start with the prefix registered for this episode")
@@ -436,11 +562,15 @@ class PrefixEpisode:
         token j or -1.  -> [B, d] final-norm hidden state of every prompt's last token, differentiable w.r.t. vis_all."""
         P = self.prefix
         assert P is not None, "PrefixEpisode.begin() first"
-        B, cap = self.B, self.cap
+        win = bool(P.get("window"))
+        sb = P["sb"] if win else 0                 # first prefix slot of this episode's samples (accumulation window: `_begin_window`)
+        B, cap = self.Bs, self.cap
+        if win and P["finished"] >= P["episodes"]:
+            raise RuntimeError("a navigation step after finish_episode(): begin_episode() opens the window's next episode")
         n = []
         for b in range(B):
-            lp = int(P["lens"][b])
-            assert ids_list[b][:lp] == P["ids"][b], "the prompt does not start with the prefix registered for this episode"
+            lp = int(P["lens"][sb + b])
+            assert ids_list[b][:lp] == P["ids"][sb + b], "the prompt does not start with the prefix registered for this episode"
             assert lp < len(ids_list[b]) <= cap, "prompt longer than the cache (left truncation is not supported in this mode)"
             n.append(len(ids_list[b]) - lp)
         # the step's rows are PACKED, sample after sample (round 3b; round 2 padded every sample to the longest suffix: 6.8 % of the
@@ -449,7 +579,7 @@ class PrefixEpisode:
         off = np.zeros(B + 1, np.int64)
         off[1:] = np.cumsum(n)
         M = int(off[B])
-        junk = B * cap
+        junk = self.B * cap
         ids_new = np.full(M, self.m.cfg.pad_token_id, np.int32)
         vix_new = np.full(M, -1, np.int32)
         pos_new = np.zeros(M, np.int32)
@@ -457,14 +587,14 @@ class PrefixEpisode:
         grow = np.zeros(M, np.int32)
         last = np.zeros(B, np.int32)
         for b in range(B):
-            lp = int(P["lens"][b])
+            lp = int(P["lens"][sb + b])
             s, e = int(off[b]), int(off[b + 1])
             ids_new[s:e] = ids_list[b][lp:]
             vix_new[s:e] = vis_idx_list[b][lp:]
             ar = np.arange(lp, lp + n[b], dtype=np.int32)
             pos_new[s:e] = ar
-            crow[s:e] = b * cap + ar
-            grow[s:e] = b * cap + ar
+            crow[s:e] = (sb + b) * cap + ar
+            grow[s:e] = (sb + b) * cap + ar
             last[b] = e - 1
         tok_rows = np.flatnonzero(vix_new >= 0)
         R = 0 if vis_all is None else int(vis_all.shape[0])
@@ -474,9 +604,10 @@ class PrefixEpisode:
         packed = np.concatenate([ids_new, vix_new, pos_new, crow, grow, last, vis_rows])
         idx = ops.h2d(torch.from_numpy(packed), self.m.device)
         parts = [idx[k * M:(k + 1) * M] for k in range(5)] + [idx[5 * M:5 * M + B], idx[5 * M + B:]]
-        step = dict(M=M, N=N, n=n, off=[int(x) for x in off[:B]], Lmax=int(max(int(P["lens"][b]) + n[b] for b in range(B))), qmin=(int(P["lens"].min()) // 128) * 128,
+        step = dict(M=M, N=N, n=n, off=[int(x) for x in off[:B]], Lmax=int(max(int(P["lens"][sb + b]) + n[b] for b in range(B))),
+                    qmin=(int(P["lens"][sb:sb + B].min()) // 128) * 128,
                     ids=parts[0], vix=parts[1], pos=parts[2], crow=parts[3], grow=parts[4], last=parts[5], vis_rows=parts[6],
-                    ids_np=ids_new)
+                    ids_np=ids_new, sb=sb)
         self.stats["suffix_rows"].append(int(sum(n)))
         anchor = self.m._anchor if torch.is_grad_enabled() else None
         if P.get("lazy") and torch.is_grad_enabled():
@@ -484,17 +615,32 @@ class PrefixEpisode:
             # happens in finish() / flush_segment(), batched with every other step's (`_forward_lazy`)
             step["vis_live"] = vis_all
             step["batched"] = True
+            k = P["steps"]
+            P["steps"] = k + 1
+            if win:
+                # accumulation window: the block's place is only known when the window is sealed (behind ALL the prefixes); its slot
+                # in the step tables / lse slabs is the step's index inside its own episode
+                if P["t"] >= 128 or N > 1536:
+                    raise RuntimeError("accumulation windows batch episodes of at most 128 steps and 1536 suffix tokens per prompt; "
+                                       "open long-horizon episodes with accumulate=1")
+                rec = dict(step=step, layers=[], x_last=None, rstdf=None, serial=k + 1, r0=None, r0_rel=P["srows"], defer=True, batched=True,
+                           k=P["t"], dH=None, lazy=True, targets=None, scale=None)
+                P["srows"] += M
+                P["t"] += 1
+                P["recs"].append(rec)
+                return rec
             if P["recs"] and self._segment_full(self._cursor + M):
                 self.flush_segment()
             r0 = self._cursor
             self._ensure_rows(r0 + M)
             self._cursor = r0 + M
-            k = P["steps"]
-            P["steps"] = k + 1
             rec = dict(step=step, layers=[], x_last=None, rstdf=None, serial=k + 1, r0=r0, defer=True, batched=True, k=len(P["recs"]), dH=None,
                        lazy=True, targets=None, scale=None)
             P["recs"].append(rec)
             return rec
+        if win:
+            raise RuntimeError("an accumulation window holds teacher-forced TRAINING steps only (a no-grad / sampled step needs the "
+                               "prefix's K/V now): open this episode with accumulate=1")
         self._need_prefix_cache()          # (a step that runs now: the prefix's K/V must be in the cache)
         if self.mode == "all" and P["defer"] and torch.is_grad_enabled():
             # the LM sees a detached copy; the live tensor keeps this step's scene-encoder / fusion graph alive until finish()
@@ -647,6 +793,12 @@ class PrefixEpisode:
         P = self.prefix
         if P is None:
             return
+        if P.get("window"):
+            # accumulation window: the episode is complete, its work waits for the window's last episode (or for whoever needs `.grad`)
+            P["finished"] = P["episodes"]
+            if P["nb"] + self.Bs > self.B:
+                self.flush_window()
+            return
         m, cfg, st = self.m, self.m.cfg, self.m.store
         B, H, hd, L, d = self.B, cfg.num_heads, cfg.head_dim, cfg.num_layers, cfg.hidden_size
         Mp, Lmax = P["Mp"], P["Lmax"]
@@ -715,6 +867,24 @@ class PrefixEpisode:
         rec["targets"] = ops.h2d(torch.as_tensor(targets).to(torch.int64).contiguous(), self.m.device)
         rec["scale"] = float(scale)
 
+    def _step_table(self, recs, Bk, Mp):
+        """what the one-launch episode attention kernels read: tab = off[T, Bk] | n[T, Bk] (first row / number of rows of table-step k's
+        block of prefix slot b; 0 rows where that sample has no such step -- the shorter episodes of an accumulation window) and, per
+        layer, the T lse-slab pointers.  One episode: table-step k is the k-th recorded step; a window: the k-th step of every episode."""
+        L, Bs = self.m.cfg.num_layers, self.Bs
+        T = max(r["k"] for r in recs) + 1
+        off = np.full((T, Bk), Mp, np.int32)
+        n = np.zeros((T, Bk), np.int32)
+        for r in recs:
+            sb = r["step"].get("sb", 0)
+            off[r["k"], sb:sb + Bs] = [r["r0"] + o for o in r["step"]["off"]]
+            n[r["k"], sb:sb + Bs] = r["step"]["n"]
+        while len(self.lse_s) < T:
+            self.lse_s.append([torch.zeros((self.B, self.m.cfg.num_heads, self.cap), dtype=F32, device=self.m.device) for _ in range(L)])
+        ptrs = np.array([[self.lse_s[k][i].data_ptr() for k in range(T)] for i in range(L)], dtype=np.int64)
+        dev = self.m.device
+        return T, ops.h2d(torch.from_numpy(np.concatenate([off.reshape(-1), n.reshape(-1)])), dev), ops.h2d(torch.from_numpy(ptrs), dev)
+
     def _forward_lazy(self, recs):
         """teacher-forced episode (round 4): the LM forward of ALL recorded steps as ONE batch over their rows [Mp, R) of the episode
         buffers -- the qkv / o / gate|up / down GEMMs and every row kernel see M = sum of the steps' suffix rows (~4 200 at the bench
@@ -727,8 +897,9 @@ class PrefixEpisode:
         from . import functions as Fn
         P = self.prefix
         m, cfg, st = self.m, self.m.cfg, self.m.store
-        B, cap, H, hd, eps, L, d, ff = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers, cfg.hidden_size, \
+        B, cap, H, hd, eps, L, d, ff = self.Bs, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers, cfg.hidden_size, \
             cfg.intermediate_size
+        Bk = P.get("nb", self.B)                         # prefix slots in use (an accumulation window: all its episodes' samples)
         Mp, R = P["Mp"], self._cursor
         # round 5: a prefix that has not gone through the decoder yet (begin() of a teacher-forced episode only builds its tables) joins
         # the batch: rows [0, R) instead of [Mp, R)
@@ -750,22 +921,17 @@ class PrefixEpisode:
             pos_cat = torch.cat(([P["pos"]] if pend else []) + [r["step"]["pos"] for r in recs])
             vix_cat = torch.cat(([P["vix_dev"]] if pend else []) + vix_parts)
             vis_cat = torch.cat(vis_parts, 0).contiguous() if vis_parts else None
-            while len(self.lse_s) < len(recs):
-                self.lse_s.append([torch.zeros((B, H, cap), dtype=F32, device=m.device) for _ in range(L)])
+            while len(self.lse_s) < len(recs) and not P.get("window"):
+                self.lse_s.append([torch.zeros((self.B, H, cap), dtype=F32, device=m.device) for _ in range(L)])
             last_cat = torch.cat([r["step"]["last"] + (r["r0"] - Mp) for r in recs])      # each step's last rows, relative to row Mp
             last_x = last_cat + Mp if pend else last_cat                                   # ... relative to the first row of this batch
             prune_top = os.environ.get("NAVILLM_EPISODE_PRUNE_TOP", "1") != "0" and L > 1
             P.pop("top", None)
             # round 5: the attention of ALL steps in one launch per layer, reading the episode buffers in place (nv_attn_fwd_episode_bf16;
             # NAVILLM_EPISODE_ATTN_FWD=steps: round 4's scatter -> strided forward -> gather per step, bit-identical)
-            epi_fwd = os.environ.get("NAVILLM_EPISODE_ATTN_FWD", "episode") != "steps" and len(recs) <= 4096
+            epi_fwd = (os.environ.get("NAVILLM_EPISODE_ATTN_FWD", "episode") != "steps" and len(recs) <= 4096) or bool(P.get("window"))
             if epi_fwd:
-                T = len(recs)
-                tab = np.concatenate([np.array([[r["r0"] + o for o in r["step"]["off"]] for r in recs], np.int32).reshape(-1),
-                                      np.array([r["step"]["n"] for r in recs], np.int32).reshape(-1)])
-                ptrs = np.array([[self.lse_s[r["k"]][i].data_ptr() for r in recs] for i in range(L)], dtype=np.int64)
-                f_tab = ops.h2d(torch.from_numpy(tab), m.device)
-                f_lse = ops.h2d(torch.from_numpy(ptrs), m.device)
+                T, f_tab, f_lse = self._step_table(recs, Bk, Mp)
                 f_nmax = max(r["step"]["N"] for r in recs)
             x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_cat, vix_cat, vis_cat, out=self._E[0]["x"][rows])
             for i in range(L):
@@ -776,16 +942,16 @@ class PrefixEpisode:
                 if pend:
                     # the prefix rows' own causal attention (the top layer's is never read: only its K/V are, by the steps' queries)
                     if i < L - 1 or not prune_top:
-                        ops.attn_fwd_varlen(E["qkv"][:Mp], P["cu"], P["pos0"], B, P["Lmax"], H, hd, out=E["attn"][:Mp], lse2=P["layers"][i]["lse"])
+                        ops.attn_fwd_varlen(E["qkv"][:Mp], P["cu"], P["pos0"], Bk, P["Lmax"], H, hd, out=E["attn"][:Mp], lse2=P["layers"][i]["lse"])
                     if not epi_fwd:
                         ops.scatter_rows_bf16_(E["qkv"][:Mp], P["crow"], self.cache[i])
                 if epi_fwd:
-                    ops.attn_fwd_episode(E["qkv"][:R], E["attn"][:R], f_lse[i], P["cu"], f_tab, T, B, H, hd, cap, f_nmax)
+                    ops.attn_fwd_episode(E["qkv"][:R], E["attn"][:R], f_lse[i], P["cu"], f_tab, T, Bk, H, hd, cap, f_nmax)
                 for r in (() if epi_fwd else recs):  # round 4 form: per step over the K/V cache (prefix rows + this step's rows)
                     sp = r["step"]
                     sl = slice(r["r0"], r["r0"] + sp["M"])
                     ops.scatter_rows_bf16_(E["qkv"][sl], sp["crow"], self.cache[i])
-                    ops.attn_fwd_strided(self.cache[i], self.kv0, B, sp["Lmax"], cap, H, hd, out=self.attn_buf[i], lse2=self.lse_s[r["k"]][i],
+                    ops.attn_fwd_strided(self.cache[i], self.kv0, self.B, sp["Lmax"], cap, H, hd, out=self.attn_buf[i], lse2=self.lse_s[r["k"]][i],
                                          q_row_min=sp["qmin"])
                     ops._lib.check(ops._L().nv_gather_rows_bf16(self.attn_buf[i].data_ptr(), sp["grow"].data_ptr(), E["attn"][sl].data_ptr(),
                                                                 sp["M"], d, ops._st()), "nv_gather_rows_bf16")
@@ -857,7 +1023,8 @@ class PrefixEpisode:
         final=False (flush_segment): the steps' rows [Mp, R) only, the prefix stays open."""
         P = self.prefix
         m, cfg, st = self.m, self.m.cfg, self.m.store
-        B, cap, H, hd, L, d, ff = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.num_layers, cfg.hidden_size, cfg.intermediate_size
+        B, cap, H, hd, L, d, ff = self.Bs, self.cap, cfg.num_heads, cfg.head_dim, cfg.num_layers, cfg.hidden_size, cfg.intermediate_size
+        Bk = P.get("nb", self.B)                         # prefix slots in use (an accumulation window: all its episodes' samples)
         Mp, R = P["Mp"], self._cursor
         recs = P["recs"]
         if any(r.get("lazy") and r["x_last"] is None for r in recs):
@@ -917,14 +1084,11 @@ class PrefixEpisode:
             # (the one-launch kernels keep a step table of 128 entries and 1536 statistics rows in LDS: longer episodes / blocks take
             # the per-step path)
             Nz = max([r["step"]["N"] for r in recs] or [0])
-            if recs and os.environ.get("NAVILLM_EPISODE_ATTN_BWD", "episode") != "steps" and len(recs) <= 128 and Nz <= 1536:
+            T_tab = 0
+            if recs and ((os.environ.get("NAVILLM_EPISODE_ATTN_BWD", "episode") != "steps" and max(r["k"] for r in recs) < 128 and Nz <= 1536)
+                         or P.get("window")):
                 # where every step's block sits (r0 | rows per sample | live rows of each sample) and, per layer, where its lse is
-                T = len(recs)
-                tab = np.concatenate([np.array([[r["r0"] + o for o in r["step"]["off"]] for r in recs], np.int32).reshape(-1),
-                                      np.array([r["step"]["n"] for r in recs], np.int32).reshape(-1)])
-                ptrs = np.array([[self.lse_s[r["k"]][i].data_ptr() for r in recs] for i in range(L)], dtype=np.int64)
-                epi_tab = ops.h2d(torch.from_numpy(tab), m.device)
-                lse_tab = ops.h2d(torch.from_numpy(ptrs), m.device)
+                T_tab, epi_tab, lse_tab = self._step_table(recs, Bk, Mp)
                 assert recs[0]["r0"] == Mp and all(a["r0"] + a["step"]["M"] == b_["r0"] for a, b_ in zip(recs, recs[1:])) and \
                     recs[-1]["r0"] + recs[-1]["step"]["M"] == R, "the steps' blocks must tile rows [Mp, R) of the episode buffers"
             for i in reversed(range(L)):
@@ -960,7 +1124,7 @@ class PrefixEpisode:
                 # attention backward.  The prefix rows' own causal attention (packed rows) ...
                 if final:
                     if lo == 0:
-                        ops.attn_bwd_varlen(E["qkv"][:Mp], E["attn"][:Mp], dattn[:Mp], P["layers"][i]["lse"], P["cu"], P["pos0"], B, Lp_max, H, hd,
+                        ops.attn_bwd_varlen(E["qkv"][:Mp], E["attn"][:Mp], dattn[:Mp], P["layers"][i]["lse"], P["cu"], P["pos0"], Bk, Lp_max, H, hd,
                                             dqkv[:Mp], q_row_min=0, rope=None)
                     else:
                         dqkv[:Mp].zero_()
@@ -970,7 +1134,7 @@ class PrefixEpisode:
                     # ONE launch per kernel for all the steps, reading the episode buffers in place: the prefix key blocks walk every
                     # step's queries and STORE the fp32 sum in dkv_acc (a later segment of a long episode: ADD to it); dQ and the steps'
                     # own dK|dV land in dqkv through RoPE^T
-                    ops.attn_bwd_episode(E["qkv"][:R], E["attn"][:R], dattn, dqkv, lse_tab[i], P["cu"], epi_tab, self.dkv_acc[i], len(recs), B, H, hd,
+                    ops.attn_bwd_episode(E["qkv"][:R], E["attn"][:R], dattn, dqkv, lse_tab[i], P["cu"], epi_tab, self.dkv_acc[i], T_tab, Bk, H, hd,
                                          cap, Mp, Lp_max, Nz, rope=(m.rope_cos, m.rope_sin), accumulate=seg_before > 0)
                 elif recs:
                     self._attn_bwd_by_step(i, recs, E, dattn, dqkv, zeros_md, first=seg_before == 0)

@@ -245,8 +245,9 @@ class NavCollator:
     # behind everything queued before it -- under teacher forcing the whole deferred backward of the previous episode (~270 ms at 7B):
     # with 4 slots the host blocked on its 5th step of every episode until the GPU had drained (tools/episode_host_probe.py: step 4
     # took 278 ms of host time), then the GPU idled while the host caught up -- 2-4 % of every episode.  32 slots (a few MB of pinned
-    # memory) let the host run five episodes ahead.
-    RING = 32
+    # memory) let the host run five episodes ahead.  128: an accumulation window (`begin_episode(..., accumulate=8)`) records 48+ steps
+    # while the previous window's batch still occupies the GPU.
+    RING = 128
 
     def __init__(self, B, Nv, Gcap=128, angle_feat_size=4, enc_full_graph=True, pair_dists=False, pin=None):
         import torch
@@ -264,6 +265,8 @@ class NavCollator:
             o += (n * np.dtype(dt).itemsize + 15) // 16 * 16
         self.nbytes = o
         pin = torch.cuda.is_available() if pin is None else pin
+        # (up to RING slots within ~8 MB of pinned memory, never fewer than 32: the [B, G, G] distance matrices make a slot 0.5 MB)
+        self.RING = max(32, min(self.RING, (8 << 20) // max(o, 1)))
         self.ring = [torch.empty(o, dtype=torch.uint8, pin_memory=pin) for _ in range(self.RING)]
         self.events = [None] * self.RING
         self.k = 0

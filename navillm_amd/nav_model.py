@@ -153,6 +153,8 @@ class NavModel(nn.Module):
         self.pack_rows = os.environ.get("NAVILLM_PACK_ROWS", "1") != "0"   # LM over the real tokens only (no left-padding rows)
         self._row_map = None
         self.episode = None              # PrefixEpisode (begin_episode): static prompt prefix computed once per training episode
+        self._window = None              # the PrefixEpisode of the open accumulation window (begin_episode(..., accumulate=n))
+        self._episode_plain = None       # ... and the non-windowed one it displaced from `self.episode`, kept for the next plain episode
         self.fp8 = None                  # Fp8DecoderWeights after to_fp8_weight_only()
         self._gen_kv = None              # K/V cache object kept between generate() calls
         self.flop_log = None             # bench: list of ("lm", tokens, sum of S_b^2, backward?) / ("lm_head", rows, backward?) per LM call
@@ -275,7 +277,7 @@ class NavModel(nn.Module):
         return self.kv
 
     # ---- optional training mode: the prompt's static prefix is computed once per episode (navillm_amd/episode.py)
-    def begin_episode(self, prefix_ids, capacity=1024, teacher_forced=False, max_length=None):
+    def begin_episode(self, prefix_ids, capacity=1024, teacher_forced=False, max_length=None, accumulate=1):
         """prefix_ids: B lists of token ids -- the part of every navigation prompt of the coming episode that never changes
         (everything up to "### History:").  Until `finish_episode()`, training-mode `model('navigation')` calls push only the rest
         of each prompt through the LM, over the cached prefix (every other mode -- object_grounding included -- takes the full `_lm`
@@ -287,14 +289,41 @@ class NavModel(nn.Module):
         deferred as well -- `model('navigation')` returns `fuse_embeds` at once (the next step's history token) and a
         `losses.DeferredLogits` handle as `fuse_logits`; `criterion(handle, targets) * coef / B` and `.backward()` work on it as on a
         tensor (they record targets and scale), and `finish_episode()` pushes ALL the steps through the decoder as one batch before
-        the batched backward.  The logits / loss values exist afterwards (`handle.value`, `float(loss)`)."""
+        the batched backward.  The logits / loss values exist afterwards (`handle.value`, `float(loss)`).
+        accumulate=n > 1 (round 5; teacher-forced episodes only) = the training loop's `gradient_accumulation_step` (train.py:68,86-89;
+        scripts/multi_wo_pretrain.sh:16 runs `--batch_size 1 --gradient_accumulation_step 8`): the optimizer steps only after every
+        n-th episode, so the n episodes of a window are batched with one another as the steps of one episode are --
+        `finish_episode()` of the first n - 1 returns at once, the n-th (or whatever needs `.grad` first: `FlatAdamW.clip_grad_norm_` /
+        `step`, `model.parameters()`, an episode opened without `accumulate`) runs ONE forward + backward over the rows of all n
+        (navillm_amd/episode.py::_begin_window).  Logits / loss values exist after that."""
         from .episode import PrefixEpisode
         B = len(prefix_ids)
+        if max_length is None:         # the tokenizer's left-truncation limit (modified_lm.py:57); the stub tokenizer of the synthetic driver: 1024
+            max_length = int(getattr(self.lang_model, "max_length", 1024))
+        accumulate = int(accumulate or 1)
+        if accumulate > 1 and teacher_forced and os.environ.get("NAVILLM_EPISODE_DEFER", "all") == "all" and \
+                os.environ.get("NAVILLM_EPISODE_WINDOW", "1") != "0":
+            w = self._window
+            if w is not None and (w.Bs != B or w.B != B * accumulate or w.cap != capacity):
+                w.flush_window()
+                w = None
+            if self.episode is not None and self.episode is not w:
+                self.episode.assert_no_pending_gradients("begin_episode()")
+                if self.episode is not self._window:
+                    self._episode_plain = self.episode
+            if w is None:
+                w = PrefixEpisode(self, B * accumulate, capacity, max_length, samples_per_episode=B)
+            self._window = self.episode = w
+            w.max_length = int(max_length)
+            w.begin(prefix_ids, teacher_forced=True, window=True)
+            return w
+        if self._window is not None:
+            self._window.flush_window()                # an episode outside the window: the window's gradients go to .grad first
+            if self.episode is self._window:
+                self.episode = self._episode_plain
         if self.episode is not None:
             # a begin before the previous episode's finish would silently drop that episode's deferred gradients (ADVICE r3, medium)
             self.episode.assert_no_pending_gradients("begin_episode()")
-        if max_length is None:         # the tokenizer's left-truncation limit (modified_lm.py:57); the stub tokenizer of the synthetic driver: 1024
-            max_length = int(getattr(self.lang_model, "max_length", 1024))
         if self.episode is None or self.episode.B != B or self.episode.cap != capacity:
             self.episode = PrefixEpisode(self, B, capacity, max_length)
         self.episode.max_length = int(max_length)
@@ -305,13 +334,20 @@ class NavModel(nn.Module):
         if self.episode is not None:
             self.episode.finish()
 
+    def flush_accumulation_window(self):
+        """hand over the gradients of the open accumulation window (`begin_episode(..., accumulate=n)`) now; a no-op without one.
+        Called by FlatAdamW before the clip / the update and by `parameters()`."""
+        if self._window is not None:
+            self._window.flush_window()
+
     def episode_release(self):
         """give the prefix-reuse episode buffers back (tens of GB after long episodes); the next begin_episode() re-creates them"""
-        if self.episode is not None:
-            self.episode.assert_no_pending_gradients("episode_release()")
-            self.episode.prefix = None
-            self.episode._cursor = 0
-            self.episode.release_buffers()
+        self.flush_accumulation_window()
+        for ep in {id(e): e for e in (self.episode, self._window, self._episode_plain) if e is not None}.values():
+            ep.assert_no_pending_gradients("episode_release()")
+            ep.prefix = None
+            ep._cursor = 0
+            ep.release_buffers()
 
     def episode_abort(self):
         """drop an episode that was begun but will not be finished.  Its deferred gradients are discarded -- but whatever the
@@ -324,6 +360,10 @@ class NavModel(nn.Module):
             P = ep.prefix
             if P is not None and (P.get("segments", 0) > 0 or P.get("kv_steps", 0) > 0 or ep.stats.get("recomputed_steps", 0) > 0):
                 self.store.tainted = "episode_abort() after part of the episode's gradients had been written to .grad"
+            if P is not None and P.get("window") and P.get("finished", 0) > 0:
+                # the FINISHED episodes of an accumulation window hold gradients that exist nowhere else: dropping them silently would
+                # make the optimizer step on a partial sum
+                self.store.tainted = "episode_abort() dropped the deferred gradients of the accumulation window's finished episodes"
             ep.prefix = None
             ep._cursor = 0
 
@@ -332,6 +372,8 @@ class NavModel(nn.Module):
         ran backward(), finish_episode() has not run) raises: the only caller of `model.parameters()` inside the reference's
         training loop is `torch.nn.utils.clip_grad_norm_(model.parameters(), 40.)` (train.py:87), which would clip -- and the
         optimizer then step on -- the encoder's gradients alone.  (FlatAdamW guards its own clip/step the same way.)"""
+        if getattr(self, "_window", None) is not None:
+            self._window.flush_window()
         if self.episode is not None:
             self.episode.assert_no_pending_gradients("model.parameters() [e.g. torch.nn.utils.clip_grad_norm_(model.parameters(), ...)]")
         return super().parameters(recurse)

@@ -161,6 +161,9 @@ class FlatAdamW(torch.optim.Optimizer):
         if self.store.tainted:
             raise RuntimeError(f"the gradient buffers are inconsistent ({self.store.tainted}): call zero_grad() before the next "
                                "clip_grad_norm_ / step")
+        flush = getattr(self.model, "flush_accumulation_window", None)
+        if flush is not None:
+            flush()                      # an open accumulation window (begin_episode(..., accumulate=n)) hands its gradients over now
         ep = getattr(self.model, "episode", None)
         if ep is not None and ep.has_pending_gradients():
             raise RuntimeError("optimizer step inside an open prefix-reuse episode: call model.finish_episode() (under "

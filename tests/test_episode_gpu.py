@@ -494,3 +494,86 @@ def test_first_writer_wgrad_store_equals_accumulate_into_zeros(monkeypatch):
         assert torch.equal(res["1"][0][g], res["0"][0][g]), ("first episode", g)
         assert torch.equal(res["1"][1][g], res["0"][1][g]), ("accumulated second episode", g)
         assert not torch.equal(res["1"][1][g], res["1"][0][g])
+
+
+def _window_run(m, cfg, plan, accumulate, Bs=2, flush=None):
+    """the episodes of `plan` [(seed, instruction length, steps)] one after the other, every step loss scaled 1 / Bs / len(plan) as the
+    reference's accumulation does (mp3d_agent.py:750); accumulate > 1: opened as an accumulation window"""
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step
+    from navillm_amd.losses import CrossEntropyLoss
+    crit = CrossEntropyLoss()
+    m.zero_grad()
+    m.store.touched.clear()
+    handles = []
+    for e, (seed, il, steps) in enumerate(plan):
+        ep = SyntheticEpisodes(cfg, Bs, seed=seed, instr_len=il, device=torch.device(DEV))
+        ep.instr[1] = ep.instr[1][: il - 17]                       # ragged prefixes inside an episode too
+        m.begin_episode(ep.prefix_ids(), teacher_forced=True, accumulate=accumulate)
+        for t in range(steps):
+            torch.manual_seed(7000 + 31 * e + t)
+            loss, lg = nav_step(m, crit, ep, train=True, last=(t == steps - 1), accum=len(plan))
+            handles.append((lg, loss))
+        m.finish_episode()
+    if flush is not None:
+        flush()
+    torch.cuda.synchronize()
+    logits = [lg.value.detach().float().cpu() for lg, _ in handles]
+    losses = [float(ls) for _, ls in handles]
+    grads = {g: t.detach().float().clone() for g, t in m.store.grad.items()}
+    return logits, losses, grads
+
+
+@pytest.mark.parametrize("size", ["mid", "7b-width"])
+def test_accumulation_window_batches_the_episodes_between_two_optimizer_steps(size):
+    """round 5 (second half): `begin_episode(..., teacher_forced=True, accumulate=n)` -- the reference launches
+    `--batch_size 1 --gradient_accumulation_step 8` (scripts/multi_wo_pretrain.sh:16); the weights are frozen between two optimizer
+    steps (train.py:68,86-89), so the n episodes of a window run as ONE batch at the n-th finish_episode() (episode.py::_begin_window).
+    Against the same episodes finished one by one (same kernels on the same rows; the GEMMs' M and the weight gradients' summation
+    order differ: last bits): logits of every step, loss values, every gradient buffer.  Episodes of different lengths (a shorter
+    episode has no rows in the later table-steps), ragged prefixes, and a window that is cut short by the optimizer."""
+    from navillm_amd.nav_model import NavModel
+    from navillm_amd import config as nvcfg
+    from navillm_amd.optim import FlatAdamW
+    cfg = _mid_cfg() if size == "mid" else nvcfg.vicuna_7b(image_feat_size=768, num_layers=2, base_vocab_size=2000)
+    m = NavModel(nav_config=cfg, device=torch.device(DEV), seed=12)
+    m.eval()
+    plan = [(41, 150, 3), (42, 96, 2), (43, 171, 4), (44, 120, 3)]
+    l_one, s_one, g_one = _window_run(m, cfg, plan, accumulate=1)
+    assert m._window is None
+    l_win, s_win, g_win = _window_run(m, cfg, plan, accumulate=len(plan))
+    assert m._window is not None and m._window.prefix is None, "the window's last finish_episode() runs it"
+    st = m._window.stats
+    assert st["window_episodes"] == len(plan) and len(st["suffix_rows"]) == sum(p[2] for p in plan)
+    worst = max(bf16_ulps_at_scale(a, b) for a, b in zip(l_win, l_one))
+    rel = {g: round(((g_win[g] - g_one[g]).norm() / (g_one[g].norm() + 1e-20)).item(), 4) for g in g_one}
+    lrel = max(abs(a - b) / max(abs(b), 1e-6) for a, b in zip(s_win, s_one))
+    print(f"[accumulation window {size}] {len(plan)} episodes x 2 prompts, {len(l_one)} steps: logits worst {worst:.2f} bf16 spacings vs one "
+          f"finish per episode, loss values rel {lrel:.2e}, gradient buffers rel err {rel}")
+    assert worst <= (2.0 if size == "mid" else 3.0) and lrel < 2e-2
+    for g, v in rel.items():
+        assert v < 1.5e-2, (g, v)
+    # a window sized for 8 episodes that the optimizer cuts short after 4: clip_grad_norm_ hands its gradients over first
+    opt = FlatAdamW(m, lr=0.0)
+    l_cut, _, g_cut = _window_run(m, cfg, plan, accumulate=8, flush=lambda: opt.clip_grad_norm_(40.0))
+    assert m._window.prefix is None
+    for a, b in zip(l_cut, l_win):
+        assert bf16_ulps_at_scale(a, b) <= 2.0
+    for g in g_one:
+        assert ((g_cut[g] - g_win[g]).norm() / (g_win[g].norm() + 1e-20)).item() < 1.5e-2, g
+    # inside an open window nothing exists yet: reading a value is an error, not a silent zero; a plain episode flushes the window first
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step
+    from navillm_amd.losses import CrossEntropyLoss
+    m.zero_grad()
+    ep = SyntheticEpisodes(cfg, 2, seed=5, instr_len=100, device=torch.device(DEV))
+    m.begin_episode(ep.prefix_ids(), teacher_forced=True, accumulate=4)
+    loss, lg = nav_step(m, CrossEntropyLoss(), ep, train=True, last=True, accum=4)
+    m.finish_episode()
+    assert m._window.window_open() and m._window.has_pending_gradients()
+    with pytest.raises(RuntimeError, match="finish_episode"):
+        lg.value
+    assert float(m.store.grad["lm"].float().abs().max()) == 0.0
+    ep2 = SyntheticEpisodes(cfg, 2, seed=6, instr_len=100, device=torch.device(DEV))
+    m.begin_episode(ep2.prefix_ids(), teacher_forced=False)         # not part of the window: the window runs now
+    assert not m._window.window_open() and float(loss) > 0 and float(m.store.grad["lm"].float().abs().max()) > 0.0
+    m.episode_abort()
+    m.zero_grad()

@@ -753,3 +753,74 @@ def test_kvcache_key_codes_vectorised_equals_the_token_loop():
         got = kv._key_codes(vis_idx.tolist(), keys)
         assert np.array_equal(got, want) and kv._key_ids == ref_ids
     assert np.array_equal(kv._key_codes([-1, 0, -1], None), np.array([0, -1, 0]))
+
+
+def test_accumulation_window_bookkeeping_slots_rows_and_step_tables(monkeypatch):
+    """navillm_amd/episode.py::_begin_window (round 5; `begin_episode(..., accumulate=n)`, the reference's `--gradient_accumulation_step`,
+    train.py:68,86-89): the HOST side of a window on a stub model -- every episode takes the next prefix slots, its steps only reserve
+    rows, sealing puts all prefixes first and the steps' blocks behind them, and the tables of the one-launch attention kernels map
+    table-step k to the k-th step of EVERY episode (0 rows where an episode is shorter).  No kernel runs."""
+    import types
+    from navillm_amd import config as nvcfg
+    from navillm_amd.episode import PrefixEpisode
+    cfg = nvcfg.tiny(precision="amp_bf16")
+    stub = types.SimpleNamespace(cfg=cfg, device=torch.device("cpu"), store=None, _anchor=None)
+    special = set(cfg.special_token_ids)
+    tok = [t for t in range(5, 400) if t not in special]
+    vis_tok = sorted(special)[0]
+
+    def prompt(pre, n_text, n_vis):
+        return list(pre) + tok[50:50 + n_text] + [vis_tok] * n_vis + [tok[7]]
+
+    plan = [([tok[:9], tok[10:17]], [(3, 2), (5, 1)]),            # episode 0: prefixes of 9 / 7 tokens, 2 steps
+            ([tok[20:31], tok[30:35]], [(2, 1)]),                 # episode 1: 11 / 5, 1 step
+            ([tok[40:46], tok[60:68]], [(1, 1), (2, 2), (4, 3)])]  # episode 2: 6 / 8, 3 steps
+    win = PrefixEpisode(stub, 8, capacity=64, max_length=64, samples_per_episode=2)
+    recs = []
+    with torch.enable_grad():
+        for pre, steps in plan:
+            win.begin(pre, teacher_forced=True, window=True)
+            for n_text, n_vis in steps:
+                ids = [prompt(p, n_text + j, n_vis) for j, p in enumerate(pre)]
+                vix = [[-1] * len(row) for row in ids]
+                k = 0
+                for b, row in enumerate(ids):
+                    for j, t in enumerate(row):
+                        if t == vis_tok:
+                            vix[b][j] = k
+                            k += 1
+                assert win.fits(ids)
+                recs.append(win.lm(ids, vix, torch.zeros((k, cfg.hidden_size), requires_grad=True)))
+                assert recs[-1]["r0"] is None and recs[-1]["lazy"]
+            recs[-1]["targets"] = torch.zeros(2)                  # (a registered loss = pending gradients)
+            with pytest.raises(RuntimeError, match="current episode is still open"):
+                win.flush_window()
+            recs[-1]["targets"] = None
+            win.finish()
+            with pytest.raises(RuntimeError, match="after finish_episode"):
+                win.lm(ids, vix, None)
+    P = win.prefix
+    assert P["window"] and P["nb"] == 6 and P["episodes"] == 3 and P["finished"] == 3 and len(P["recs"]) == 6
+    assert [r["k"] for r in recs] == [0, 1, 0, 0, 1, 2] and [r["step"]["sb"] for r in recs] == [0, 0, 2, 4, 4, 4]
+    assert list(P["lens"]) == [9, 7, 11, 5, 6, 8]
+    win._seal_window()
+    Mp = 46
+    assert P["Mp"] == Mp and win._cursor == Mp + sum(r["step"]["M"] for r in recs) and P["cu"].tolist() == [0, 9, 16, 27, 32, 38, 46]
+    assert recs[0]["r0"] == Mp and all(a["r0"] + a["step"]["M"] == b["r0"] for a, b in zip(recs, recs[1:]))
+    # cache rows (K/V slot b * cap + position) use the GLOBAL slot
+    assert int(recs[3]["step"]["crow"][0]) == 4 * 64 + 6 and int(recs[2]["step"]["crow"][-1]) == 3 * 64 + 5 + recs[2]["step"]["n"][1] - 1
+    T, tab, ptrs = win._step_table(recs, 6, Mp)
+    tab = tab.view(2, T, 6)
+    assert T == 3 and tuple(ptrs.shape) == (cfg.num_layers, 3)
+    n = tab[1].tolist()
+    assert n[0] == recs[0]["step"]["n"] + recs[2]["step"]["n"] + recs[3]["step"]["n"]          # every episode has a first step
+    assert n[1] == recs[1]["step"]["n"] + [0, 0] + recs[4]["step"]["n"]                         # episode 1 has no second step
+    assert n[2] == [0, 0, 0, 0] + recs[5]["step"]["n"]
+    off = tab[0].tolist()
+    assert off[0][:2] == [recs[0]["r0"], recs[0]["r0"] + recs[0]["step"]["n"][0]] and off[2][4] == recs[5]["r0"]
+    assert off[1][2] == Mp and off[2][0] == Mp                                                  # empty entries point at a valid row
+    # an unfinished episode without losses is dropped when the window must run; one WITH a registered loss is an error (above)
+    win.begin([tok[:4], tok[:5]], teacher_forced=True, window=True)
+    assert P["nb"] == 8 and P["episodes"] == 4
+    win._drop_open_episode()
+    assert P["nb"] == 6 and P["episodes"] == 3 and list(P["lens"]) == [9, 7, 11, 5, 6, 8] and P["prows"] == Mp
