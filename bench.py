@@ -405,7 +405,7 @@ def long_horizon_extra(a, cfg, model, wrapped, crit, device, seed, T=64):
     try:
         from navillm_amd.synthetic import prefix_reuse_episode
         model.zero_grad()
-        for rep in range(2):
+        for rep in range(3):          # (the episode buffers settle over the first TWO episodes of a new shape: tools/t64_probe.py 94 / 117 / 141)
             ep.reset()
             torch.cuda.synchronize()
             t0 = time.perf_counter()

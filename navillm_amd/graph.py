@@ -9,6 +9,7 @@ matrices: the O(n^2) relaxation per visit, all slots' 7-d pose features in one c
 call per batch.  Results are pinned by tests/golden/g7_graph.npz (generated from the reference) through this C ABI.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -266,7 +267,7 @@ class NavCollator:
         self.nbytes = o
         pin = torch.cuda.is_available() if pin is None else pin
         # (up to RING slots within ~8 MB of pinned memory, never fewer than 32: the [B, G, G] distance matrices make a slot 0.5 MB)
-        self.RING = max(32, min(self.RING, (8 << 20) // max(o, 1)))
+        self.RING = max(32, min(int(os.environ.get("NAVILLM_COLLATE_RING", self.RING)), (8 << 20) // max(o, 1)))
         self.ring = [torch.empty(o, dtype=torch.uint8, pin_memory=pin) for _ in range(self.RING)]
         self.events = [None] * self.RING
         self.k = 0

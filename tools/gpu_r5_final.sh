@@ -29,4 +29,4 @@ DB=$(find gpurun_out/prof_b -name "*.db" | head -1)
 python tools/rocprof_summary.py "$DB" gpurun_out/r05_bench_kernel_stats_prefix_reuse_$TAG.txt
 find gpurun_out/prof_b -name "*.db" -delete
 head -16 gpurun_out/r05_bench_kernel_stats_prefix_reuse_$TAG.txt | cut -c1-160
-bash tools/gpu_pmc_bench_r4.sh r05 2>&1 | tail -8
+[ -n "$SKIP_PMC" ] || bash tools/gpu_pmc_bench_r4.sh r05 2>&1 | tail -8
