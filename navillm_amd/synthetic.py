@@ -650,3 +650,22 @@ def prefix_reuse_episode(model, criterion, ep, steps, accum=1, teacher_forced=Fa
     with ctx():
         inner.finish_episode()
     return losses
+
+
+def accumulation_window(model, criterion, episodes, steps):
+    """One accumulation window of teacher-forced prefix-reuse episodes (`begin_episode(..., accumulate=n)`; the reference's
+    `--gradient_accumulation_step n`, train.py:68,86-89): `episodes` = n SyntheticEpisodes batches, `steps[e]` navigation steps each,
+    every loss scaled / B / n.  The n-th `finish_episode()` runs the whole window; under a `NavDataParallel` wrapper it is the one inside
+    `final_backward()`, so the exchange is launched from inside the window's batched backward."""
+    inner = model.module if hasattr(model, "module") else model
+    n = len(episodes)
+    losses = []
+    for e, ep in enumerate(episodes):
+        inner.begin_episode(ep.prefix_ids(), teacher_forced=True, accumulate=n)
+        for t in range(steps[e]):
+            losses.append(nav_step(model, criterion, ep, train=True, last=(t == steps[e] - 1), accum=n, final=False)[0])
+        last = e == n - 1
+        ctx = model.final_backward if (last and hasattr(model, "final_backward")) else contextlib.nullcontext
+        with ctx():
+            inner.finish_episode()
+    return losses

@@ -304,12 +304,18 @@ def _prefix_episode(model, wrapped, seed, steps, dev=DEV, teacher_forced=False):
     """one prefix-reuse training episode (navillm_amd/episode.py, the bench's default mode): every step's backward() only records its
     output gradient; ALL gradients of the episode appear in finish_episode(), which under the wrapper runs inside `final_backward()`
     and launches the per-layer exchange from the deferred backward walk"""
-    from navillm_amd.synthetic import SyntheticEpisodes, prefix_reuse_episode
+    from navillm_amd.synthetic import SyntheticEpisodes, prefix_reuse_episode, accumulation_window
     from navillm_amd.losses import CrossEntropyLoss
     ep = SyntheticEpisodes(model.cfg, 3, seed=seed, instr_len=150, device=torch.device(dev))
     model.zero_grad()
     torch.manual_seed(1)
-    prefix_reuse_episode(wrapped, CrossEntropyLoss(), ep, steps, teacher_forced=teacher_forced)
+    if teacher_forced == "window":
+        # round 5: an accumulation window of two teacher-forced episodes (begin_episode(..., accumulate=2)); the second finish_episode()
+        # runs the whole window inside final_backward()
+        ep_b = SyntheticEpisodes(model.cfg, 3, seed=seed + 50, instr_len=110, device=torch.device(dev))
+        accumulation_window(wrapped, CrossEntropyLoss(), [ep, ep_b], [steps, max(steps - 1, 1)])
+    else:
+        prefix_reuse_episode(wrapped, CrossEntropyLoss(), ep, steps, teacher_forced=teacher_forced)
     torch.cuda.synchronize()
     return {k: v.clone() for k, v in model.store.grad.items()}
 
@@ -340,14 +346,15 @@ def _shared_gpu_rank_prefix(rank, world, port, q, steps_by_rank, teacher_forced=
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("teacher_forced", [False, True])
+@pytest.mark.parametrize("teacher_forced", [False, True, "window"])
 def test_dp_world2_shared_gpu_prefix_reuse_episode_mean_and_replica_consistency(teacher_forced):
     """the HEADLINE training mode under data parallelism with two real ranks and the real kernels.  Rank 0 runs a
     2-step episode, rank 1 a 3-step one (ranks may run different numbers of nav steps, mp3d_agent.py:661-676: only the final backward
     synchronises); the exchange is launched from inside finish_episode()'s deferred backward walk under final_backward().  After it both
     ranks hold bit-identical gradients == the mean of the two single-rank prefix-reuse gradients, nothing is left for the optimizer's
     flush, and after clip + AdamW the replicas are bit-identical.  teacher_forced: the same with the steps' forward deferred and batched
-    into finish_episode() (round 4), i.e. the bench's default training step under data parallelism."""
+    into finish_episode() (round 4), i.e. the bench's default training step under data parallelism.  "window" (round 5): each rank runs
+    an accumulation window of two teacher-forced episodes; the exchange runs from inside the window's batched backward."""
     import torch.multiprocessing as mp
     from navillm_amd.nav_model import NavModel
     world, steps_by_rank = 2, (2, 3)
