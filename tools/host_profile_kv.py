@@ -14,6 +14,7 @@ from navillm_amd.losses import CrossEntropyLoss
 from navillm_amd.synthetic import SyntheticEpisodes, nav_step
 
 dev = torch.device("cuda:0")
+torch.set_num_threads(16)          # as bench.py does: the default (all hardware threads) makes tiny CPU ops 100x slower now and then
 cfg = C.vicuna_7b(image_feat_size=768)
 m = NavModel(nav_config=cfg, device=dev, seed=0)
 m.eval()
