@@ -126,7 +126,6 @@ class PrefixEpisode:
         self.mode = mode
         self.defer_wgrad = mode != "none"
         self.lse_s = []                                       # mode "all": per step, per layer lse [B, H, cap] (1 MB each at B = 8)
-        self._lse_ptrs = {}                                   # ... and, per step slot, the device table of its L slab pointers
         self.fuse_kvacc = os.environ.get("NAVILLM_EPISODE_FUSE_KVACC", "1") != "0"
         self._E, self._E32, self._ecap, self._cursor, self._last_rows = None, None, 0, 0, 0
         self._seg_total = 0                                   # suffix rows of the episode so far that earlier segments already flushed
@@ -674,17 +673,6 @@ class PrefixEpisode:
                 self.lse_s.append([torch.zeros((B, H, cap), dtype=F32, device=m.device) for _ in range(L)])
         x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), step["ids"], step["vix"], vis_all,
                           out=self._E[0]["x"][r0:r0 + M] if allm else self._buf("E", (M, d)))
-        # round 5: a deferred step's attention reads the episode buffers in place (nv_attn_fwd_episode_bf16 with ONE table-step: the
-        # prefix's K/V are rows [0, Mp) of the same buffer) instead of scatter -> strided forward over the K/V cache -> gather: one
-        # launch per layer instead of three, no attention over the prefix rows above `qmin`, bit-identical (NAVILLM_EPISODE_ATTN_FWD=steps
-        # restores the cache form)
-        epi = allm and os.environ.get("NAVILLM_EPISODE_ATTN_FWD", "episode") != "steps"
-        if epi:
-            s_tab = ops.h2d(torch.from_numpy(np.concatenate([np.array([r0 + o for o in step["off"]], np.int32),
-                                                             np.array(step["n"], np.int32)])), m.device)
-            if ks not in self._lse_ptrs:
-                self._lse_ptrs[ks] = ops.h2d(torch.from_numpy(np.array([t_.data_ptr() for t_ in self.lse_s[ks]], np.int64)), m.device)
-            s_lse = self._lse_ptrs[ks]
         layers = []
         for i in range(L):
             Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
@@ -702,15 +690,12 @@ class PrefixEpisode:
             # q|k|v with RoPE in the GEMM epilogue (bit-identical to the GEMM followed by nv_rope_rows_bf16), row r at position pos[r]
             qkv = ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, cap, 2 * H * hd, out=E["qkv"][r0:r0 + M] if allm else self._buf("qkv", (M, 3 * d)),
                                     pos_i32=step["pos"])
+            ops.scatter_rows_bf16_(qkv, step["crow"], self.cache[i])
+            lse_i = self.lse_s[ks][i] if allm else self.lse[i]
+            ops.attn_fwd_strided(self.cache[i], self.kv0, B, Lmax, cap, H, hd, out=self.attn_buf[i], lse2=lse_i, q_row_min=qmin)
             attn = t("attn", d)
-            if epi:
-                ops.attn_fwd_episode(E["qkv"][:r0 + M], E["attn"][:r0 + M], s_lse[i:i + 1], self.prefix["cu"], s_tab, 1, B, H, hd, cap, step["N"])
-            else:
-                ops.scatter_rows_bf16_(qkv, step["crow"], self.cache[i])
-                lse_i = self.lse_s[ks][i] if allm else self.lse[i]
-                ops.attn_fwd_strided(self.cache[i], self.kv0, B, Lmax, cap, H, hd, out=self.attn_buf[i], lse2=lse_i, q_row_min=qmin)
-                ops._lib.check(ops._L().nv_gather_rows_bf16(self.attn_buf[i].data_ptr(), step["grow"].data_ptr(), attn.data_ptr(), M, d, ops._st()),
-                               "nv_gather_rows_bf16")
+            ops._lib.check(ops._L().nv_gather_rows_bf16(self.attn_buf[i].data_ptr(), step["grow"].data_ptr(), attn.data_ptr(), M, d, ops._st()),
+                           "nv_gather_rows_bf16")
             x1 = ops.gemm_bf16(ops.NT, attn, Wo, out=t("x1", d), R=x, epilogue=ops.EPI_RESID)
             n2, rstd2 = ops.rmsnorm_fwd(x1, w2, eps, out=t("n2", d), rstd=t("r2", 0, F32))
             gu = ops.gemm_bf16(ops.NT, n2, Wgu, out=t("gu", 2 * ff))
