@@ -1424,6 +1424,7 @@ int nv_attn_fwd_episode_bf16(const void* qkv, void* out, const void* lse_ptrs, c
     if (T == 0 || n_max <= 0) return NV_OK;
     const long bytes = rows * 3L * H * HD * 2;
     if (bytes > 0xffffffffL) return NV_ERR_SHAPE;
+    if ((long)T * ((n_max + 127) / 128) > 65535) return NV_ERR_SHAPE;      // grid.y limit: the caller takes the per-step path
     static bool once = false;
     if (!once) { if (set_lds((const void*)epi_fwd_kernel, 65536)) return NV_ERR_LAUNCH; once = true; }
     EpiFwdArgs p{};

@@ -53,6 +53,7 @@ import os
 import numpy as np
 import torch
 
+from . import debug
 from . import ops
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
@@ -126,6 +127,7 @@ class PrefixEpisode:
         self.mode = mode
         self.defer_wgrad = mode != "none"
         self.lse_s = []                                       # mode "all": per step, per layer lse [B, H, cap] (1 MB each at B = 8)
+        self._lse_ptrs = {}                                   # ... and, per step slot, the device table of its L slab pointers
         self.fuse_kvacc = os.environ.get("NAVILLM_EPISODE_FUSE_KVACC", "1") != "0"
         self._E, self._E32, self._ecap, self._cursor, self._last_rows = None, None, 0, 0, 0
         self._seg_total = 0                                   # suffix rows of the episode so far that earlier segments already flushed
@@ -223,6 +225,27 @@ class PrefixEpisode:
         self._last_rows = 0
         if self.m.device.type == "cuda":
             torch.cuda.empty_cache()
+
+    def _poison_release(self):
+        """NAVILLM_POISON=1 (navillm_amd/debug.py): the episode is over -- whatever it left in the row buffers, the statistics slabs, the
+        K/V-cache slabs, the fp32 K/V-gradient accumulators and the scratch becomes NaN, so that state surviving into the next episode
+        cannot pass for a plausible number; then the canaries around every live buffer are verified.  (`dout_full`, `kv0` and
+        `zeros_md` are zero BY CONTRACT and stay.)"""
+        if not debug.POISON:
+            return
+        for group in (self._E or []), (self._E32 or []):
+            for bufs in group:
+                for t in (bufs or {}).values():
+                    debug.poison_(t)
+        for k, t in self._slab.items():
+            if k != "zeros_md":
+                debug.poison_(t)
+        for per_step in self.lse_s:
+            for t in per_step:
+                debug.poison_(t)
+        for t in self.lse + self.dkv_acc + self.cache + self.attn_buf + [self.dqkv_full]:
+            debug.poison_(t)
+        debug.check_guards("at the end of a prefix-reuse episode")
 
     def _rows_fit(self, cap):
         """would episode buffers of `cap` rows fit?  (what is held now is released layer by layer while the new ones are built)"""
@@ -673,6 +696,17 @@ class PrefixEpisode:
                 self.lse_s.append([torch.zeros((B, H, cap), dtype=F32, device=m.device) for _ in range(L)])
         x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), step["ids"], step["vix"], vis_all,
                           out=self._E[0]["x"][r0:r0 + M] if allm else self._buf("E", (M, d)))
+        # round 5: a deferred step's attention reads the episode buffers in place (nv_attn_fwd_episode_bf16 with ONE table-step: the
+        # prefix's K/V are rows [0, Mp) of the same buffer) instead of scatter -> strided forward over the K/V cache -> gather: one
+        # launch per layer instead of three, no attention over the prefix rows above `qmin`, bit-identical (NAVILLM_EPISODE_ATTN_FWD=steps
+        # restores the cache form)
+        epi = allm and os.environ.get("NAVILLM_EPISODE_ATTN_FWD", "episode") != "steps"
+        if epi:
+            s_tab = ops.h2d(torch.from_numpy(np.concatenate([np.array([r0 + o for o in step["off"]], np.int32),
+                                                             np.array(step["n"], np.int32)])), m.device)
+            if ks not in self._lse_ptrs:
+                self._lse_ptrs[ks] = ops.h2d(torch.from_numpy(np.array([t_.data_ptr() for t_ in self.lse_s[ks]], np.int64)), m.device)
+            s_lse = self._lse_ptrs[ks]
         layers = []
         for i in range(L):
             Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
@@ -690,12 +724,15 @@ class PrefixEpisode:
             # q|k|v with RoPE in the GEMM epilogue (bit-identical to the GEMM followed by nv_rope_rows_bf16), row r at position pos[r]
             qkv = ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, cap, 2 * H * hd, out=E["qkv"][r0:r0 + M] if allm else self._buf("qkv", (M, 3 * d)),
                                     pos_i32=step["pos"])
-            ops.scatter_rows_bf16_(qkv, step["crow"], self.cache[i])
-            lse_i = self.lse_s[ks][i] if allm else self.lse[i]
-            ops.attn_fwd_strided(self.cache[i], self.kv0, B, Lmax, cap, H, hd, out=self.attn_buf[i], lse2=lse_i, q_row_min=qmin)
             attn = t("attn", d)
-            ops._lib.check(ops._L().nv_gather_rows_bf16(self.attn_buf[i].data_ptr(), step["grow"].data_ptr(), attn.data_ptr(), M, d, ops._st()),
-                           "nv_gather_rows_bf16")
+            if epi:
+                ops.attn_fwd_episode(E["qkv"][:r0 + M], E["attn"][:r0 + M], s_lse[i:i + 1], self.prefix["cu"], s_tab, 1, B, H, hd, cap, step["N"])
+            else:
+                ops.scatter_rows_bf16_(qkv, step["crow"], self.cache[i])
+                lse_i = self.lse_s[ks][i] if allm else self.lse[i]
+                ops.attn_fwd_strided(self.cache[i], self.kv0, B, Lmax, cap, H, hd, out=self.attn_buf[i], lse2=lse_i, q_row_min=qmin)
+                ops._lib.check(ops._L().nv_gather_rows_bf16(self.attn_buf[i].data_ptr(), step["grow"].data_ptr(), attn.data_ptr(), M, d, ops._st()),
+                               "nv_gather_rows_bf16")
             x1 = ops.gemm_bf16(ops.NT, attn, Wo, out=t("x1", d), R=x, epilogue=ops.EPI_RESID)
             n2, rstd2 = ops.rmsnorm_fwd(x1, w2, eps, out=t("n2", d), rstd=t("r2", 0, F32))
             gu = ops.gemm_bf16(ops.NT, n2, Wgu, out=t("gu", 2 * ff))
@@ -807,6 +844,7 @@ class PrefixEpisode:
         if P["kv_steps"] == 0:                         # no step ran a backward: nothing to propagate (and dkv_acc holds no data)
             self.prefix = None
             self._cursor = 0
+            self._poison_release()
             return
         defer = P["defer"]
         R = self._cursor if defer else Mp               # token rows of the whole episode: prefix [0, Mp) + every step's block
@@ -856,6 +894,7 @@ class PrefixEpisode:
             self._cursor = 0
         self._embed_grad(dx, P["ids_np"])
         self.prefix = None
+        self._poison_release()
         dp = getattr(m, "_dp", None)
         if dp is not None and dp._exchanging():
             dp._finalize()                         # outside autograd: no engine callback will run the end-of-backward exchange
@@ -929,10 +968,12 @@ class PrefixEpisode:
             P.pop("top", None)
             # round 5: the attention of ALL steps in one launch per layer, reading the episode buffers in place (nv_attn_fwd_episode_bf16;
             # NAVILLM_EPISODE_ATTN_FWD=steps: round 4's scatter -> strided forward -> gather per step, bit-identical)
-            epi_fwd = (os.environ.get("NAVILLM_EPISODE_ATTN_FWD", "episode") != "steps" and len(recs) <= 4096) or bool(P.get("window"))
+            # (the kernel's grid is (slots * heads, table-steps * query blocks): beyond 65 535 in y the per-step cache form runs -- ADVICE r5)
+            f_nmax = max(r["step"]["N"] for r in recs)
+            f_fits = (max(r["k"] for r in recs) + 1) * ((f_nmax + 127) // 128) <= 65535
+            epi_fwd = (os.environ.get("NAVILLM_EPISODE_ATTN_FWD", "episode") != "steps" and f_fits) or bool(P.get("window"))
             if epi_fwd:
                 T, f_tab, f_lse = self._step_table(recs, Bk, Mp)
-                f_nmax = max(r["step"]["N"] for r in recs)
             x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_cat, vix_cat, vis_cat, out=self._E[0]["x"][rows])
             for i in range(L):
                 Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
@@ -1044,6 +1085,8 @@ class PrefixEpisode:
             self._cursor = Mp
             self.stats["segments_flushed"] += 1
         if not live and not (final and seg_before):
+            if final:
+                self._poison_release()
             return
         with torch.no_grad():
             # round 5: nothing has written a decoder-layer gradient since zero_grad() (FlatStore.layers_zero) -> the weight-gradient GEMMs of this walk
@@ -1166,6 +1209,8 @@ class PrefixEpisode:
                 with torch.enable_grad():
                     torch.autograd.backward([v], [g])
             r["step"]["vis_live"] = None
+        if final:
+            self._poison_release()
         dp = getattr(m, "_dp", None)
         if final and dp is not None and dp._exchanging():
             dp._finalize()                         # outside autograd: no engine callback will run the end-of-backward exchange

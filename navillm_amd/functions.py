@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import torch
+from . import debug
 from . import ops
 
 F32, BF16 = torch.float32, torch.bfloat16
@@ -362,6 +363,18 @@ class ActivationArena:
             off += cap * w
         self.cap = cap
 
+    def poison(self, keep=("E",)):
+        """NAVILLM_POISON=1: the next forward takes the arena over -- everything the previous one left (saved activations, backward scratch)
+        becomes NaN, except the embedding rows `EmbedVis.forward` has just written for THIS forward"""
+        if not debug.POISON or not self.cap:
+            return
+        for rec in self.layers:
+            for t in rec.values():
+                debug.poison_(t)
+        for k, t in self.scratch.items():
+            if k not in keep:
+                debug.poison_(t)
+
 
 class LlamaStack(torch.autograd.Function):
     """All decoder layers + final RMSNorm (HF LlamaModel reached from modified_lm.py:112-116).
@@ -388,6 +401,8 @@ class LlamaStack(torch.autograd.Function):
         cu, pos, Sm = packed if packed is not None else (None, None, S)
         ar.reserve(max(M, B * Sm))
         ar.generation += 1
+        if debug.POISON and E.data_ptr() == ar.scratch["E"].data_ptr():
+            ar.poison()
         x = E
 
         def qkv_proj(n1, i, a):

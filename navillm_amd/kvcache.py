@@ -27,6 +27,7 @@ import torch
 
 from . import lib as _lib
 from . import ops
+from . import debug as _debug
 
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 DEVICE_GREEDY = os.environ.get("NAVILLM_DEVICE_GREEDY", "1") != "0"      # greedy decoding with the loop on the device (no trie)
@@ -63,6 +64,9 @@ class KVCacheLM:
         if b is None:
             self.state = [empty for _ in range(self.B)]
             self._key_ids.clear()
+            if _debug.POISON:                      # NAVILLM_POISON=1: nothing of the forgotten prompts may be read again
+                for t in self.qkv + [self.attn, self.lse]:
+                    _debug.poison_(t)
         else:
             self.state[b] = empty
 

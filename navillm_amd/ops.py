@@ -5,7 +5,10 @@ Every function launches hand-written gfx950 kernels; nothing falls back to torch
 """
 import ctypes
 import torch
+from . import debug as _debug
 from . import lib as _lib
+
+_debug.install_if_enabled()          # NAVILLM_POISON=1: NaN-filled, canaried allocations (navillm_amd/debug.py)
 
 BF16 = torch.bfloat16
 F32 = torch.float32

@@ -457,6 +457,16 @@ def test_episode_forward_attention_one_launch_equals_the_per_step_cache_form(siz
         assert torch.equal(l_seg_new[t], l_seg_old[t]), f"segmented, step {t}"
     for g in g_old:
         assert torch.equal(g_seg_new[g], g_seg_old[g]), ("segmented", g)
+    # the per-step-forward form (sampled / argmax rollouts: every step's forward runs at once, its backward is deferred): one table-step
+    # of the same kernel per step instead of scatter -> strided forward over the K/V cache -> gather
+    monkeypatch.setenv("NAVILLM_EPISODE_ATTN_FWD", "steps")
+    l_ps_old, g_ps_old, _ = _episode(m, cfg, steps, use_prefix=True, teacher_forced=False)
+    monkeypatch.setenv("NAVILLM_EPISODE_ATTN_FWD", "episode")
+    l_ps_new, g_ps_new, _ = _episode(m, cfg, steps, use_prefix=True, teacher_forced=False)
+    for t in range(steps):
+        assert torch.equal(l_ps_new[t], l_ps_old[t]), f"per-step forward, step {t}"
+    for g in g_old:
+        assert torch.equal(g_ps_new[g], g_ps_old[g]), ("per-step forward", g)
 
 
 def test_first_writer_wgrad_store_equals_accumulate_into_zeros(monkeypatch):

@@ -210,8 +210,23 @@ def test_eight_layer_7b_width_episode_gradients_vs_oracle_autograd():
     with torch.no_grad():
         assert m.load_reference_state_dict(P16) == len(P16)
     rc, _, n_rc = _hip_episode(m, cfg, B, steps, "recompute", 83, 512, ragged=37, keep_inputs=True, grad_names=GRAD_NAMES)
-    pr, _, n_pr = _hip_episode(m, cfg, B, steps, "prefix_reuse", 83, 512, ragged=37, grad_names=GRAD_NAMES)
-    _, _, n_tf = _hip_episode(m, cfg, B, steps, "prefix_reuse_tf", 83, 512, ragged=37, grad_names=GRAD_NAMES)
+    pr, _, n_pr = _hip_episode(m, cfg, B, steps, "prefix_reuse", 83, 512, ragged=37, keep_inputs=True, grad_names=GRAD_NAMES)
+    tf, _, n_tf = _hip_episode(m, cfg, B, steps, "prefix_reuse_tf", 83, 512, ragged=37, keep_inputs=True, grad_names=GRAD_NAMES)
+    # the oracle below is fed the inputs the RECOMPUTE run recorded: the three runs must have seen the same episode -- same prompts,
+    # same map tensors, same history tokens (outputs of the fp32 fusion stage) -- or the comparison would blame the LM for the driver
+    for tag, other in (("prefix_reuse", pr), ("prefix_reuse_tf", tf)):
+        for t in range(steps):
+            a, b_ = rc[t], other[t]
+            assert torch.equal(a["ids"], b_["ids"]) and torch.equal(a["am"], b_["am"]) and torch.equal(a["targets"], b_["targets"]), (tag, t)
+            assert torch.equal(a["fuse_embeds"], b_["fuse_embeds"]), (tag, t, "fuse_embeds")
+            for k, v in a["nav"].items():
+                if torch.is_tensor(v):
+                    assert torch.equal(v, b_["nav"][k]), (tag, t, k)
+            for hv_a, hv_b in zip(a["nav"]["hist_vis"], b_["nav"]["hist_vis"]):
+                assert len(hv_a) == len(hv_b) and all(torch.equal(x, y) for x, y in zip(hv_a, hv_b)), (tag, t, "hist_vis")
+            for k, v in a["pin"].items():
+                if torch.is_tensor(v):
+                    assert torch.equal(v, b_["pin"][k]), (tag, t, k)
     del m
     torch.cuda.empty_cache()
     cfg32 = nvcfg.NavConfig(**{**cfg.__dict__, "precision": "fp32"})
