@@ -440,7 +440,7 @@ def reference_launch_extra(a, cfg, model, opt, crit, device, seed):
     ACC = 8
     ep1 = SyntheticEpisodes(cfg, 1, seed=seed, instr_len=a.instr_len, device=device)
     out = {"batch_per_gpu": 1, "gradient_accumulation_step": ACC, "steps_per_window": ACC * STEPS_PER_EPISODE,
-           "windows_timed": 4, "what": "scripts/multi_wo_pretrain.sh:16 on one rank: 8 episodes of B = 1, 6 nav steps each, loss / 1 / 8, one clip + AdamW per window"}
+           "windows_timed": 4, "best_of": 2, "what": "scripts/multi_wo_pretrain.sh:16 on one rank: 8 episodes of B = 1, 6 nav steps each, loss / 1 / 8, one clip + AdamW per window"}
 
     def window(form):
         for e in range(ACC):
@@ -491,6 +491,66 @@ def reference_launch_extra(a, cfg, model, opt, crit, device, seed):
     model.zero_grad()
     model.episode_release()
     model.episode = model._window = model._episode_plain = None      # the B = 1 caches: the next begin_episode() builds its own
+    return out
+
+
+def unmodified_rollout_extra(a, cfg, model, opt, crit, device, seed):
+    """What an UNMODIFIED tasks/agents/mp3d_agent.py + train.py get with INTEGRATION.md's three edits and nothing else (round 6; VERDICT
+    r5 next-2): `navillm_amd.synthetic.reference_train_steps` restates train.py:60-91 around MP3DAgent.rollout (:660-778) call for call
+    -- `model('panorama')`, `model('navigation')`, `torch.softmax(nav_logits / T, 1)`, criterion, `backward()` per step, `loss.item()`
+    per meta-step, clip + step + zero_grad every `gradient_accumulation_step` meta-steps, teacher forcing alternating with DAgger
+    sampling (the multi-task stage, mp3d_agent.py:509-525) -- and never calls begin_episode / finish_episode.  The model opens the
+    prefix-reuse episode itself (per-step-forward form) and the optimizer's clip / the next rollout's first navigation call closes it
+    (NavModel._auto_*).  Beside it, same process and loop: the same rollouts inside EXPLICIT begin_episode(teacher_forced=False) /
+    finish_episode calls, and with NAVILLM_AUTO_EPISODE=0 (the reference's formulation: the whole prompt at every step)."""
+    from navillm_amd import ops
+    from navillm_amd.synthetic import SyntheticEpisodes, reference_train_steps
+    out = {"what": "train.py:60-91 + mp3d_agent.py:660-778 verbatim over the synthetic driver, no begin_episode / finish_episode in the loop; "
+                   "feedback alternates teacher / sample per meta-step; clip = optimizer.clip_grad_norm_(40.) (INTEGRATION.md edit 3)"}
+    for tag, B, accum, metas in (("B8", a.batch, 1, 4), ("B1x8", 1, 8, 16)):
+        epx = SyntheticEpisodes(cfg, B, seed=seed, instr_len=a.instr_len, device=device)
+        res = {"batch_per_gpu": B, "gradient_accumulation_step": accum, "meta_steps_timed": metas, "nav_steps_timed": metas * STEPS_PER_EPISODE}
+        for form in ("automatic", "explicit_per_step_forward", "auto_off_recompute"):
+            try:
+                model.episode_abort()
+                model.zero_grad()
+                model.auto_episode = form == "automatic"
+                model.auto_stats = {"opened": 0, "closed_by": {}}
+                begin = (lambda step: model.begin_episode(epx.prefix_ids(), teacher_forced=False)) if form.startswith("explicit") else None
+                end = (lambda step: model.finish_episode()) if form.startswith("explicit") else None
+
+                def loop(n):
+                    return reference_train_steps(model, opt, crit, epx, n, STEPS_PER_EPISODE, accum=accum, stage="multi", fused_clip=True,
+                                                 on_rollout=begin, after_rollout=end)
+                loop(2 * accum if accum > 1 else 2)            # warm: buffers sized for this shape
+                tm = GemmTimer()
+                tm.install(ops)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loop(metas)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                tm.uninstall()
+                g = tm.summary(layouts=(0, 1, 2))
+                n = metas * STEPS_PER_EPISODE * B
+                res[form] = {"nav_steps_per_s_per_gpu": round(n / dt, 2), "ms_per_step": round(dt / (metas * STEPS_PER_EPISODE) * 1e3, 2),
+                             "gemm_frac_of_mfma_peak": None if g is None else round(g["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4)}
+                if form == "automatic":
+                    res[form]["episodes_opened"] = int(model.auto_stats["opened"])
+                    res[form]["closed_by"] = dict(model.auto_stats["closed_by"])
+            except Exception as e:
+                res[form] = {"error": f"{type(e).__name__}: {e}"}
+                model.episode_abort()
+        try:
+            res["automatic_over_explicit"] = round(res["automatic"]["nav_steps_per_s_per_gpu"] / res["explicit_per_step_forward"]["nav_steps_per_s_per_gpu"], 3)
+        except Exception:
+            pass
+        out[tag] = res
+    model.auto_episode = False
+    model.episode_abort()
+    model.zero_grad()
+    model.episode_release()
+    model.episode = model._window = model._episode_plain = None
     return out
 
 
@@ -697,7 +757,9 @@ def main():
     _JSON_OUT = os.fdopen(json_fd, "w")
     if REHEARSAL:
         os.environ["NAVILLM_COMM"] = "torch"
-    device, rank, world = init_distributed_device(backend="gloo" if REHEARSAL else None, device_index=0 if REHEARSAL else None)
+    # N > 1: the CONTROL plane (rendezvous, barriers, the max-over-ranks clock, the 128-byte RCCL id) runs over gloo, so that nothing of it
+    # depends on RCCL; the gradients travel through the C-ABI communicator (RCCL over xGMI), picked and verified by `dp_preflight` below
+    device, rank, world = init_distributed_device(backend="gloo", device_index=0 if REHEARSAL else None)
     # Host threads for torch's CPU-side glue ops (masks, index lists): a handful.  With the default (all 256 hardware
     # threads) a barrier of the intra-op pool now and then takes 80-100 ms on a tiny tensor (tools/pack_probe.py), longer
     # than a whole forward; and with one process per GPU the ranks must share the host anyway.  (cpu_baseline sets its own.)
@@ -710,11 +772,49 @@ def main():
     from navillm_amd.optim import FlatAdamW
     from navillm_amd.synthetic import SyntheticEpisodes, nav_step
 
+    # ---- N > 1 preflight (round 6): a few seconds of verified collectives BEFORE the 7B model is built.  Picks the transport (the C-ABI
+    # communicator over RCCL; ProcessGroupNCCL if that fails on any rank) or ends the run with ONE JSON line that names the failing stage
+    # per rank -- RCCL with more than one rank has never run on this build's hardware pool, so the first SCALE run must yield a curve or
+    # an actionable error, not a hang
+    preflight, pre_comm, pre_group = None, None, None
+    if world > 1 and not REHEARSAL and os.environ.get("NAVILLM_DP_PREFLIGHT", "1") != "0":
+        from navillm_amd.parallel import dp_preflight
+
+        def error_line(reports, why):
+            return {"metric": "nav-steps/sec (whole node), Vicuna-7B + 36-view scene enc", "value": None, "unit": "nav-steps/s", "n_gpus": world,
+                    "steps": a.steps, "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "bf16", "data": "synthetic", "config": {"workload": f"{a.model}, batch={a.batch}/GPU", "parallelism": f"dp{world}"},
+                    "error": why, "dp_preflight": reports}
+
+        def on_hang(rep):
+            sys.stderr.write(f"[bench rank {rank}] dp_preflight HUNG in stage {rep.get('hang_in_stage')}: {json.dumps(rep)}\n")
+            sys.stderr.flush()
+            if rank == 0:
+                _JSON_OUT.write(json.dumps(error_line([rep], f"dp_preflight hung in stage {rep.get('hang_in_stage')} on rank 0 (watchdog)")) + "\n")
+                _JSON_OUT.flush()
+        preflight, pre_comm, pre_group = dp_preflight(device, rank, world, watchdog_s=float(os.environ.get("NAVILLM_DP_PREFLIGHT_TIMEOUT", "240")),
+                                                      on_hang=on_hang)
+        all_reports = [None] * world
+        dist.all_gather_object(all_reports, preflight)
+        phase(f"dp preflight: transport = {preflight['transport']}")
+        if preflight["transport"] is None:
+            if rank == 0:
+                _JSON_OUT.write(json.dumps(error_line(all_reports, "no working collective transport: see dp_preflight[rank].stages")) + "\n")
+                _JSON_OUT.flush()
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(2)
+        if preflight["transport"] == "torch":
+            os.environ["NAVILLM_COMM"] = "torch"
+        preflight = all_reports
     cfg = make_cfg(a)
     seed = 1234 + rank
     torch.manual_seed(seed)
     model = NavModel(nav_config=cfg, device=device, seed=0)   # same weights on every rank
     model.train()
+    # every number of this file names ITS training form (explicit begin_episode / finish_episode, or the reference's full-prompt recompute);
+    # the automatic episodes the model would otherwise open for training-mode navigation calls are measured in `unmodified_rollout`
+    model.auto_episode = False
     model.reserve_activations(a.batch, a.instr_len + 256)
     opt = FlatAdamW(model, lr=a.lr)
     if world == 1 and os.environ.get("NAVILLM_DP_FORCE"):
@@ -724,7 +824,7 @@ def main():
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29617", world_size=1, rank=0, device_id=device)
         wrapped = NavDataParallel(model, force_sync=True)
     else:
-        wrapped = NavDataParallel(model) if world > 1 else model
+        wrapped = NavDataParallel(model, comm=pre_comm, group=pre_group) if world > 1 else model
         if world > 1 and os.environ.get("NAVILLM_DP_ALGO") is None:
             wrapped.calibrate()        # all-reduce vs reduce-scatter + all-gather on one layer slice: keep the faster
     crit = CrossEntropyLoss()
@@ -799,7 +899,7 @@ def main():
         dt = time.perf_counter() - t0
         if not a.no_profile:
             tm.uninstall()
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if REHEARSAL else device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if (REHEARSAL or not dist.is_initialized() or dist.get_backend() == "gloo") else device)
         if world > 1 and sync_ranks:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item()), tm, loss
@@ -893,6 +993,7 @@ def main():
         for name, fn in (("mixed_task_training_config3", lambda: mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed + 100)),
                          ("long_horizon_config4", lambda: long_horizon_extra(a, cfg, model, wrapped, crit, device, seed + 200)),
                          ("reference_launch_line", lambda: reference_launch_extra(a, cfg, model, opt, crit, device, seed + 400) if world == 1 else None),
+                         ("unmodified_rollout", lambda: unmodified_rollout_extra(a, cfg, model, opt, crit, device, seed + 500) if world == 1 else None),
                          ("fp8_weight_only_13b_config5", lambda: fp8_13b_extra(a, device, seed + 300) if world == 1 else None)):
             phase(name)
             try:        # never take the headline line (or a rank) down
@@ -946,7 +1047,7 @@ def main():
         if world > 1:
             line["dp"] = {"transport": "nv_comm (RCCL, C ABI)" if wrapped.comm is not None else "torch.distributed",
                           "reduce": wrapped.reduce, "algo": wrapped.algo, "calibration": wrapped.calibration,
-                          "rccl_version_per_rank": rccl_versions, "exchange": dp_exchange,
+                          "rccl_version_per_rank": rccl_versions, "exchange": dp_exchange, "control_plane": dist.get_backend(), "preflight": preflight,
                           "what": "gradients averaged once per optimizer step, per-layer slices exchanged from inside the "
                                   "episode's last backward on a side stream"}
         if infer is not None:

@@ -109,12 +109,13 @@ class PrefixEpisode:
         d, L, H = cfg.hidden_size, cfg.num_layers, cfg.num_heads
         dev = model.device
         rows = batch_size * capacity
-        self.cache = [torch.zeros((rows + 1, 3 * d), dtype=BF16, device=dev) for _ in range(L)]   # + a junk row for padding rows
-        self.attn_buf = [torch.zeros((rows + 1, d), dtype=BF16, device=dev) for _ in range(L)]      # (+ junk row: steps are scattered back in finish())
-        self.lse = [torch.zeros((batch_size, H, capacity), dtype=F32, device=dev) for _ in range(L)]
+        # the K/V-cache layout (per-layer post-RoPE q|k|v slab, attention outputs, statistics, the dO / dqkv staging rows) serves the steps that
+        # run AT ONCE over the cached prefix -- per-step-forward episodes, no-grad steps, the `steps` forms of the attention.  Teacher-forced
+        # episodes and accumulation windows read the episode row buffers in place and never touch it: it is allocated on first use
+        # (`_kv_layout`; ADVICE r5: a B = 1 x 8 window carried ~9 GB of it for nothing at 7B)
+        self.cache = self.attn_buf = self.lse = None
+        self.dout_full = self.dqkv_full = None
         self.dkv_acc = [torch.zeros((rows, 2 * d), dtype=F32, device=dev) for _ in range(L)]
-        self.dout_full = torch.zeros((rows + 1, d), dtype=BF16, device=dev)
-        self.dqkv_full = torch.zeros((rows + 1, 3 * d), dtype=BF16, device=dev)
         self.kv0 = torch.zeros((batch_size,), dtype=I32, device=dev)
         self.prefix = None
         self._slab = {}
@@ -133,6 +134,21 @@ class PrefixEpisode:
         self._seg_total = 0                                   # suffix rows of the episode so far that earlier segments already flushed
 
     # ------------------------------------------------------------------ helpers
+    def _kv_layout(self):
+        """the K/V-cache layout's buffers, built when a step first needs them (see __init__)"""
+        if self.cache is not None:
+            return
+        cfg, dev = self.m.cfg, self.m.device
+        d, L, H = cfg.hidden_size, cfg.num_layers, cfg.num_heads
+        rows = self.B * self.cap
+        self.cache = [torch.zeros((rows + 1, 3 * d), dtype=BF16, device=dev) for _ in range(L)]   # + a junk row for padding rows
+        self.attn_buf = [torch.zeros((rows + 1, d), dtype=BF16, device=dev) for _ in range(L)]      # (+ junk row: steps are scattered back in finish())
+        self.lse = [torch.zeros((self.B, H, self.cap), dtype=F32, device=dev) for _ in range(L)]
+        self.dout_full = torch.zeros((rows + 1, d), dtype=BF16, device=dev)
+        self.dqkv_full = torch.zeros((rows + 1, 3 * d), dtype=BF16, device=dev)
+        if self.prefix is not None:
+            self.prefix["cache_valid"] = False         # (whatever ran before did not write the prefix's K/V there)
+
     def _buf(self, tag, shape, dtype=BF16):
         """grow-only scratch tensors keyed by tag (no allocator traffic inside a step)"""
         n = int(np.prod(shape))
@@ -243,7 +259,7 @@ class PrefixEpisode:
         for per_step in self.lse_s:
             for t in per_step:
                 debug.poison_(t)
-        for t in self.lse + self.dkv_acc + self.cache + self.attn_buf + [self.dqkv_full]:
+        for t in self.dkv_acc + ((self.lse + self.cache + self.attn_buf + [self.dqkv_full]) if self.cache is not None else []):
             debug.poison_(t)
         debug.check_guards("at the end of a prefix-reuse episode")
 
@@ -488,6 +504,7 @@ class PrefixEpisode:
         teacher-forced episode whose prefix is still pending -- when a step that cannot be deferred needs the cache"""
         m, cfg, st = self.m, self.m.cfg, self.m.store
         P = self.prefix
+        self._kv_layout()
         B, cap, H, hd, eps, L = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers
         d, ff = cfg.hidden_size, cfg.intermediate_size
         Mp, Lmax, defer = P["Mp"], P["Lmax"], P["defer"]
@@ -537,6 +554,7 @@ class PrefixEpisode:
         """a step that runs NOW (not deferred) reads the prefix's K/V from the per-layer cache: compute the prefix if it is still
         pending, or -- it went through `_forward_lazy` with the in-place attention -- copy its K/V rows into the cache"""
         P = self.prefix
+        self._kv_layout()
         if P.get("pending"):
             self._prefix_forward()
         elif not P.get("cache_valid", True):
@@ -974,6 +992,8 @@ class PrefixEpisode:
             epi_fwd = (os.environ.get("NAVILLM_EPISODE_ATTN_FWD", "episode") != "steps" and f_fits) or bool(P.get("window"))
             if epi_fwd:
                 T, f_tab, f_lse = self._step_table(recs, Bk, Mp)
+            else:
+                self._kv_layout()
             x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_cat, vix_cat, vis_cat, out=self._E[0]["x"][rows])
             for i in range(L):
                 Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
@@ -1221,6 +1241,7 @@ class PrefixEpisode:
         into the cached prefix rows are summed in fp32 by the kernel itself (first step: stored)"""
         m, cfg = self.m, self.m.cfg
         B, cap, H, hd = self.B, self.cap, cfg.num_heads, cfg.head_dim
+        self._kv_layout()
         for n_, r in enumerate(recs):
             sp = r["step"]
             rows = slice(r["r0"], r["r0"] + sp["M"])

@@ -19,7 +19,8 @@ class DeferredLogits:
     def value(self):
         v = self._rec.get("logits")
         if v is None:
-            raise RuntimeError("the logits of a deferred (teacher-forced) step exist after model.finish_episode()")
+            raise RuntimeError("the logits of a deferred (teacher-forced) step exist after model.finish_episode() -- inside an accumulation "
+                               "window (begin_episode(..., accumulate=n)) after the window's last finish_episode() or model.flush_accumulation_window()")
         return v
 
 
@@ -58,7 +59,9 @@ class DeferredLoss:
     def value(self):
         v = self._logits._rec.get("loss_sum")
         if v is None:
-            raise RuntimeError("the value of a deferred (teacher-forced) step loss exists after model.finish_episode()")
+            raise RuntimeError("the value of a deferred (teacher-forced) step loss exists after model.finish_episode() -- inside an "
+                               "accumulation window (begin_episode(..., accumulate=n)) after the window's last finish_episode() or "
+                               "model.flush_accumulation_window()")
         return v * self._scale
 
     def item(self):

@@ -155,6 +155,11 @@ class NavModel(nn.Module):
         self.episode = None              # PrefixEpisode (begin_episode): static prompt prefix computed once per training episode
         self._window = None              # the PrefixEpisode of the open accumulation window (begin_episode(..., accumulate=n))
         self._episode_plain = None       # ... and the non-windowed one it displaced from `self.episode`, kept for the next plain episode
+        # round 6: AUTOMATIC episodes -- the unmodified rollout (mp3d_agent.py:660-778) never calls begin_episode / finish_episode; a
+        # grad-enabled training-mode navigation call then opens the episode itself and whoever needs `.grad` closes it (`_auto_*` below)
+        self.auto_episode = os.environ.get("NAVILLM_AUTO_EPISODE", "1") != "0"
+        self._auto_open = False          # the open episode was opened by forward_navigation, not by the caller
+        self.auto_stats = {"opened": 0, "closed_by": {}}
         self.fp8 = None                  # Fp8DecoderWeights after to_fp8_weight_only()
         self._gen_kv = None              # K/V cache object kept between generate() calls
         self.flop_log = None             # bench: list of ("lm", tokens, sum of S_b^2, backward?) / ("lm_head", rows, backward?) per LM call
@@ -297,6 +302,8 @@ class NavModel(nn.Module):
         `step`, `model.parameters()`, an episode opened without `accumulate`) runs ONE forward + backward over the rows of all n
         (navillm_amd/episode.py::_begin_window).  Logits / loss values exist after that."""
         from .episode import PrefixEpisode
+        if self._auto_open:            # an explicit begin_episode() takes precedence: the automatic episode hands its gradients over first
+            self._auto_close("begin_episode")
         B = len(prefix_ids)
         if max_length is None:         # the tokenizer's left-truncation limit (modified_lm.py:57); the stub tokenizer of the synthetic driver: 1024
             max_length = int(getattr(self.lang_model, "max_length", 1024))
@@ -331,8 +338,85 @@ class NavModel(nn.Module):
         return self.episode
 
     def finish_episode(self):
+        self._auto_open = False
         if self.episode is not None:
             self.episode.finish()
+
+    # ---- automatic episodes (round 6): the fast path behind the reference's OWN call pattern
+    # The rollout of tasks/agents/mp3d_agent.py:660-778 knows nothing of episodes: per step `model('navigation', ...)`, `criterion`,
+    # `backward()`; train.py:86-89 then clips through `model.parameters()` and steps.  So the model opens the episode itself on the
+    # first grad-enabled training-mode navigation call (prefix = the static part of each incoming prompt, per-step-forward form: the
+    # logits are real tensors, `torch.softmax(nav_logits / T, 1)` at mp3d_agent.py:732 and sampled / argmax feedback keep working),
+    # later calls whose prompts start with the same prefixes extend it, and it is closed -- its deferred backward run, every gradient
+    # handed to `.grad` -- by whatever comes first: a navigation call with OTHER prompts (the next rollout), `model.parameters()` /
+    # `named_parameters()` (torch.nn.utils.clip_grad_norm_, train.py:87; also through the NavDataParallel wrapper),
+    # `FlatAdamW.clip_grad_norm_` / `step`, an explicit `begin_episode()`, `state_dict()`-free code never needs it.
+    # `zero_grad()` while such an episode still HOLDS gradients raises (they would leak into the next optimizer step).
+    # NAVILLM_AUTO_EPISODE=0 switches it off (the reference's formulation, every step through the full prompt).
+    def _episode_active(self):
+        """is there an open episode the next grad-enabled navigation step belongs to?  (An accumulation window whose episodes are all
+        finished is open but has no CURRENT episode: a step without begin_episode() then takes the automatic / full path -- ADVICE r5.)"""
+        ep = self.episode
+        if ep is None or ep.prefix is None:
+            return False
+        P = ep.prefix
+        return not (P.get("window") and P["finished"] >= P["episodes"])
+
+    def _auto_prefix_ids(self, batch, ids_l):
+        """the static prefix of every incoming prompt, or None when it cannot be told (then the step takes the full `_lm` path):
+        `batch['prefix_lens']` (callers that tokenise themselves, e.g. the synthetic driver) or the prompt STRINGS + the attached
+        tokenizer (the reference's agents: everything up to "### History:", navillm_amd/prompts.py::static_prefix)"""
+        cfg = self.cfg
+        pl = batch.get("prefix_lens")
+        if pl is not None:
+            pre = [list(ids_l[b][:int(pl[b])]) for b in range(len(ids_l))]
+        elif batch.get("prompts") is not None and self.lang_model.tokenizer is not None and batch.get("input_ids") is None:
+            from .episode import prefix_ids_from_prompts
+            try:
+                pre = prefix_ids_from_prompts(self.lang_model.tokenizer, list(batch["prompts"]))
+            except ValueError:             # a prompt without the "### History:" marker
+                return None
+            pre = [p if ids_l[b][:len(p)] == p else None for b, p in enumerate(pre)]     # (a left-truncated prompt no longer starts with it)
+            if any(p is None for p in pre):
+                return None
+        else:
+            return None
+        special = set(cfg.special_token_ids)
+        limit = int(getattr(self.lang_model, "max_length", 1024))
+        for b, p in enumerate(pre):
+            if not (0 < len(p) < min(len(ids_l[b]), limit, 1024)) or len(ids_l[b]) >= limit or any(t in special for t in p):
+                return None
+        return pre
+
+    def _auto_matches(self, ids_l):
+        """do these prompts belong to the open automatic episode?  (same batch size, every prompt starts with its registered prefix --
+        or was left-truncated at the tokenizer's limit, which `PrefixEpisode.fits` then sends through the full path)"""
+        ep = self.episode
+        P = None if ep is None else ep.prefix
+        if P is None or P.get("window") or len(ids_l) != ep.Bs:
+            return False
+        for j, ids in enumerate(ids_l):
+            lp = int(P["lens"][j])
+            if not (ids[:lp] == P["ids"][j] and lp < len(ids)) and len(ids) < min(ep.cap, ep.max_length):
+                return False
+        return True
+
+    def _auto_close(self, why="caller"):
+        """hand the automatic episode's gradients over to `.grad` (its one deferred backward); a no-op without one"""
+        if not self._auto_open:
+            return
+        self._auto_open = False
+        self.auto_stats["closed_by"][why] = self.auto_stats["closed_by"].get(why, 0) + 1
+        if self.episode is not None and self.episode.prefix is not None:
+            self.episode.finish()
+
+    def grad_handover(self, why="caller"):
+        """everything that is still deferred becomes `.grad` NOW: the open accumulation window and the automatic episode.  Called by
+        whoever is about to read the gradients (FlatAdamW, `parameters()`, NavDataParallel.parameters())."""
+        if getattr(self, "_window", None) is not None:
+            self._window.flush_window()
+        if getattr(self, "_auto_open", False):
+            self._auto_close(why)
 
     def flush_accumulation_window(self):
         """hand over the gradients of the open accumulation window (`begin_episode(..., accumulate=n)`) now; a no-op without one.
@@ -342,7 +426,7 @@ class NavModel(nn.Module):
 
     def episode_release(self):
         """give the prefix-reuse episode buffers back (tens of GB after long episodes); the next begin_episode() re-creates them"""
-        self.flush_accumulation_window()
+        self.grad_handover("episode_release")
         for ep in {id(e): e for e in (self.episode, self._window, self._episode_plain) if e is not None}.values():
             ep.assert_no_pending_gradients("episode_release()")
             ep.prefix = None
@@ -355,6 +439,7 @@ class NavModel(nn.Module):
         embedding and encoder gradients of those steps), steps that ran their backward at once (the non-deferred forms, truncated
         prompts), while the prefix's own backward never runs.  `.grad` then holds a partial, inconsistent sum, so the gradient
         store is marked tainted: `FlatAdamW.clip_grad_norm_` / `step` raise until `zero_grad()`."""
+        self._auto_open = False
         ep = self.episode
         if ep is not None:
             P = ep.prefix
@@ -367,21 +452,22 @@ class NavModel(nn.Module):
             ep.prefix = None
             ep._cursor = 0
 
-    def parameters(self, recurse=True):
-        """nn.Module.parameters, except that asking for the parameters while a prefix-reuse episode still HOLDS gradients (its steps
-        ran backward(), finish_episode() has not run) raises: the only caller of `model.parameters()` inside the reference's
-        training loop is `torch.nn.utils.clip_grad_norm_(model.parameters(), 40.)` (train.py:87), which would clip -- and the
-        optimizer then step on -- the encoder's gradients alone.  (FlatAdamW guards its own clip/step the same way.)"""
-        if getattr(self, "_window", None) is not None:
-            self._window.flush_window()
-        if self.episode is not None:
+    def named_parameters(self, *args, **kwargs):
+        """nn.Module.named_parameters (and, through it, `parameters()`), except that whoever asks for the parameters may be about to read
+        `.grad`: the only caller inside the reference's training loop is `torch.nn.utils.clip_grad_norm_(model.parameters(), 40.)`
+        (train.py:87).  So an open accumulation window and an AUTOMATIC episode hand their gradients over first; an episode the
+        caller opened explicitly and that still HOLDS gradients (its steps ran backward(), finish_episode() has not run) raises --
+        the clip would see, and the optimizer then step on, the encoder's gradients alone.  (FlatAdamW guards its own clip / step the
+        same way.)"""
+        self.grad_handover("parameters")
+        if getattr(self, "episode", None) is not None:
             self.episode.assert_no_pending_gradients("model.parameters() [e.g. torch.nn.utils.clip_grad_norm_(model.parameters(), ...)]")
-        return super().parameters(recurse)
+        return super().named_parameters(*args, **kwargs)
 
-    def _lm_episode(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None):
+    def _lm_episode(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None, layout=None):
         """-> [B, d] over the cached prefix, or None when a prompt of this step was left-truncated at the tokenizer's max_length
         (modified_lm.py:77-87): the caller then runs the step through the full `_lm` path (PrefixEpisode.fits)"""
-        ids_l, vix_l, vis_all, _ = self._vis_layout(ids_cpu, am_cpu, cand_vis, hist_vis, obj_vis)
+        ids_l, vix_l, vis_all, _ = layout if layout is not None else self._vis_layout(ids_cpu, am_cpu, cand_vis, hist_vis, obj_vis)
         if not self.episode.fits(ids_l):
             return None
         return self.episode.lm(ids_l, vix_l, vis_all)
@@ -391,7 +477,17 @@ class NavModel(nn.Module):
             self.kv.reset()
 
     def zero_grad(self, set_to_none=False):
+        self.assert_no_auto_pending("zero_grad()")
         self.store.zero_grad()
+
+    def assert_no_auto_pending(self, what):
+        """an AUTOMATIC episode that still holds gradients at zero_grad(): nothing handed them to `.grad` (no clip through
+        `model.parameters()`, no FlatAdamW) -- zeroing now would make them part of the NEXT optimizer step"""
+        if self._auto_open and self.episode is not None and self.episode.has_pending_gradients():
+            raise RuntimeError(f"{what} while the automatic prefix-reuse episode still holds this step's LM gradients: nothing read "
+                               "them (torch.nn.utils.clip_grad_norm_(model.parameters(), ...) or FlatAdamW.clip_grad_norm_ / step hand "
+                               "them over; with another optimizer call model.grad_handover() before optimizer.step(), or set "
+                               "NAVILLM_AUTO_EPISODE=0)")
 
     def _apply(self, fn, recurse=True):
         # .to(device)/.cuda() on the right device are no-ops; anything else would break the flat views
@@ -777,9 +873,20 @@ class NavModel(nn.Module):
         if self.kv is not None and not torch.is_grad_enabled() and self.kv.B == B:
             hk = self._hist_keys(batch["hist_vis"])
             Hs_cls = self._lm_cached(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, hist_keys=hk)
-        elif self.episode is not None and self.episode.prefix is not None and torch.is_grad_enabled():
-            Hs_cls = self._lm_episode(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis)
-            if Hs_cls is None:         # a left-truncated prompt: this step takes the reference's formulation, gradients land in .grad at once
+        elif torch.is_grad_enabled() and (self._episode_active() or (self.auto_episode and self.training and self.fp8 is None)):
+            layout = self._vis_layout(ids, am, cand_embeds, hist_vis, None)
+            if self._auto_open and not self._auto_matches(layout[0]):
+                self._auto_close("next_episode")           # other prompts: the previous rollout's episode hands its gradients over
+            if not self._episode_active():
+                pre = self._auto_prefix_ids(batch, layout[0]) if (self.auto_episode and self.training) else None
+                if pre is not None:
+                    self.begin_episode(pre, teacher_forced=False)     # (flushes an accumulation window whose episodes are all finished)
+                    self._auto_open = True
+                    self.auto_stats["opened"] += 1
+            Hs_cls = None
+            if self._episode_active():
+                Hs_cls = self._lm_episode(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, layout=layout)
+            if Hs_cls is None:         # a left-truncated prompt (or no prefix to be told): this step takes the reference's formulation, gradients land in .grad at once
                 Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)
         else:
             Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)

@@ -161,9 +161,10 @@ class FlatAdamW(torch.optim.Optimizer):
         if self.store.tainted:
             raise RuntimeError(f"the gradient buffers are inconsistent ({self.store.tainted}): call zero_grad() before the next "
                                "clip_grad_norm_ / step")
-        flush = getattr(self.model, "flush_accumulation_window", None)
-        if flush is not None:
-            flush()                      # an open accumulation window (begin_episode(..., accumulate=n)) hands its gradients over now
+        hand = getattr(self.model, "grad_handover", None)
+        if hand is not None:
+            hand("optimizer")            # an open accumulation window (begin_episode(..., accumulate=n)) and an AUTOMATIC episode
+                                         # (NavModel._auto_*: opened by the unmodified rollout's navigation calls) hand their gradients over now
         ep = getattr(self.model, "episode", None)
         if ep is not None and ep.has_pending_gradients():
             raise RuntimeError("optimizer step inside an open prefix-reuse episode: call model.finish_episode() (under "
@@ -211,6 +212,9 @@ class FlatAdamW(torch.optim.Optimizer):
         self._zeroed_at = st.grad_writes
 
     def zero_grad(self, set_to_none=False):
+        chk = getattr(self.model, "assert_no_auto_pending", None)
+        if chk is not None:
+            chk("optimizer.zero_grad()")
         z, self._zeroed_segs = self._zeroed_segs, None
         # the fused form is only valid when nothing wrote a gradient since step() zeroed the updated segments (with
         # step(); backward(); zero_grad() only the gaps were cleared and the new gradients survived into the next step)

@@ -210,6 +210,22 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
     def forward(self, *a, **k):
         return self.module(*a, **k)
 
+    def named_parameters(self, *args, **kwargs):
+        """`torch.nn.utils.clip_grad_norm_(model.parameters(), 40.)` on the WRAPPED model (train.py:87): nn.Module walks the children's
+        `_parameters` dicts directly, so `NavModel.named_parameters` never runs -- without this the clip norm would be taken before an
+        open accumulation window / automatic episode had handed its gradients to `.grad`, and `FlatAdamW.step()` would then add them
+        AFTER the clip coefficient was fixed.  `reduce="step"`: what was accumulated locally is averaged over the
+        ranks here as well, so the norm the caller computes is the norm of the gradient the optimizer applies."""
+        m = self.module
+        hand = getattr(m, "grad_handover", None)
+        if hand is not None:
+            hand("parameters")
+        if getattr(m, "episode", None) is not None:
+            m.episode.assert_no_pending_gradients("model.parameters() [e.g. torch.nn.utils.clip_grad_norm_(model.parameters(), ...)]")
+        if getattr(self, "_pending", False):
+            self.flush()
+        return super().named_parameters(*args, **kwargs)
+
     # ---- transport
     def _world(self):
         if self.comm is not None:
@@ -427,6 +443,134 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
                 self._launch(t)
             self._join()
         self._pending = False
+
+
+def dp_preflight(device, rank, world, watchdog_s=240.0, on_hang=None, try_nv_comm=True):
+    """A few seconds of collectives before an N-rank job commits to its transport (round 6): RCCL through the
+    C-ABI communicator has never run with more than one rank on this build's hardware pool, so the first multi-GPU launch must end in
+    a measurement or in an ACTIONABLE error, never in a hang or a bare traceback.
+
+    Requires an initialised torch.distributed group (any backend; the bench uses gloo, so the control plane does not depend on RCCL).
+    Stages, each recorded with its outcome and time:
+      control_plane      barrier + a tiny all-reduce over the existing group;
+      nv_comm_init       `RcclComm(rank, world)`: dlopen'd librccl, unique-id exchange, ncclCommInitRank, the enum self-check all-reduce;
+      nv_comm_collective mean all-reduce of a known bf16 vector + reduce-scatter / all-gather of 16 MB, values verified, timed;
+      agreement          every rank reports; the transport is nv_comm only if ALL ranks passed;
+      torch_nccl_group   (fallback, only if nv_comm failed somewhere) `dist.new_group(backend="nccl")` -- ProcessGroupNCCL is RCCL behind
+                         torch's own binding -- with one verified all-reduce; the data path then runs through torch.distributed.
+    A watchdog (`watchdog_s`) calls `on_hang(report)` and exits the process when a stage never returns (an RCCL bootstrap that hangs).
+    -> (report dict, comm or None, group or None): transport = report["transport"] in {"nv_comm", "torch", None}."""
+    import threading
+    report = {"rank": rank, "world": world, "stages": [], "transport": None,
+              "env": {k: v for k, v in os.environ.items() if k.startswith(("HSA_", "NCCL_", "RCCL_", "HIP_VISIBLE", "ROCR_VISIBLE"))},
+              "control_backend": dist.get_backend() if dist.is_initialized() else None}
+    state = {"stage": "start", "done": False}
+
+    def hang():
+        if state["done"]:
+            return
+        report["hang_in_stage"] = state["stage"]
+        try:
+            if on_hang is not None:
+                on_hang(report)
+        finally:
+            os._exit(3)
+    timer = threading.Timer(watchdog_s, hang)
+    timer.daemon = True
+    timer.start()
+
+    def stage(name, fn):
+        state["stage"] = name
+        t0 = time.perf_counter()
+        rec = {"stage": name, "ok": False}
+        try:
+            out = fn()
+            rec["ok"] = True
+            if isinstance(out, dict):
+                rec.update(out)
+            return out
+        except BaseException as e:                      # (a failing collective must be REPORTED, and by every rank)
+            rec["error"] = f"{type(e).__name__}: {e}"[:600]
+            return None
+        finally:
+            rec["seconds"] = round(time.perf_counter() - t0, 3)
+            report["stages"].append(rec)
+
+    def agree(flag):
+        """min over ranks of a 0/1 flag through the control plane"""
+        t = torch.tensor([1.0 if flag else 0.0])
+        if dist.get_backend() == "nccl":
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def control():
+        dist.barrier()
+        return {"all_ranks_present": agree(True)}
+    stage("control_plane", control)
+    on_gpu = torch.device(device).type == "cuda"
+    comm = None
+    if try_nv_comm and on_gpu:
+        def init():
+            c = RcclComm(rank, world)
+            v = int(c._L.nv_comm_rccl_version())
+            return {"comm": c, "rccl_version": v}
+        r = stage("nv_comm_init", init)
+        if r is not None:
+            comm = r["comm"]
+            report["stages"][-1].pop("comm", None)
+
+        def collective():
+            x = torch.full((4096,), float(rank + 1), dtype=torch.bfloat16, device=device)
+            comm.allreduce_mean_(x)
+            want = sum(range(1, world + 1)) / world
+            torch.cuda.synchronize()
+            assert abs(float(x.float().mean()) - want) < 0.02 * want, (float(x.float().mean()), want)
+            n = (16 << 20) // 2 // world * world
+            y = torch.full((n,), float(rank + 1), dtype=torch.bfloat16, device=device)
+            comm.reduce_scatter_all_gather_mean_(y)          # warm
+            torch.cuda.synchronize()
+            y.fill_(float(rank + 1))
+            t0 = time.perf_counter()
+            comm.reduce_scatter_all_gather_mean_(y)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert abs(float(y.float().mean()) - want) < 0.02 * want, (float(y.float().mean()), want)
+            return {"rs_ag_16MB_ms": round(dt * 1e3, 3), "busbw_GBps": round(2 * (world - 1) / world * n * 2 / dt / 1e9, 1)}
+        ok = comm is not None and stage("nv_comm_collective", collective) is not None
+    else:
+        ok = False
+        report["stages"].append({"stage": "nv_comm_init", "ok": False, "skipped": "no GPU" if not on_gpu else "not requested"})
+    all_ok = stage("agreement", lambda: {"nv_comm_on_every_rank": agree(ok)})
+    group = None
+    if all_ok is not None and all_ok["nv_comm_on_every_rank"]:
+        report["transport"] = "nv_comm"
+    else:
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:
+                pass
+            comm = None
+
+        def fallback():
+            g = dist.new_group(backend="nccl" if on_gpu else "gloo")
+            x = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=device if on_gpu else "cpu")
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=g)
+            if on_gpu:
+                torch.cuda.synchronize()
+            assert abs(float(x[0]) - sum(range(1, world + 1))) < 1e-3, float(x[0])
+            return {"group": g}
+        r = stage("torch_nccl_group", fallback)
+        if r is not None:
+            report["stages"][-1].pop("group", None)
+        f_ok = stage("agreement_fallback", lambda: {"torch_group_on_every_rank": agree(r is not None)})
+        if f_ok is not None and f_ok["torch_group_on_every_rank"]:
+            group = r["group"]
+            report["transport"] = "torch"
+    state["done"] = True
+    timer.cancel()
+    return report, comm, group
 
 
 def broadcast_task_id(task_id, device, group=None, comm=None):

@@ -360,6 +360,10 @@ class SyntheticEpisodes:
             seqs.append(self._tok_cache[b] + self.tok.encode(p[len(head):], self.instr[b])[1:])
         ids, am = self.tok.pad_left(seqs)
         self.S_hist.append(ids.shape[1])
+        # a caller that tokenises itself tells the model how many leading tokens of each prompt never change inside the episode (the
+        # reference's agents hand over prompt STRINGS instead and the model cuts at "### History:" itself): what an AUTOMATIC episode
+        # registers as its prefix (NavModel._auto_prefix_ids)
+        nav["prefix_lens"] = [len(self._tok_cache[b]) for b in range(self.B)]
         return ids, am
 
     def prefix_ids(self):
@@ -447,6 +451,75 @@ def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accu
             raise NotImplementedError(feedback)
         ep.advance(nav, actions, out["fuse_embeds"])
     return loss, logits
+
+
+def reference_rollout(model, criterion, ep, steps, feedback="teacher", train_ml=1.0, accum=1, temperature=1.0):
+    """`MP3DAgent.rollout`'s training branch, call for call (tasks/agents/mp3d_agent.py:660-778), with the synthetic driver standing
+    in for MatterSim: per step `model('panorama')`, the map update, `model('navigation')`, `torch.softmax(nav_logits / T, 1)` (:732 --
+    the logits must be real tensors), `cnt_loss += criterion(...) * train_ml / batch_size / gradient_accumulation_step`, `ml_loss +=
+    cnt_loss.detach()`, `cnt_loss.backward()` at once (:750-757), the action from the teacher or one draw from `Categorical(nav_probs)`
+    (:759-769), the history append (:774-778); every step but the last inside `model.no_sync()` when the model is a
+    DistributedDataParallel (:661-676).  NOTHING else: no begin_episode / finish_episode -- what an unmodified agent does to the model.
+    -> ml_loss (a tensor; the caller reads `.item()`, train.py:83)"""
+    ml_loss, cnt_loss = 0., 0.
+    is_ddp = isinstance(model, torch.nn.parallel.DistributedDataParallel)
+    inner = model.module if hasattr(model, "module") else model
+    for t in range(steps):
+        last = t == steps - 1
+        context = model.no_sync if (is_ddp and not last) else contextlib.nullcontext
+        with context():
+            pin = ep.panorama_inputs()
+            pano = model("panorama", pin)
+            pe, pm = pano["pano_embeds"], pano["pano_masks"]
+            ep.update_maps(pe, pm, pin["cand_vpids"])
+            nav = ep.nav_inputs(pe, pm, pin["cand_vpids"])
+            ids, am = ep.tokenise(nav, inner.lang_model.cls_token[0])
+            nav["input_ids"], nav["attention_mask"] = ids, am
+            nav_outs = model("navigation", nav)
+            nav_logits = nav_outs["fuse_logits"]
+            nav_probs = torch.softmax(nav_logits / temperature, 1)
+            nav_targets = ep.teacher_targets(nav, last)
+            cnt_loss += criterion(nav_logits, ops.h2d(nav_targets, nav_logits.device)) * train_ml / ep.B / accum
+            ml_loss += cnt_loss.detach()
+            cnt_loss.backward()
+            cnt_loss = 0.
+            if feedback == "teacher":
+                a_t = nav_targets
+            elif feedback == "sample":
+                a_t = torch.distributions.Categorical(nav_probs.float()).sample().detach().cpu()
+            else:
+                raise NotImplementedError(feedback)
+            ep.advance(nav, a_t, nav_outs["fuse_embeds"])
+    return ml_loss
+
+
+def reference_train_steps(model, optimizer, criterion, ep, meta_steps, steps, accum=1, stage="pretrain", on_rollout=None, fused_clip=False,
+                          after_rollout=None):
+    """`train_one_epoch` (train.py:60-91) around `MP3DAgent.train` (mp3d_agent.py:497-527), verbatim in what it does to the model and the
+    optimizer: per meta-step one rollout (`stage == 'pretrain'` or every even step: teacher forcing, else DAgger sampling), `loss.item()`
+    for the running metrics, and every `accum` meta-steps `torch.nn.utils.clip_grad_norm_(model.parameters(), 40.)`, `optimizer.step()`,
+    `optimizer.zero_grad()`.  `ep.reset()` draws the next batch of episodes.  fused_clip: INTEGRATION.md's edit 3 (`optimizer.clip_grad_norm_(40.)`,
+    the clip folded into FlatAdamW's update kernel) instead of torch's clip.  on_rollout / after_rollout(step): hooks around a rollout
+    (tests and the bench wrap the SAME loop in explicit begin_episode / finish_episode calls for the comparison).
+    -> the per-meta-step loss values"""
+    losses = []
+    for step in range(meta_steps):
+        ep.reset()
+        if on_rollout is not None:
+            on_rollout(step)
+        fb = "teacher" if (stage == "pretrain" or step % 2 == 0) else "sample"
+        loss = reference_rollout(model, criterion, ep, steps, feedback=fb, accum=accum) * accum
+        if after_rollout is not None:
+            after_rollout(step)
+        losses.append(loss.item())
+        if (step + 1) % accum == 0:
+            if fused_clip:
+                optimizer.clip_grad_norm_(40.)
+            else:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 40.)
+            optimizer.step()
+            optimizer.zero_grad()
+    return losses
 
 
 # --------------------------------------------------------------------------- inference: two episode batches in flight

@@ -189,3 +189,45 @@ def test_data_parallel_gradient_mean_world2_gloo():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def _preflight_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from navillm_amd.parallel import init_distributed_device, NavDataParallel, dp_preflight
+    dev, r, w = init_distributed_device(backend="gloo")
+    rep, comm, group = dp_preflight(dev, rank, world, watchdog_s=120.0)
+    names = [s["stage"] for s in rep["stages"]]
+    ok = names == ["control_plane", "nv_comm_init", "agreement", "torch_nccl_group", "agreement_fallback"], names
+    ok = ok[0] if isinstance(ok, tuple) else ok
+    # no GPU here: the C-ABI communicator is skipped on every rank, the ranks AGREE on the fallback, and the group it hands back works
+    ok &= rep["transport"] == "torch" and comm is None and group is not None and rep["control_backend"] == "gloo"
+    ok &= rep["stages"][1]["ok"] is False and "skipped" in rep["stages"][1] and rep["stages"][3]["ok"] and rep["stages"][0]["all_ranks_present"]
+    cfg = tiny_cfg("bf16")
+    model = _FakeModel(cfg)
+    ddp = NavDataParallel(model, group=group, reduce="step")
+    model.store.grad["f32"].fill_(float(rank + 1))
+    ddp._pending = True
+    ddp.flush()
+    ok &= bool((model.store.grad["f32"] == 1.5).all())
+    import json
+    json.dumps(rep)                                   # the report goes into the bench's JSON line as it is
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_preflight_picks_a_transport_every_rank_agrees_on_world2_gloo():
+    """round 6: `bench.py --gpus N` runs `dp_preflight` before it builds the model.  On CPU ranks the C-ABI
+    communicator is not available, so this exercises the other half: every rank records its stages, the ranks agree through the
+    control plane, the fallback group is created collectively and verified, and the report is JSON-serialisable."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_preflight_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)], res

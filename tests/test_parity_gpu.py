@@ -179,7 +179,7 @@ def _g12_prefix_ids(z, meta):
     return out
 
 
-@pytest.mark.parametrize("mode", ["recompute", "prefix_reuse"])
+@pytest.mark.parametrize("mode", ["recompute", "prefix_reuse", "auto"])
 def test_g12_episode_accumulated_gradients_vs_reference(mode):
     """VERDICT r2 missing #3: a reference-pinned MULTI-STEP episode.  Three nav steps the way the rollout runs them
     (mp3d_agent.py:659-778): panorama -> navigation with the history THIS model's previous steps produced -> CE * train_ml / B /
@@ -191,7 +191,15 @@ def test_g12_episode_accumulated_gradients_vs_reference(mode):
     zb, zf = gold("g12_episode_bf16.npz"), gold("g12_episode_fp32.npz")
     meta = meta_of(zb)
     B = meta["B"]
-    m = build(tiny_cfg("bf16"))
+    if mode == "auto":
+        # round 6: the AUTOMATIC episode -- no begin_episode / finish_episode: the model opens the episode on the first training-mode
+        # navigation call (prefix = the lengths the batch carries) and `model.parameters()` (train.py:87's clip) closes it.  Automatic
+        # episodes exist in training mode only; the fixture is the reference in eval(), so the dropout rates are zero instead
+        m = build(tiny_cfg("bf16", feat_dropout=0.0, enc_dropout=0.0))
+        m.train()
+        m.auto_episode = True
+    else:
+        m = build(tiny_cfg("bf16"))
     m.zero_grad()
     m.store.touched.clear()
     crit = CrossEntropyLoss()
@@ -208,8 +216,12 @@ def test_g12_episode_accumulated_gradients_vs_reference(mode):
         for k in ("gmap_img_embeds", "gmap_step_ids", "gmap_pos_fts", "gmap_visited_masks", "gmap_masks", "pano_masks", "vp_pos_fts"):
             batch[k] = batch[k].to(DEV)
         batch["input_ids"], batch["attention_mask"] = T(zt["input_ids"]), T(zt["attention_mask"])
+        if mode == "auto":
+            batch["prefix_lens"] = list(ms["prefix_lens"])
         torch.manual_seed(ms["seed_before_nav"])
         out = m("navigation", batch)
+        if mode == "auto":
+            assert m._auto_open and m.auto_stats["opened"] == 1 and m.episode.prefix is not None
         assert maxerr(out["fuse_embeds"], zt["fuse_embeds"]) < 3e-5
         lg, l16, l32 = out["fuse_logits"], T(zt["fuse_logits"]), T(zf[pre + "fuse_logits"])
         ulps = bf16_ulps_at_scale(lg, l16)
@@ -221,7 +233,7 @@ def test_g12_episode_accumulated_gradients_vs_reference(mode):
         # logits are then BIT-IDENTICAL to the recompute path run in that frame (tests/test_parity_r4_gpu.py::
         # test_rope_frame_isolated_on_the_reference_episode_g12, profiles/r04_parity_rope_frame.txt) -- so its bound is the batch-frame
         # bound + the measured frame effect (1.0) with the same x1.5 margin
-        assert ulps <= ULPS_LOGITS + (ULPS_FRAME if mode == "prefix_reuse" else 0.0) and e_hip <= 1.5 * e_ref + 4e-3
+        assert ulps <= ULPS_LOGITS + (ULPS_FRAME if mode != "recompute" else 0.0) and e_hip <= 1.5 * e_ref + 4e-3
         top2 = torch.topk(l16.masked_fill(~torch.isfinite(l16), -1e9), 2, dim=1).values
         for b in range(B):
             if (top2[b, 0] - top2[b, 1]).item() > 2 * gap:
@@ -238,6 +250,10 @@ def test_g12_episode_accumulated_gradients_vs_reference(mode):
         m.finish_episode()
         assert m.episode.prefix is None
         print(f"[g12 prefix_reuse] token rows: prefix {stats['prefix_rows']} once + suffixes {stats['suffix_rows']}")
+    if mode == "auto":
+        assert m.episode.has_pending_gradients()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1e9)          # train.py:87 (a bound that never clips): hands the episode over
+        assert not m._auto_open and m.episode.prefix is None and m.auto_stats["closed_by"] == {"parameters": 1}
     torch.cuda.synchronize()
     assert [len(h) for h in hist] == meta["hist_final"]
     assert maxerr(torch.stack([v for h in hist for v in h], 0), zb["hist_final_flat"]) < 3e-5
