@@ -282,6 +282,9 @@ class PrefixEpisode:
 
     def _weights(self, i):
         """(Wqkv, Wo, Wgu, Wd, w1, w2, their six gradient views) of layer i: views of the flat store, built once"""
+        st = self.m.store
+        if st._upd is not None:
+            st.wait_params(layer=i)            # (an optimizer update of this layer still on the side stream: FlatAdamW.step, round 6)
         w = self._wcache.get(i)
         if w is None:
             w = self._wcache[i] = self._weights_uncached(i)

@@ -76,6 +76,42 @@ class FlatStore:
         self.grad = {g: torch.zeros(tot[g], dtype=dt[g], device=self.device) for g in tot}
         self.exp_avg = None
         self.exp_avg_sq = None
+        self._upd = None          # an AdamW update of the LM group still running on the optimizer's side stream (FlatAdamW.step, round 6)
+
+    # ---- asynchronous update of the LM group (navillm_amd/optim.py::FlatAdamW.step with overlap): the update kernels run on a side stream,
+    # decoder layer by decoder layer in flat order, while the launch stream goes on with the next episode's scene-encoder / fusion steps
+    # (fp32 group: updated on the launch stream itself).  Whoever touches LM-group parameters OR gradients next waits for exactly the
+    # part it needs: every accessor below (`p`, `g`, `qkv`, `gate_up`, `lm_head_padded`) and `PrefixEpisode._weights` calls
+    # `wait_params`; code that reads the raw buffers (`state_dict`, the native decoder's pointer table, the DP broadcast, the next clip /
+    # step, a full zero_grad) calls it without arguments = waits for all of it.  Other streams (the DP exchange, the wgrad side stream)
+    # fork from the launch stream AFTER it has waited, so they inherit the order.
+    def begin_async_update(self, stream, head_ev, layer_evs, done_ev, home):
+        self._upd = {"stream": stream, "head": head_ev, "layer": layer_evs, "done": done_ev, "home": home, "waited": set()}
+
+    def wait_params(self, name=None, layer=None):
+        """order the CURRENT stream after the pending update of `name` / decoder layer `layer` (None, None: all of the LM group)"""
+        u = self._upd
+        if u is None:
+            return
+        import torch
+        if layer is None and name is not None:
+            if name.startswith("lang_model.model.layers."):
+                layer = int(name.split(".")[3])
+            elif name != "lang_model.model.embed_tokens.weight":
+                name = None                                  # final norm, lm_head, the heads: the tail of the buffer = the whole update
+        key = ("L", layer) if layer is not None else (("H",) if name is not None else ("D",))
+        cur = torch.cuda.current_stream(self.device)
+        at_home = cur.cuda_stream == u["home"]
+        if at_home and (key in u["waited"] or ("D",) in u["waited"]):
+            return
+        if cur.cuda_stream == u["stream"].cuda_stream:
+            return
+        ev = u["layer"][layer] if layer is not None else (u["head"] if name is not None else u["done"])
+        cur.wait_event(ev)
+        if at_home:
+            u["waited"].add(key)
+            if key == ("D",):
+                self._upd = None                             # the launch stream is behind the whole update: nothing left to order
 
     # ---- views
     def _view(self, store, name):
@@ -86,11 +122,15 @@ class FlatStore:
     def p(self, name):
         if name in getattr(self, "released", ()):
             raise RuntimeError(f"{name}: released by to_fp8_weight_only() (weight-only fp8 deployment); use NavModel.lm_w / lm_linear")
+        if self._upd is not None and self.group_of[name] == "lm":
+            self.wait_params(name)
         return self._view(self.param, name)
 
     def g(self, name):
         if self.grad is None:
             raise RuntimeError("gradient buffers were released by to_fp8_weight_only(): the fp8 deployment is inference only")
+        if self._upd is not None and self.group_of[name] == "lm":
+            self.wait_params(name)                 # (the update zeroes the gradient it consumes: writers are ordered behind it too)
         return self._view(self.grad, name)
 
     def _packed(self, store, first, last):
@@ -106,12 +146,16 @@ class FlatStore:
 
     def qkv(self, i, grad=False):
         p = f"lang_model.model.layers.{i}.self_attn."
+        if self._upd is not None:
+            self.wait_params(layer=i)
         v = self._packed(self.grad if grad else self.param, p + "q_proj.weight", p + "v_proj.weight")
         assert v.shape[0] == 3 * self.cfg.hidden_size, "q/k/v must be adjacent and unpadded"
         return v
 
     def gate_up(self, i, grad=False):
         p = f"lang_model.model.layers.{i}.mlp."
+        if self._upd is not None:
+            self.wait_params(layer=i)
         v = self._packed(self.grad if grad else self.param, p + "gate_proj.weight", p + "up_proj.weight")
         assert v.shape[0] == 2 * self.cfg.intermediate_size, "gate/up must be adjacent and unpadded"
         return v
@@ -119,6 +163,8 @@ class FlatStore:
     def lm_head_padded(self, grad=False):
         o = self.offsets["lang_model.lm_head.weight"]
         d = self.cfg.hidden_size
+        if self._upd is not None:
+            self.wait_params()
         return (self.grad if grad else self.param)["lm"][o:o + self.vocab_pad * d].view(self.vocab_pad, d)
 
     def layer_slice(self, i):
@@ -145,6 +191,7 @@ class FlatStore:
 
     def zero_grad(self):
         self.tainted = None
+        self.wait_params()
         if self.grad is not None:
             for g in self.grad.values():
                 g.zero_()
@@ -154,6 +201,7 @@ class FlatStore:
         """Inference deployment with weight-only fp8 decoder weights (navillm_amd/fp8.py): drop the bf16 copies of the decoder's
         Linear weights and every gradient buffer.  The remaining LM-dtype tensors (embeddings, norms, lm_head, heads) move to
         a compact buffer; the nn.Parameters are re-pointed at it (released ones become empty)."""
+        self.wait_params()
         gone = lambda n: n.startswith("lang_model.model.layers.") and n.endswith("_proj.weight")
         keep = [n for n in self.names["lm"] if not gone(n)]
         off, new_off = 0, {}
@@ -189,6 +237,7 @@ class FlatStore:
             self.exp_avg_sq = {g: torch.zeros_like(t) for g, t in self.param.items()}
 
     def load_state_dict_tensors(self, sd):
+        self.wait_params()
         for n in self.offsets:
             if n in sd:
                 self.p(n).copy_(sd[n].to(self.p(n).dtype))

@@ -78,6 +78,7 @@ class KVCacheLM:
     # ------------------------------------------------------------------ the native layer loop (navillm_amd/csrc/decoder_runtime.cpp)
     def _decoder(self):
         m, cfg, st = self.model, self.model.cfg, self.model.store
+        st.wait_params()           # the native layer loop reads the weights through raw pointers: behind a pending optimizer update
         # keyed by what the layer table POINTS AT, not by the stream (with the stream in the key the decoder was torn
         # down and rebuilt -- ~200 ctypes calls and a fresh split-K workspace allocation + memset -- INSIDE the hipGraph capture of
         # the greedy step, which runs on a side stream).  The split-K workspace handed to the decoder is only touched by the tile

@@ -200,6 +200,7 @@ class NavModel(nn.Module):
         """Load a NaviLLM checkpoint's `model_state_dict` (tools/optims.py:12-24 semantics: strip `module.`,
         skip shape mismatches)."""
         n = 0
+        self.store.wait_params()
         for k, v in sd.items():
             k = k[7:] if k.startswith("module.") else k
             if k in self._named and tuple(v.shape) == tuple(self._named[k].shape):
@@ -462,7 +463,13 @@ class NavModel(nn.Module):
         self.grad_handover("parameters")
         if getattr(self, "episode", None) is not None:
             self.episode.assert_no_pending_gradients("model.parameters() [e.g. torch.nn.utils.clip_grad_norm_(model.parameters(), ...)]")
+        if getattr(self, "store", None) is not None:
+            self.store.wait_params()           # an optimizer update still on its side stream: the caller is about to read parameters / .grad
         return super().named_parameters(*args, **kwargs)
+
+    def state_dict(self, *args, **kwargs):
+        self.store.wait_params()
+        return super().state_dict(*args, **kwargs)
 
     def _lm_episode(self, ids_cpu, am_cpu, cand_vis=None, hist_vis=None, obj_vis=None, layout=None):
         """-> [B, d] over the cached prefix, or None when a prompt of this step was left-truncated at the tokenizer's max_length

@@ -149,6 +149,15 @@ class FlatAdamW(torch.optim.Optimizer):
         self.fused_zero_grad = os.environ.get("NAVILLM_ADAMW_ZERO_GRAD", "1") != "0"
         self._zeroed_segs = None
         self._zeroed_at = -1            # FlatStore.grad_writes when step() zeroed them: any gradient write since invalidates the fused form
+        # round 6: the LM group's update runs on a SIDE stream, decoder layer by decoder layer, while the launch stream goes on with the next
+        # episode's scene-encoder / fusion steps (fp32 group: updated on the launch stream); whoever touches an LM parameter or gradient next
+        # waits for the part it needs (FlatStore.wait_params).  In a teacher-forced episode the LM weights are not read again before
+        # finish_episode()'s batched forward, so most of the 18 ms of weight streaming disappear behind latency-bound launches.
+        # NAVILLM_ADAMW_OVERLAP=0 / `optimizer.overlap_update = False`: everything on the launch stream, as before.  Contract: between
+        # step() and the next model call read parameters through model.parameters() / state_dict() (they join the update); a tensor handle
+        # kept from BEFORE the step is ordered only after torch.cuda.synchronize().
+        self.overlap_update = os.environ.get("NAVILLM_ADAMW_OVERLAP", "1") != "0" and self.store.device.type == "cuda"
+        self._side = None
 
     # `lr` as an attribute mirrors the single param group (tests / callers that poke it directly)
     @property
@@ -172,6 +181,7 @@ class FlatAdamW(torch.optim.Optimizer):
                                "clip_grad_norm_ / step, or model.episode_abort() to drop the episode")
 
     def _dp_flush(self):
+        self.store.wait_params()         # a previous step's update still on the side stream: the gradients it zeroes / the clip vector it reads
         self._no_open_episode()
         dp = getattr(self.model, "_dp", None)
         if dp is not None:
@@ -203,10 +213,38 @@ class FlatAdamW(torch.optim.Optimizer):
         g0 = self.param_groups[0]
         lr, (b1, b2), eps, wd = g0["lr"], g0["betas"], g0["eps"], g0["weight_decay"]
         clip = self._clip if self._clip_valid else None
-        for grp, segs in self._segs.items():
-            for s, e, born in segs:
-                ops.adamw_(st.param[grp][s:e], st.grad[grp][s:e], st.exp_avg[grp][s:e], st.exp_avg_sq[grp][s:e],
-                           self.step_count - born, lr, b1, b2, eps, wd, clip=clip, zero_grad=self.fused_zero_grad)
+
+        def upd(grp, s, e, born):
+            ops.adamw_(st.param[grp][s:e], st.grad[grp][s:e], st.exp_avg[grp][s:e], st.exp_avg_sq[grp][s:e],
+                       self.step_count - born, lr, b1, b2, eps, wd, clip=clip, zero_grad=self.fused_zero_grad)
+        if self.overlap_update and st.grad["lm"].is_cuda:
+            # fp32 group (scene encoder, fusion: the very next launches read it) on the launch stream; the LM group on the side stream, cut
+            # at the decoder layers' boundaries (the kernel is elementwise: the same values whatever the cut) with an event per layer
+            for s, e, born in self._segs.get("f32", ()):
+                upd("f32", s, e, born)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=st.device)
+            main = torch.cuda.current_stream(st.device)
+            L = st.cfg.num_layers
+            bounds = [st.layer_slice(i) for i in range(L)]
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                def run(lo, hi):
+                    for s, e, born in self._segs.get("lm", ()):
+                        a, b = max(s, lo), min(e, hi)
+                        if a < b:
+                            upd("lm", a, b, born)
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                    return ev
+                head = run(0, bounds[0][0])
+                layer = [run(lo, hi) for lo, hi in bounds]
+                done = run(bounds[-1][1], st.total["lm"])
+            st.begin_async_update(self._side, head, layer, done, main.cuda_stream)
+        else:
+            for grp, segs in self._segs.items():
+                for s, e, born in segs:
+                    upd(grp, s, e, born)
         self._clip_valid = False
         self._zeroed_segs = {grp: [(s, e) for s, e, _ in segs] for grp, segs in self._segs.items()} if self.fused_zero_grad else None
         self._zeroed_at = st.grad_writes
@@ -235,6 +273,7 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def state_dict(self):
         """flat-layout state (copies); not a torch.optim.AdamW state dict"""
+        self.store.wait_params()
         return {"step": self.step_count, "born": dict(self.born),
                 "exp_avg": {g: t.clone() for g, t in self.store.exp_avg.items()},
                 "exp_avg_sq": {g: t.clone() for g, t in self.store.exp_avg_sq.items()},
@@ -243,9 +282,11 @@ class FlatAdamW(torch.optim.Optimizer):
     def reference_state_dict(self, names=None):
         """this optimizer's state as the reference's `optimizer.state_dict()` (per-parameter, indexed in `names` order; default
         the installed transformers' `named_parameters()` order)"""
+        self.store.wait_params()
         return flat_to_reference_optimizer(self.store, self.step_count, self.born, self.param_groups[0], names)
 
     def load_state_dict(self, sd, names=None):
+        self.store.wait_params()
         if "state" in sd and "param_groups" in sd and "exp_avg" not in sd:
             # a reference checkpoint's `optimizer` entry (tools/optims.py:26-29 calls exactly this method with it)
             self.step_count, self.born, hyper = reference_optimizer_to_flat(self.store, sd, names)

@@ -244,6 +244,7 @@ class NavDataParallel(torch.nn.parallel.DistributedDataParallel):
     @torch.no_grad()
     def broadcast_parameters(self):
         """DDP's initial rank-0 broadcast."""
+        self.module.store.wait_params()
         if self.comm is not None:
             if self.comm.world > 1:
                 for t in self.module.store.param.values():

@@ -102,3 +102,57 @@ def test_isolation_and_episode_parity_under_poisoned_buffers():
     tail = (r.stdout or "")[-3000:] + (r.stderr or "")[-1500:]
     assert r.returncode == 0, tail
     assert "NAVILLM_POISON = 1" in r.stdout, tail
+
+
+@pytest.mark.parametrize("size", ["mid", "7b-width"])
+def test_overlapped_optimizer_update_equals_the_serial_update(size):
+    """round 6: FlatAdamW.step() runs the LM group's update on a side stream, decoder layer by decoder layer, while the launch stream
+    goes on with the next episode's scene-encoder steps; every consumer of an LM parameter / gradient waits for the part it needs
+    (FlatStore.wait_params).  The same training loop -- teacher-forced episodes, per-step-forward episodes, a recompute step, an
+    immediate no-grad navigation step and a state_dict() read right after step() -- with the overlap on and off: bit-identical
+    logits, parameters and optimizer moments."""
+    from navillm_amd.synthetic import SyntheticEpisodes, nav_step, prefix_reuse_episode
+    from navillm_amd.losses import CrossEntropyLoss
+    from navillm_amd.optim import FlatAdamW
+    cfg = _cfg(size)
+    crit = CrossEntropyLoss()
+
+    def run(overlap):
+        m = _model(cfg)
+        opt = FlatAdamW(m, lr=3e-3)
+        opt.overlap_update = overlap
+        ep = SyntheticEpisodes(cfg, 2, seed=91, instr_len=120, device=torch.device(DEV))
+        seen = []
+        for k, form in enumerate(["teacher", "teacher", "per_step", "recompute", "teacher"]):
+            ep.reset()
+            torch.manual_seed(700 + k)
+            if form == "recompute":
+                nav_step(m, crit, ep, train=True, last=True)
+            else:
+                prefix_reuse_episode(m, crit, ep, 2, teacher_forced=(form == "teacher"))
+            opt.clip_grad_norm_(40.0)
+            opt.step()
+            opt.zero_grad()
+            if overlap and k == 0:
+                assert m.store._upd is not None, "the LM group's update should still be pending on the side stream's events"
+            if k == 1:
+                # consumers right behind the step: a no-grad navigation step (full LM path) ...
+                m.eval()
+                with torch.no_grad():
+                    _, lg = nav_step(m, crit, ep, train=False)
+                seen.append(lg.detach().float().cpu())
+                m.train()
+            if k == 2:
+                # ... and the checkpoint writer
+                sd = m.state_dict()
+                seen.append(sd["lang_model.model.layers.1.mlp.down_proj.weight"].detach().float().cpu())
+                seen.append(sd["out_head.0.weight"].detach().float().cpu())
+        torch.cuda.synchronize()
+        return seen, {g: t.detach().clone() for g, t in m.store.param.items()}, {g: t.detach().clone() for g, t in m.store.exp_avg_sq.items()}
+    s1, p1, v1 = run(True)
+    s0, p0, v0 = run(False)
+    for a, b in zip(s1, s0):
+        assert torch.equal(a, b)
+    for g in p0:
+        assert torch.equal(p1[g], p0[g]), ("param", g)
+        assert torch.equal(v1[g], v0[g]), ("exp_avg_sq", g)
