@@ -32,12 +32,26 @@ _registry = []          # (weakref to the payload view, payload bytes, tag)
 stats = {"guarded": 0, "checks": 0, "poisoned": 0}
 
 
-def poison_(t):
-    """overwrite a floating-point tensor with NaN (integer tensors are left alone: a poisoned index would fault the GPU)"""
+SENTINEL = 1.0e4        # the finite poison of buffers that are read UNDER A MASK by design (see poison_)
+
+
+def poison_(t, masked_reads=False):
+    """overwrite a floating-point tensor with NaN (integer tensors are left alone: a poisoned index would fault the GPU).
+    masked_reads: the buffer is one the kernels read under a mask BY DESIGN -- the K/V-cache layout: the strided attention kernels run
+    every sample over the batch's longest length, and a shorter sample's rows beyond its own length enter as keys that the causal mask
+    zeroes (P = 0) and as queries whose outputs nobody gathers (dO = 0).  `0 x NaN` would turn that design into NaN, so these slabs
+    get a large FINITE sentinel instead: multiplied by the zeros it is harmless, read for real it throws the logits off by orders of
+    magnitude (every parity test fails)."""
     if POISON and t is not None and t.dtype in _FLOAT and t.numel():
-        t.fill_(float("nan"))
+        t.fill_(SENTINEL if masked_reads else float("nan"))
         stats["poisoned"] += 1
     return t
+
+
+def guard_bytes(nbytes):
+    """canary size per side: 4 KiB, growing with the buffer up to 1 MiB (a row of the big slabs is 8-64 KiB: an overrun by whole
+    rows must still land in the canary)"""
+    return max(GUARD, min(1 << 20, (nbytes // 64 + 4095) // 4096 * 4096))
 
 
 def _guarded(shape, dtype, device, fill, requires_grad=False, tag=""):
@@ -47,10 +61,11 @@ def _guarded(shape, dtype, device, fill, requires_grad=False, tag=""):
         n *= s
     nbytes = n * dtype.itemsize
     pad = (-nbytes) % 512                    # the upper canary starts on a 512-B boundary, as the allocator's blocks do
-    base = _orig["empty"]((GUARD + nbytes + pad + GUARD,), dtype=torch.uint8, device=device)
-    base[:GUARD].fill_(_PAT)
-    base[GUARD + nbytes:].fill_(_PAT)
-    t = base[GUARD:GUARD + nbytes].view(dtype).view(shape)
+    G = guard_bytes(nbytes)
+    base = _orig["empty"]((G + nbytes + pad + G,), dtype=torch.uint8, device=device)
+    base[:G].fill_(_PAT)
+    base[G + nbytes:].fill_(_PAT)
+    t = base[G:G + nbytes].view(dtype).view(shape)
     if fill == "zero":
         t.zero_()
     elif dtype in _FLOAT and n:
@@ -144,16 +159,18 @@ def check_guards(where=""):
         if t is None:
             continue
         base = _raw(t)
-        if base.numel() < 2 * GUARD + nbytes:
+        G = guard_bytes(nbytes)
+        if base.numel() < 2 * G + nbytes:
             continue
         live.append((t, base, nbytes, tag))
-        b = (base[:GUARD] != _PAT).any() | (base[GUARD + nbytes:] != _PAT).any()
+        b = (base[:G] != _PAT).any() | (base[G + nbytes:] != _PAT).any()
         bad = b if bad is None else (bad | b)
     stats["checks"] += 1
     if bad is not None and bool(bad.item()):
         for t, base, nbytes, tag in live:
-            lo = int((base[:GUARD] != _PAT).sum())
-            hi = int((base[GUARD + nbytes:] != _PAT).sum())
+            G = guard_bytes(nbytes)
+            lo = int((base[:G] != _PAT).sum())
+            hi = int((base[G + nbytes:] != _PAT).sum())
             if lo or hi:
                 raise RuntimeError(f"NAVILLM_POISON: canary overrun {where}: buffer {tuple(t.shape)} {t.dtype} {tag!r} -- {lo} bytes changed below, "
                                    f"{hi} bytes changed above its {nbytes} payload bytes")

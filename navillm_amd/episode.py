@@ -259,8 +259,10 @@ class PrefixEpisode:
         for per_step in self.lse_s:
             for t in per_step:
                 debug.poison_(t)
-        for t in self.dkv_acc + ((self.lse + self.cache + self.attn_buf + [self.dqkv_full]) if self.cache is not None else []):
+        for t in self.dkv_acc + ((self.lse + [self.dqkv_full]) if self.cache is not None else []):
             debug.poison_(t)
+        for t in (self.cache + self.attn_buf) if self.cache is not None else []:
+            debug.poison_(t, masked_reads=True)        # the K/V-cache layout: read under the causal mask by design (debug.poison_)
         debug.check_guards("at the end of a prefix-reuse episode")
 
     def _rows_fit(self, cap):
@@ -1117,6 +1119,8 @@ class PrefixEpisode:
             # matrices of a layer is written exactly once per walk).  Later segments of a long episode / a second accumulation read-add.
             wacc = ops.EPI_STORE if (getattr(st, "layers_zero", False) and seg_before == 0
                                      and os.environ.get("NAVILLM_WGRAD_STORE", "1") != "0") else ops.EPI_ACCUM
+            if wacc == ops.EPI_STORE and debug.POISON:
+                st.assert_layers_zero("finish_episode()")
             st.touch_layers()
             dp0 = getattr(m, "_dp", None)
             if dp0 is not None and final:

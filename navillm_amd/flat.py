@@ -182,6 +182,17 @@ class FlatStore:
         self.grad_writes += 1           # a gradient was (or is about to be) written: FlatAdamW's fused zero-grad bookkeeping is stale
         self.touched.update(names)
 
+    def assert_layers_zero(self, where):
+        """debug (NAVILLM_POISON=1): a first-writer STORE of the decoder layers' weight gradients is only correct while those
+        buffers really hold zeros -- every writer must have gone through touch() / touch_layers(), which clear `layers_zero`"""
+        import torch
+        s0, _ = self.layer_slice(0)
+        _, e1 = self.layer_slice(self.cfg.num_layers - 1)
+        nz = int(torch.count_nonzero(self.grad["lm"][s0:e1]))
+        if nz:
+            raise RuntimeError(f"{where}: FlatStore.layers_zero is set but {nz} decoder-layer gradient elements are non-zero -- a writer "
+                               "bypassed FlatStore.touch() / touch_layers() (a STORE epilogue would have dropped its gradient)")
+
     def touch_layers(self):
         """every decoder-layer tensor + the final norm (LlamaStack.backward accumulates into all of them)"""
         self.layers_zero = False

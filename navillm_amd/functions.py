@@ -481,6 +481,8 @@ class LlamaStack(torch.autograd.Function):
         # round 5: the first backward after a zero_grad() (FlatStore.layers_zero) STORES its weight gradients -- every matrix is written
         # exactly once per backward -- instead of read-accumulating zeros; every later backward of the optimizer step read-adds
         WACC = ops.EPI_STORE if (getattr(st, "layers_zero", False) and os.environ.get("NAVILLM_WGRAD_STORE", "1") != "0") else ops.EPI_ACCUM
+        if WACC == ops.EPI_STORE and debug.POISON:
+            st.assert_layers_zero("LlamaStack.backward")
         st.touch_layers()
         model._dp_begin_backward()
         L_full = L

@@ -65,8 +65,9 @@ class KVCacheLM:
             self.state = [empty for _ in range(self.B)]
             self._key_ids.clear()
             if _debug.POISON:                      # NAVILLM_POISON=1: nothing of the forgotten prompts may be read again
-                for t in self.qkv + [self.attn, self.lse]:
-                    _debug.poison_(t)
+                for t in self.qkv + [self.attn]:
+                    _debug.poison_(t, masked_reads=True)
+                _debug.poison_(self.lse)
         else:
             self.state[b] = empty
 
