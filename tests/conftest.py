@@ -45,6 +45,17 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """printed in -q runs too: what the debug instrumentation did (tests/test_episode_isolation_gpu.py reads it from its child process)"""
+    try:
+        from navillm_amd import debug
+    except Exception:
+        return
+    if debug.POISON:
+        terminalreporter.write_line(f"navillm_amd poison: {debug.stats['guarded']} guarded allocations, {debug.stats['poisoned']} re-poisoned "
+                                    f"buffers, {debug.stats['checks']} canary checks; order = {config.getoption('--nv-order') or 'file order'}")
+
+
 def pytest_report_header(config):
     return [f"navillm_amd: test order = {config.getoption('--nv-order') or 'file order'}, NAVILLM_POISON = {os.environ.get('NAVILLM_POISON', '0')}"]
 

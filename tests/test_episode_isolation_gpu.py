@@ -101,7 +101,7 @@ def test_isolation_and_episode_parity_under_poisoned_buffers():
                        capture_output=True, text=True, timeout=1500)
     tail = (r.stdout or "")[-3000:] + (r.stderr or "")[-1500:]
     assert r.returncode == 0, tail
-    assert "NAVILLM_POISON = 1" in r.stdout, tail
+    assert "navillm_amd poison:" in r.stdout and " 0 guarded allocations" not in r.stdout, tail
 
 
 @pytest.mark.parametrize("size", ["mid", "7b-width"])
