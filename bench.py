@@ -500,8 +500,10 @@ def unmodified_rollout_extra(a, cfg, model, opt, crit, device, seed):
     -- `model('panorama')`, `model('navigation')`, `torch.softmax(nav_logits / T, 1)`, criterion, `backward()` per step, `loss.item()`
     per meta-step, clip + step + zero_grad every `gradient_accumulation_step` meta-steps, teacher forcing alternating with DAgger
     sampling (the multi-task stage, mp3d_agent.py:509-525) -- and never calls begin_episode / finish_episode.  The model opens the
-    prefix-reuse episode itself (per-step-forward form) and the optimizer's clip / the next rollout's first navigation call closes it
-    (NavModel._auto_*).  Beside it, same process and loop: the same rollouts inside EXPLICIT begin_episode(teacher_forced=False) /
+    prefix-reuse episode itself and the optimizer's clip / the next rollout's first navigation call closes it (NavModel._auto_*); `fuse_logits`
+    is a LazyLogits handle: a teacher-forced rollout never reads it and its LM forward runs as ONE batch when `loss.item()` asks for the
+    value, a sampled rollout reads it at every step and runs step by step (`automatic`; `automatic_step_form`: NAVILLM_AUTO_EPISODE=step,
+    plain tensors, every forward at once).  Beside it, same process and loop: the same rollouts inside EXPLICIT begin_episode(teacher_forced=False) /
     finish_episode calls, and with NAVILLM_AUTO_EPISODE=0 (the reference's formulation: the whole prompt at every step)."""
     from navillm_amd import ops
     from navillm_amd.synthetic import SyntheticEpisodes, reference_train_steps
@@ -510,17 +512,22 @@ def unmodified_rollout_extra(a, cfg, model, opt, crit, device, seed):
     for tag, B, accum, metas in (("B8", a.batch, 1, 4), ("B1x8", 1, 8, 16)):
         epx = SyntheticEpisodes(cfg, B, seed=seed, instr_len=a.instr_len, device=device)
         res = {"batch_per_gpu": B, "gradient_accumulation_step": accum, "meta_steps_timed": metas, "nav_steps_timed": metas * STEPS_PER_EPISODE}
-        for form in ("automatic", "explicit_per_step_forward", "auto_off_recompute"):
+        # (name, automatic episodes?, their form, training stage: "multi" alternates teacher forcing and sampling per meta-step, "pretrain" is
+        # all teacher-forced -- mp3d_agent.py:509-525)
+        forms = (("automatic", True, "lazy", "multi"), ("automatic_pretrain_stage", True, "lazy", "pretrain"),
+                 ("automatic_step_form", True, "step", "multi"), ("explicit_per_step_forward", False, None, "multi"),
+                 ("auto_off_recompute", False, None, "multi"))
+        for form, auto, aform, stage in forms:
             try:
                 model.episode_abort()
                 model.zero_grad()
-                model.auto_episode = form == "automatic"
+                model.auto_episode, model.auto_form = auto, (aform or "lazy")
                 model.auto_stats = {"opened": 0, "closed_by": {}}
                 begin = (lambda step: model.begin_episode(epx.prefix_ids(), teacher_forced=False)) if form.startswith("explicit") else None
                 end = (lambda step: model.finish_episode()) if form.startswith("explicit") else None
 
-                def loop(n):
-                    return reference_train_steps(model, opt, crit, epx, n, STEPS_PER_EPISODE, accum=accum, stage="multi", fused_clip=True,
+                def loop(n, stage=stage):
+                    return reference_train_steps(model, opt, crit, epx, n, STEPS_PER_EPISODE, accum=accum, stage=stage, fused_clip=True,
                                                  on_rollout=begin, after_rollout=end)
                 loop(2 * accum if accum > 1 else 2)            # warm: buffers sized for this shape
                 tm = GemmTimer()
@@ -535,7 +542,7 @@ def unmodified_rollout_extra(a, cfg, model, opt, crit, device, seed):
                 n = metas * STEPS_PER_EPISODE * B
                 res[form] = {"nav_steps_per_s_per_gpu": round(n / dt, 2), "ms_per_step": round(dt / (metas * STEPS_PER_EPISODE) * 1e3, 2),
                              "gemm_frac_of_mfma_peak": None if g is None else round(g["tflops"] / MFMA_BF16_PEAK_TFLOPS, 4)}
-                if form == "automatic":
+                if auto:
                     res[form]["episodes_opened"] = int(model.auto_stats["opened"])
                     res[form]["closed_by"] = dict(model.auto_stats["closed_by"])
             except Exception as e:

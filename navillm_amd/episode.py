@@ -964,11 +964,14 @@ class PrefixEpisode:
         Bk = P.get("nb", self.B)                         # prefix slots in use (an accumulation window: all its episodes' samples)
         Mp, R = P["Mp"], self._cursor
         # round 5: a prefix that has not gone through the decoder yet (begin() of a teacher-forced episode only builds its tables) joins
-        # the batch: rows [0, R) instead of [Mp, R)
+        # the batch: rows [0, R) instead of [Mp, R).  round 6: `recs` is the TAIL of the recorded steps that has not gone through the
+        # decoder yet -- everything in finish(), or (automatic episodes: LazyLogits) the steps since the last time a step's logits were
+        # read; rows [r_lo, R) with r_lo = the first of them
         pend = bool(P.get("pending"))
-        r_lo = 0 if pend else Mp
+        r_lo = 0 if pend else recs[0]["r0"]
         rows = slice(r_lo, R)
-        assert recs[0]["r0"] == Mp and recs[-1]["r0"] + recs[-1]["step"]["M"] == R
+        assert (recs[0]["r0"] == Mp or not pend) and recs[-1]["r0"] + recs[-1]["step"]["M"] == R and \
+            all(a["r0"] + a["step"]["M"] == b_["r0"] for a, b_ in zip(recs, recs[1:])), "the pending steps must be the tail of the episode's rows"
         with torch.no_grad():
             vis_parts, vix_parts, off = [], [], 0
             for r in recs:
@@ -983,12 +986,12 @@ class PrefixEpisode:
             pos_cat = torch.cat(([P["pos"]] if pend else []) + [r["step"]["pos"] for r in recs])
             vix_cat = torch.cat(([P["vix_dev"]] if pend else []) + vix_parts)
             vis_cat = torch.cat(vis_parts, 0).contiguous() if vis_parts else None
-            while len(self.lse_s) < len(recs) and not P.get("window"):
+            while len(self.lse_s) < max(r["k"] for r in recs) + 1 and not P.get("window"):
                 self.lse_s.append([torch.zeros((self.B, H, cap), dtype=F32, device=m.device) for _ in range(L)])
             last_cat = torch.cat([r["step"]["last"] + (r["r0"] - Mp) for r in recs])      # each step's last rows, relative to row Mp
-            last_x = last_cat + Mp if pend else last_cat                                   # ... relative to the first row of this batch
+            last_x = last_cat + (Mp - r_lo)                                                # ... relative to the first row of this batch
             prune_top = os.environ.get("NAVILLM_EPISODE_PRUNE_TOP", "1") != "0" and L > 1
-            P.pop("top", None)
+            top_now = None
             # round 5: the attention of ALL steps in one launch per layer, reading the episode buffers in place (nv_attn_fwd_episode_bf16;
             # NAVILLM_EPISODE_ATTN_FWD=steps: round 4's scatter -> strided forward -> gather per step, bit-identical)
             # (the kernel's grid is (slots * heads, table-steps * query blocks): beyond 65 535 in y the per-step cache form runs -- ADVICE r5)
@@ -1032,7 +1035,8 @@ class PrefixEpisode:
                     gu_l = ops.gemm_bf16(ops.NT, n2_l, Wgu)
                     h_l = ops.swiglu_fwd(gu_l)
                     x_last = ops.gemm_bf16(ops.NT, h_l, Wd, R=x1_l, epilogue=ops.EPI_RESID)
-                    P["top"] = dict(idx=last_cat, attn=attn_l, x1=x1_l, n2=n2_l, r2=r2_l, gu=gu_l, h=h_l)
+                    top_now = dict(idx=last_cat, attn=attn_l, x1=x1_l, n2=n2_l, r2=r2_l, gu=gu_l, h=h_l)
+                    P.setdefault("tops", []).append(top_now)
                     break
                 x1 = ops.gemm_bf16(ops.NT, E["attn"][rows], Wo, out=E["x1"][rows], R=x, epilogue=ops.EPI_RESID)
                 n2, _ = ops.rmsnorm_fwd(x1, w2, eps, out=E["n2"][rows], rstd=E32["r2"][rows])
@@ -1040,23 +1044,35 @@ class PrefixEpisode:
                 h = ops.swiglu_fwd(gu, out=E["h"][rows])
                 x = ops.gemm_bf16(ops.NT, h, Wd, out=self._E[i + 1]["x"][rows] if i + 1 < L else self._buf("lz.x2", (max(R, self._ecap), d))[:R - r_lo], R=x1,
                                   epilogue=ops.EPI_RESID)
-            if not (prune_top and "top" in P):
+            if top_now is None:
                 x_last = ops.gather_rows_bf16(x, last_x)
             if pend:
                 P["pending"] = False
                 P["cache_valid"] = not epi_fwd
             Hs_all, rstdf = ops.rmsnorm_fwd(x_last, st.p("lang_model.model.norm.weight"), eps)
-        # action head + CE on every step (tiny: B rows each), through the same autograd functions the non-lazy path uses
-        Hs_leaf = Hs_all.detach().requires_grad_(True)
+            for t, r in enumerate(recs):
+                r["x_last"], r["rstdf"], r["Hs"] = x_last[t * B:(t + 1) * B], rstdf[t * B:(t + 1) * B], Hs_all[t * B:(t + 1) * B]
+
+    def _heads_deferred(self, recs):
+        """action head + CE of every recorded step that is through the decoder (`r["Hs"]`) and has no logits / no loss gradient yet (tiny:
+        B rows each), through the same autograd functions the non-lazy path uses; their gradient w.r.t. the steps' last rows becomes
+        `dH`, exactly what a step's backward() records in the non-lazy form.  A step whose logits were READ (`force_logits(live=True)`)
+        carries its own autograd graph and gets its `dH` from the rollout's backward() instead."""
+        from . import functions as Fn
+        m, B = self.m, self.Bs
+        todo = [r for r in recs if r.get("lazy") and r.get("Hs") is not None and r.get("logits_live") is None and
+                (r.get("logits") is None or (r.get("targets") is not None and r["dH"] is None))]
+        if not todo:
+            return
+        Hs_leaf = torch.cat([r["Hs"] for r in todo], 0).detach().requires_grad_(True)
         total = None
         with torch.enable_grad():
-            for t, r in enumerate(recs):
-                r["x_last"], r["rstdf"] = x_last[t * B:(t + 1) * B], rstdf[t * B:(t + 1) * B]
+            for t, r in enumerate(todo):
                 col, mask_not = r["head"]
                 pred = Fn.HeadBF16.apply(Hs_leaf[t * B:(t + 1) * B], m, "out_head.0")
                 logits = torch.gather(pred, 1, col).masked_fill(mask_not, float("-inf"))
                 r["logits"] = logits.detach()
-                if r.get("targets") is not None:
+                if r.get("targets") is not None and r["dH"] is None:
                     ls = Fn.ActionCE.apply(logits, r["targets"])
                     r["loss_sum"] = ls.detach()
                     total = ls * r["scale"] if total is None else total + ls * r["scale"]
@@ -1064,9 +1080,62 @@ class PrefixEpisode:
                 total.backward()
         if Hs_leaf.grad is not None:
             g = Hs_leaf.grad
-            for t, r in enumerate(recs):
-                if r.get("targets") is not None:
+            for t, r in enumerate(todo):
+                if r.get("targets") is not None and r["dH"] is None:
                     r["dH"] = g[t * B:(t + 1) * B].contiguous()
+
+    def _forward_pending(self):
+        """every recorded step that has not gone through the decoder yet does so now, as one batch (with the prefix, if that is still
+        pending); -> the recorded steps"""
+        P = self.prefix
+        if P is None:
+            raise RuntimeError("the episode of this step is over (finish_episode() ran, or it was aborted): its deferred values are gone")
+        if P.get("window"):
+            raise RuntimeError("inside an accumulation window (begin_episode(..., accumulate=n)) the logits / loss values exist after the "
+                               "window's last finish_episode() or model.flush_accumulation_window()")
+        recs = P["recs"]
+        pending = [r for r in recs if r.get("lazy") and r["x_last"] is None]
+        if pending:
+            self._forward_lazy(pending)
+        return recs
+
+    def force_logits(self, rec, live=True):
+        """automatic episodes (losses.LazyLogits): the rollout READS the logits of step `rec` -- a sampled / argmax step, or a caller that
+        looks at them.  All pending steps run their LM forward now; live: -> the step's logits as a tensor connected to autograd (head ->
+        gather -> mask on a leaf whose gradient hook records the step's `dH`), so whatever loss the rollout builds on it and
+        backpropagates reaches the deferred backward; not live: only the value (`rec["logits"]`)."""
+        from . import functions as Fn
+        if rec.get("logits_live") is not None:
+            return rec["logits_live"]
+        if not live and rec.get("logits") is not None:
+            return rec["logits"]
+        if not any(r is rec for r in (self.prefix or {}).get("recs", ())):
+            if rec.get("logits") is not None:
+                return rec["logits"]                      # (the episode is over: the value it left behind; no graph any more)
+            raise RuntimeError("the episode of this step is over and its logits were never computed")
+        self._forward_pending()
+        if not live:
+            self._heads_deferred([rec])
+            return rec["logits"]
+        if rec.get("targets") is not None:
+            raise RuntimeError("the logits of this step are read AFTER its deferred loss ran backward(): read them before the loss, or not at all")
+        self.stats["forced_reads"] = self.stats.get("forced_reads", 0) + 1
+        leaf = rec["Hs"].detach().clone().requires_grad_(True)
+
+        def hook(g, rec=rec):
+            rec["dH"] = g.contiguous().clone() if rec["dH"] is None else rec["dH"] + g
+        leaf.register_hook(hook)
+        with torch.enable_grad():
+            col, mask_not = rec["head"]
+            pred = Fn.HeadBF16.apply(leaf, self.m, "out_head.0")
+            rec["logits_live"] = torch.gather(pred, 1, col).masked_fill(mask_not, float("-inf"))
+        rec["logits"] = rec["logits_live"].detach()
+        return rec["logits_live"]
+
+    def force_values(self):
+        """automatic episodes: the rollout reads a deferred LOSS value (`loss.item()`, train.py:83): the pending steps' batched forward +
+        the heads and losses of every step -- not the backward"""
+        self._heads_deferred(self._forward_pending())
 
     def flush_segment(self):
         """long episodes (round 4; VERDICT r3 next #7a): run the deferred backward of the steps recorded SO FAR -- their rows [Mp, R) only:
@@ -1093,8 +1162,10 @@ class PrefixEpisode:
         Bk = P.get("nb", self.B)                         # prefix slots in use (an accumulation window: all its episodes' samples)
         Mp, R = P["Mp"], self._cursor
         recs = P["recs"]
-        if any(r.get("lazy") and r["x_last"] is None for r in recs):
-            self._forward_lazy(recs)                    # teacher-forced episode: the steps' forward, all at once, then heads + losses
+        pending = [r for r in recs if r.get("lazy") and r["x_last"] is None]
+        if pending:
+            self._forward_lazy(pending)                 # teacher-forced episode: the steps' forward, all at once (those still pending)
+        self._heads_deferred(recs)                      # ... then heads + losses of every step that has none yet
         live = [r for r in recs if r["dH"] is not None]
         seg_before = P["segments"]                      # segments already flushed: dkv_acc holds their sums
         if final:
@@ -1134,7 +1205,13 @@ class PrefixEpisode:
             dqkv, dgu, dh = self._buf("b.dqkv", (Rc, 3 * d))[:R], self._buf("b.dgu", (Rc, 2 * ff))[:R], self._buf("b.dh", (Rc, ff))[:R]
             # gradient of the stack's output: the final norm's backward on each step's B last-token rows; zero everywhere else (the
             # top layer's prefix rows feed nothing, a step without a backward contributes nothing)
-            top = P.pop("top", None)                   # teacher-forced forward with the pruned top layer: its tail ran on T*B rows
+            tops = P.pop("tops", None)                 # teacher-forced forward with the pruned top layer: its tail ran on T*B rows
+            top = None
+            if tops:
+                # (one entry per forward batch, in step order: one in a teacher-forced episode, several when an automatic episode's
+                # logits were read on the way)
+                top = tops[0] if len(tops) == 1 else {k: torch.cat([t_[k] for t_ in tops], 0) for k in tops[0]}
+                assert top["idx"].numel() == len(recs) * B, "every recorded step went through the batched forward exactly once"
             if top is not None:
                 dxl = torch.zeros((len(recs) * B, d), dtype=BF16, device=m.device)
                 for t, r in enumerate(recs):

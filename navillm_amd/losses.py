@@ -24,6 +24,148 @@ class DeferredLogits:
         return v
 
 
+class LazyLogits(DeferredLogits):
+    """`fuse_logits` of a navigation step inside an AUTOMATIC episode (round 6; NavModel._auto_*): the unmodified rollout
+    (tasks/agents/mp3d_agent.py:660-778) cannot say whether it will read the logits -- under teacher forcing it never does (the action is
+    the teacher's, :760-761), under DAgger sampling / argmax it does at once (:762-769) -- so the model hands out a handle that decides by
+    itself:
+      * `nav_logits / T`, `x * f` and `torch.softmax(x, dim)` (line :732, computed unconditionally) stay LAZY (`LazyExpr`);
+      * anything that needs numbers -- `.float()`, `.max(1)`, `Categorical(nav_probs.float())`, `.cpu()`, any other torch function --
+        FORCES the step: every navigation step of the episode that has not gone through the decoder yet does so now, as one batch
+        (`PrefixEpisode.force_logits`), and the handle answers with a real tensor that is connected to autograd (a later
+        `criterion(...).backward()` reaches the step through it);
+      * `criterion(handle, targets)` on a step that was never forced is a `DeferredLoss`, exactly as in an explicit teacher-forced
+        episode; `loss.item()` (train.py:83) then runs the batched forward of whatever is pending + the heads, not the backward.
+    So a teacher-forced rollout batches the LM forward of all its steps (the headline form), a sampled one runs step by step, and the
+    rollout is the reference's, line for line."""
+
+    forceable = True
+
+    def __init__(self, episode, rec, shape, device, dtype):
+        super().__init__(episode, rec)
+        self.shape, self.device, self.dtype = torch.Size(shape), device, dtype
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return len(self.shape)
+
+    @property
+    def value(self):
+        v = self._rec.get("logits")
+        if v is None:
+            self._episode.force_logits(self._rec, live=False)
+            v = self._rec["logits"]
+        return v
+
+    def force(self):
+        """the step's logits as a REAL tensor, connected to autograd: the steps recorded so far run their LM forward now"""
+        return self._episode.force_logits(self._rec, live=True)
+
+    def _lazy(self, fn):
+        return LazyExpr(self, fn)
+
+    def __truediv__(self, f):
+        return self._lazy(lambda x: x / f)
+
+    def __mul__(self, f):
+        return self._lazy(lambda x: x * f)
+
+    __rmul__ = __mul__
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _LAZY_FUNCS and len(args) >= 1 and isinstance(args[0], (LazyLogits, LazyExpr)):
+            rest = args[1:]
+            return args[0]._lazy(lambda x: func(x, *rest, **kwargs))
+        return func(*_force_all(args), **_force_all(kwargs))
+
+    def __getattr__(self, name):
+        # (only reached for attributes this class does not define: tensor methods -- they need the numbers)
+        if name.startswith("__") or name in ("_episode", "_rec"):
+            raise AttributeError(name)
+        return getattr(self.force(), name)
+
+    # indexing, iteration and the rest of the arithmetic need the numbers as well
+    def __getitem__(self, i):
+        return self.force()[i]
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __iter__(self):
+        return iter(self.force())
+
+    def __add__(self, o):
+        return self.force() + o
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self.force() - o
+
+    def __neg__(self):
+        return -self.force()
+
+
+class LazyExpr:
+    """an elementwise expression over a LazyLogits handle that has not been evaluated (`nav_probs = torch.softmax(nav_logits / T, 1)`)"""
+
+    def __init__(self, root, fn):
+        self._root, self._fn = root, fn
+
+    def force(self):
+        return self._fn(self._root.force())
+
+    def _lazy(self, fn):
+        return LazyExpr(self._root, lambda x, f=self._fn: fn(f(x)))
+
+    def __truediv__(self, f):
+        return self._lazy(lambda x: x / f)
+
+    def __mul__(self, f):
+        return self._lazy(lambda x: x * f)
+
+    __rmul__ = __mul__
+
+    __torch_function__ = LazyLogits.__torch_function__
+
+    def __getattr__(self, name):
+        if name.startswith("__") or name in ("_root", "_fn"):
+            raise AttributeError(name)
+        return getattr(self.force(), name)
+
+    def __getitem__(self, i):
+        return self.force()[i]
+
+    def __iter__(self):
+        return iter(self.force())
+
+    def __add__(self, o):
+        return self.force() + o
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return self.force() - o
+
+
+_LAZY_FUNCS = {torch.softmax, torch.nn.functional.softmax, torch.log_softmax, torch.nn.functional.log_softmax, torch.div, torch.true_divide,
+               torch.mul}
+
+
+def _force_all(x):
+    if isinstance(x, (LazyLogits, LazyExpr)):
+        return x.force()
+    if isinstance(x, (list, tuple)):
+        return type(x)(_force_all(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _force_all(v) for k, v in x.items()}
+    return x
+
+
 class DeferredLoss:
     """criterion(DeferredLogits, targets): supports exactly what the rollout does with a step loss -- scale it by python numbers
     (`* train_ml / batch_size / accum`, mp3d_agent.py:750), `.backward()` (records targets and scale: the step's gradient is produced
@@ -58,6 +200,11 @@ class DeferredLoss:
     @property
     def value(self):
         v = self._logits._rec.get("loss_sum")
+        if v is None and getattr(self._logits, "forceable", False):
+            # an automatic episode (LazyLogits): `loss.item()` after the rollout (train.py:83) runs the batched LM forward of the steps that
+            # are still pending and the heads + losses -- not the backward, which waits for whoever reads `.grad`
+            self._logits._episode.force_values()
+            v = self._logits._rec.get("loss_sum")
         if v is None:
             raise RuntimeError("the value of a deferred (teacher-forced) step loss exists after model.finish_episode() -- inside an "
                                "accumulation window (begin_episode(..., accumulate=n)) after the window's last finish_episode() or "
@@ -117,6 +264,10 @@ class CrossEntropyLoss(torch.nn.Module):
             raise NotImplementedError("the navigation path uses ignore_index=-100, reduction='sum'")
 
     def forward(self, logits, targets):
+        if isinstance(logits, LazyLogits) and logits._rec.get("logits_live") is not None:
+            logits = logits._rec["logits_live"]        # the step was forced (its logits were read): an ordinary loss on the real tensor
+        elif isinstance(logits, LazyExpr):
+            logits = logits.force()
         if isinstance(logits, DeferredLogits):
             return DeferredLoss(logits, targets)
         return Fn.ActionCE.apply(logits, targets.to(device=logits.device, dtype=torch.int64).contiguous())

@@ -158,6 +158,11 @@ class NavModel(nn.Module):
         # round 6: AUTOMATIC episodes -- the unmodified rollout (mp3d_agent.py:660-778) never calls begin_episode / finish_episode; a
         # grad-enabled training-mode navigation call then opens the episode itself and whoever needs `.grad` closes it (`_auto_*` below)
         self.auto_episode = os.environ.get("NAVILLM_AUTO_EPISODE", "1") != "0"
+        # ... in which form: "lazy" (default) = the steps' LM forward is deferred too and `fuse_logits` is a losses.LazyLogits handle that
+        # forces the pending steps through the decoder the moment something reads it (a teacher-forced rollout never does: its forward
+        # runs as one batch, like an explicit teacher_forced=True episode); "step" (NAVILLM_AUTO_EPISODE=step) = every step's forward runs
+        # when it is called, `fuse_logits` is a plain tensor
+        self.auto_form = "step" if os.environ.get("NAVILLM_AUTO_EPISODE", "1") == "step" else "lazy"
         self._auto_open = False          # the open episode was opened by forward_navigation, not by the caller
         self.auto_stats = {"opened": 0, "closed_by": {}}
         self.fp8 = None                  # Fp8DecoderWeights after to_fp8_weight_only()
@@ -887,7 +892,7 @@ class NavModel(nn.Module):
             if not self._episode_active():
                 pre = self._auto_prefix_ids(batch, layout[0]) if (self.auto_episode and self.training) else None
                 if pre is not None:
-                    self.begin_episode(pre, teacher_forced=False)     # (flushes an accumulation window whose episodes are all finished)
+                    self.begin_episode(pre, teacher_forced=self.auto_form == "lazy")     # (flushes an accumulation window whose episodes are all finished)
                     self._auto_open = True
                     self.auto_stats["opened"] += 1
             Hs_cls = None
@@ -899,9 +904,12 @@ class NavModel(nn.Module):
             Hs_cls = self._lm(ids, am, cand_vis=cand_embeds, hist_vis=hist_vis, cls_tail=True)
         if isinstance(Hs_cls, dict):
             # a step of a teacher-forced prefix-reuse episode: the LM forward, the head and the loss run in finish_episode()
-            from .losses import DeferredLogits
+            from .losses import DeferredLogits, LazyLogits
             Hs_cls["head"] = (ops.h2d(col, dev), ops.h2d(cand_masks.logical_not(), dev))
-            return {"fuse_embeds": fuse.detach().view(B, G, d), "fuse_logits": DeferredLogits(self.episode, Hs_cls)}
+            # (an AUTOMATIC episode: the handle forces the step when its numbers are needed; an episode the caller opened with
+            # teacher_forced=True promised not to read them: reading raises)
+            handle = LazyLogits(self.episode, Hs_cls, (B, G), dev, BF16) if self._auto_open else DeferredLogits(self.episode, Hs_cls)
+            return {"fuse_embeds": fuse.detach().view(B, G, d), "fuse_logits": handle}
         pred = Fn.HeadBF16.apply(Hs_cls, self, "out_head.0")   # [B,100]
 
         # fuse_logits[b][cand slots] = [pred[b,0], pred[b,1:n][inv_perm]] ; -inf elsewhere (:234-242)

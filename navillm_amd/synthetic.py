@@ -453,7 +453,7 @@ def nav_step(model, criterion, ep, train=True, last=False, loss_weight=1.0, accu
     return loss, logits
 
 
-def reference_rollout(model, criterion, ep, steps, feedback="teacher", train_ml=1.0, accum=1, temperature=1.0):
+def reference_rollout(model, criterion, ep, steps, feedback="teacher", train_ml=1.0, accum=1, temperature=1.0, follow_teacher=False):
     """`MP3DAgent.rollout`'s training branch, call for call (tasks/agents/mp3d_agent.py:660-778), with the synthetic driver standing
     in for MatterSim: per step `model('panorama')`, the map update, `model('navigation')`, `torch.softmax(nav_logits / T, 1)` (:732 --
     the logits must be real tensors), `cnt_loss += criterion(...) * train_ml / batch_size / gradient_accumulation_step`, `ml_loss +=
@@ -487,6 +487,8 @@ def reference_rollout(model, criterion, ep, steps, feedback="teacher", train_ml=
                 a_t = nav_targets
             elif feedback == "sample":
                 a_t = torch.distributions.Categorical(nav_probs.float()).sample().detach().cpu()
+                if follow_teacher:          # (tests: the logits are READ as a sampled rollout reads them, the trajectory stays comparable)
+                    a_t = nav_targets
             else:
                 raise NotImplementedError(feedback)
             ep.advance(nav, a_t, nav_outs["fuse_embeds"])

@@ -824,3 +824,62 @@ def test_accumulation_window_bookkeeping_slots_rows_and_step_tables(monkeypatch)
     assert P["nb"] == 8 and P["episodes"] == 4
     win._drop_open_episode()
     assert P["nb"] == 6 and P["episodes"] == 3 and list(P["lens"]) == [9, 7, 11, 5, 6, 8] and P["prows"] == Mp
+
+
+def test_lazy_logits_handle_of_an_automatic_episode():
+    """host logic of losses.LazyLogits (round 6): what an unmodified rollout does with `fuse_logits` (mp3d_agent.py:728-769).  `/ T` and
+    `torch.softmax` stay lazy, the criterion on an unread handle is a deferred loss, anything that needs numbers forces the step ONCE
+    and from then on the handle answers with the real, autograd-connected tensor -- which the criterion then takes as an ordinary input."""
+    from navillm_amd.losses import LazyLogits, LazyExpr, DeferredLoss, CrossEntropyLoss
+
+    class FakeEpisode:
+        def __init__(self):
+            self.forced, self.valued, self.reg = 0, 0, []
+
+        def force_logits(self, rec, live=True):
+            if rec.get("logits") is None:
+                self.forced += 1
+                rec["logits"] = torch.arange(12.).view(3, 4)
+            if live and rec.get("logits_live") is None:
+                rec["logits_live"] = rec["logits"].clone().requires_grad_(True)
+            return rec["logits_live"] if live else rec["logits"]
+
+        def force_values(self):
+            self.valued += 1
+            for rec, _, _ in self.reg:
+                rec["loss_sum"] = torch.tensor(5.0)
+
+        def register_loss(self, rec, targets, scale):
+            self.reg.append((rec, targets, scale))
+
+    crit = CrossEntropyLoss()
+    tg = torch.tensor([1, 2, 0])
+    # teacher forcing: nothing is ever read
+    ep, rec = FakeEpisode(), {}
+    lg = LazyLogits(ep, rec, (3, 4), torch.device("cpu"), torch.bfloat16)
+    probs = torch.softmax(lg / 0.5, 1)
+    assert isinstance(probs, LazyExpr) and isinstance(2.0 * probs, LazyExpr) and ep.forced == 0
+    assert lg.shape == (3, 4) and lg.size(0) == 3 and lg.dim() == 2 and len(lg) == 3 and lg.device.type == "cpu"
+    cnt, ml = 0., 0.
+    cnt += crit(lg, tg) * 0.4 / 3 / 2
+    ml += cnt.detach()
+    cnt.backward()
+    assert ep.forced == 0 and len(ep.reg) == 1 and abs(ep.reg[0][2] - 0.4 / 6) < 1e-12
+    assert abs((ml * 2).item() - 5.0 * 0.4 / 6 * 2) < 1e-6 and ep.valued == 1 and ep.forced == 0     # train.py:83: values, not logits
+    # sampling: `Categorical(nav_probs.float())` reads -> the step is forced once, the loss is an ordinary one on the live tensor
+    ep, rec = FakeEpisode(), {}
+    lg = LazyLogits(ep, rec, (3, 4), torch.device("cpu"), torch.bfloat16)
+    probs = torch.softmax(lg / 0.5, 1)
+    a_t = torch.distributions.Categorical(probs.float()).sample()
+    assert a_t.shape == (3,) and ep.forced == 1
+    _, am = lg.max(1)
+    assert am.tolist() == [3, 3, 3] and int(torch.argmax(lg[0])) == 3 and ep.forced == 1
+    assert torch.equal(lg.value, rec["logits"]) and float((lg + 1.0)[0, 0]) == 1.0
+    try:
+        loss = crit(lg, tg)
+    except NotImplementedError:
+        loss = None                                  # (no GPU here: the kernel path was reached with the LIVE tensor, not a deferred loss)
+    except Exception as e:                           # the autograd function asks for the library / a device
+        assert not isinstance(e, AttributeError), e
+        loss = None
+    assert not isinstance(loss, DeferredLoss) and ep.reg == []
