@@ -247,3 +247,36 @@ def test_automatic_episode_guards_and_opt_out(monkeypatch):
     monkeypatch.delenv("NAVILLM_AUTO_EPISODE")
     on = NavModel(nav_config=cfg, device=torch.device(DEV), seed=21)
     assert on.auto_episode is True and on.auto_form == "lazy"
+
+
+def test_wrapped_model_clip_hands_over_a_partial_accumulation_window():
+    """`torch.nn.utils.clip_grad_norm_(model.parameters(), 40.)` on the WRAPPED model (train.py:87 after
+    tools/optims.py:52-54) used to walk the child's `_parameters` without running `NavModel.parameters()`: an accumulation window that
+    was still open (fewer episodes than `accumulate`: normal in a multi-task mix) kept its gradients, the clip norm was taken without
+    them and `FlatAdamW.step()` added them after the clip.  `NavDataParallel.named_parameters` hands the window over first."""
+    from test_episode_gpu import _window_run
+    from navillm_amd.parallel import NavDataParallel
+    cfg = _cfg("mid")
+    plan = [(41, 150, 3), (42, 96, 2)]
+    norms = {}
+
+    def run(wrapped_clip):
+        m = _model(cfg, auto=False)
+        m.eval()
+        w = NavDataParallel(m, comm=None)
+
+        def flush():
+            assert m._window is not None and m._window.window_open(), "two of four episodes: the window is still open"
+            if wrapped_clip:
+                norms[wrapped_clip] = float(torch.nn.utils.clip_grad_norm_(w.parameters(), 1e9))
+            else:
+                m.flush_accumulation_window()
+                norms[wrapped_clip] = float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1e9))
+            assert not m._window.window_open()
+        _, losses, grads = _window_run(m, cfg, plan, accumulate=4, flush=flush)
+        return losses, grads
+    l1, g1 = run(True)
+    l0, g0 = run(False)
+    assert l1 == l0 and norms[True] == norms[False] and norms[True] > 0
+    for g in g0:
+        assert torch.equal(g1[g], g0[g]) and float(g1[g].abs().max()) > 0, g
