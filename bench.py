@@ -146,7 +146,7 @@ def gemm_traffic_from_profile(mode):
     except OSError:
         return None, "kernel source not found"
     stale = []
-    names = (f"r05_gemm_traffic_{mode}.json", f"r04_gemm_traffic_{mode}.json") + (("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json") if mode == "recompute" else ())
+    names = (f"r06_gemm_traffic_{mode}.json", f"r05_gemm_traffic_{mode}.json", f"r04_gemm_traffic_{mode}.json") + (("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json") if mode == "recompute" else ())
     for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
