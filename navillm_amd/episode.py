@@ -1114,11 +1114,14 @@ class PrefixEpisode:
                 return rec["logits"]                      # (the episode is over: the value it left behind; no graph any more)
             raise RuntimeError("the episode of this step is over and its logits were never computed")
         self._forward_pending()
-        if not live:
+        if not live or rec.get("targets") is not None:
+            # only the values -- also when the step's deferred loss has ALREADY run backward(): the reference's order in a sampled rollout is
+            # loss + backward() (mp3d_agent.py:750-757), THEN `Categorical(nav_probs.float())` (:762-765); the loss stays deferred (the
+            # heads pass below computes it and the step's dH now), the reader gets the numbers without a graph
             self._heads_deferred([rec])
+            if live:
+                self.stats["forced_reads"] = self.stats.get("forced_reads", 0) + 1
             return rec["logits"]
-        if rec.get("targets") is not None:
-            raise RuntimeError("the logits of this step are read AFTER its deferred loss ran backward(): read them before the loss, or not at all")
         self.stats["forced_reads"] = self.stats.get("forced_reads", 0) + 1
         leaf = rec["Hs"].detach().clone().requires_grad_(True)
 

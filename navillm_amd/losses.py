@@ -5,45 +5,24 @@ from . import functions as Fn
 
 
 class DeferredLogits:
-    """`fuse_logits` of a navigation step inside a TEACHER-FORCED prefix-reuse episode (navillm_amd/episode.py, round 4): under
-    imitation learning the rollout never reads the logits to choose an action (mp3d_agent.py:760-761), so the step's LM forward is
-    postponed to `finish_episode()`, where ALL the steps of the episode go through the decoder as one batch.  The only thing the
-    rollout may do with this handle is hand it to the criterion; anything else (argmax, softmax, .cpu()) is an AttributeError -- a
-    sampling / argmax rollout must not open the episode with teacher_forced=True.  After finish_episode(): `.value` = the [B, G]
-    logits."""
+    """`fuse_logits` of a navigation step whose LM forward has been DEFERRED (navillm_amd/episode.py, round 4): under imitation learning
+    the rollout never reads the logits to choose an action (mp3d_agent.py:760-761), so the step's forward is postponed and ALL the steps of
+    the episode go through the decoder as one batch.  What the rollout may do with the handle without it ever holding numbers:
+      * `nav_logits / T`, `x * f` and the softmax family -- `nav_probs = torch.softmax(nav_logits / args.temperature, 1)`,
+        mp3d_agent.py:732, is computed unconditionally but only `feedback == 'sample'` reads it -- stay LAZY (`LazyExpr`);
+      * `criterion(handle, targets)` -> a `DeferredLoss`;
+      * `.shape`, `.size()`, `.dim()`, `.device`, `.dtype`.
+    Anything else needs the numbers.  In an episode the caller opened with `begin_episode(..., teacher_forced=True)` that is an error
+    (`.value` / a forced expression raise until finish_episode(); a tensor method is an AttributeError): the caller promised not to
+    read.  In an AUTOMATIC episode the handle is a `LazyLogits`, which runs the pending steps instead.  After finish_episode():
+    `.value` = the [B, G] logits."""
 
-    def __init__(self, episode, rec):
+    forceable = False
+
+    def __init__(self, episode, rec, shape=None, device=None, dtype=None):
         self._episode, self._rec = episode, rec
-
-    @property
-    def value(self):
-        v = self._rec.get("logits")
-        if v is None:
-            raise RuntimeError("the logits of a deferred (teacher-forced) step exist after model.finish_episode() -- inside an accumulation "
-                               "window (begin_episode(..., accumulate=n)) after the window's last finish_episode() or model.flush_accumulation_window()")
-        return v
-
-
-class LazyLogits(DeferredLogits):
-    """`fuse_logits` of a navigation step inside an AUTOMATIC episode (round 6; NavModel._auto_*): the unmodified rollout
-    (tasks/agents/mp3d_agent.py:660-778) cannot say whether it will read the logits -- under teacher forcing it never does (the action is
-    the teacher's, :760-761), under DAgger sampling / argmax it does at once (:762-769) -- so the model hands out a handle that decides by
-    itself:
-      * `nav_logits / T`, `x * f` and `torch.softmax(x, dim)` (line :732, computed unconditionally) stay LAZY (`LazyExpr`);
-      * anything that needs numbers -- `.float()`, `.max(1)`, `Categorical(nav_probs.float())`, `.cpu()`, any other torch function --
-        FORCES the step: every navigation step of the episode that has not gone through the decoder yet does so now, as one batch
-        (`PrefixEpisode.force_logits`), and the handle answers with a real tensor that is connected to autograd (a later
-        `criterion(...).backward()` reaches the step through it);
-      * `criterion(handle, targets)` on a step that was never forced is a `DeferredLoss`, exactly as in an explicit teacher-forced
-        episode; `loss.item()` (train.py:83) then runs the batched forward of whatever is pending + the heads, not the backward.
-    So a teacher-forced rollout batches the LM forward of all its steps (the headline form), a sampled one runs step by step, and the
-    rollout is the reference's, line for line."""
-
-    forceable = True
-
-    def __init__(self, episode, rec, shape, device, dtype):
-        super().__init__(episode, rec)
-        self.shape, self.device, self.dtype = torch.Size(shape), device, dtype
+        if shape is not None:
+            self.shape, self.device, self.dtype = torch.Size(shape), device, dtype
 
     def size(self, dim=None):
         return self.shape if dim is None else self.shape[dim]
@@ -55,13 +34,12 @@ class LazyLogits(DeferredLogits):
     def value(self):
         v = self._rec.get("logits")
         if v is None:
-            self._episode.force_logits(self._rec, live=False)
-            v = self._rec["logits"]
+            raise RuntimeError("the logits of a deferred (teacher-forced) step exist after model.finish_episode() -- inside an accumulation "
+                               "window (begin_episode(..., accumulate=n)) after the window's last finish_episode() or model.flush_accumulation_window()")
         return v
 
     def force(self):
-        """the step's logits as a REAL tensor, connected to autograd: the steps recorded so far run their LM forward now"""
-        return self._episode.force_logits(self._rec, live=True)
+        return self.value
 
     def _lazy(self, fn):
         return LazyExpr(self, fn)
@@ -77,14 +55,42 @@ class LazyLogits(DeferredLogits):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
-        if func in _LAZY_FUNCS and len(args) >= 1 and isinstance(args[0], (LazyLogits, LazyExpr)):
+        if func in _LAZY_FUNCS and len(args) >= 1 and isinstance(args[0], (DeferredLogits, LazyExpr)):
             rest = args[1:]
             return args[0]._lazy(lambda x: func(x, *rest, **kwargs))
         return func(*_force_all(args), **_force_all(kwargs))
 
+
+class LazyLogits(DeferredLogits):
+    """`fuse_logits` of a navigation step inside an AUTOMATIC episode (round 6; NavModel._auto_*): the unmodified rollout
+    (tasks/agents/mp3d_agent.py:660-778) cannot say whether it will read the logits -- under teacher forcing it never does (the action is
+    the teacher's, :760-761), under DAgger sampling / argmax it does (:762-769) -- so this handle decides by itself: what
+    `DeferredLogits` keeps lazy stays lazy, and anything that needs numbers -- `.float()`, `.max(1)`, `Categorical(nav_probs.float())`,
+    indexing, any other torch function -- FORCES the step: every navigation step of the episode that has not gone through the decoder yet
+    does so now, as one batch (`PrefixEpisode.force_logits`).  Read BEFORE the step's loss, the handle answers with a real tensor that
+    is connected to autograd (the `criterion(...).backward()` that follows reaches the step through it); read AFTER the loss was
+    registered (the reference's order in a sampled rollout: loss and backward() at :750-757, the draw at :762-765) with the values.
+    `loss.item()` (train.py:83) on deferred losses runs the batched forward of whatever is pending + the heads, not the backward.
+    So a teacher-forced rollout batches the LM forward of all its steps (the headline form), a sampled one runs step by step, and the
+    rollout is the reference's, line for line."""
+
+    forceable = True
+
+    @property
+    def value(self):
+        v = self._rec.get("logits")
+        if v is None:
+            self._episode.force_logits(self._rec, live=False)
+            v = self._rec["logits"]
+        return v
+
+    def force(self):
+        """the step's logits as a real tensor: the steps recorded so far run their LM forward now"""
+        return self._episode.force_logits(self._rec, live=True)
+
     def __getattr__(self, name):
         # (only reached for attributes this class does not define: tensor methods -- they need the numbers)
-        if name.startswith("__") or name in ("_episode", "_rec"):
+        if name.startswith("__") or name in ("_episode", "_rec", "shape", "device", "dtype"):
             raise AttributeError(name)
         return getattr(self.force(), name)
 
@@ -111,7 +117,7 @@ class LazyLogits(DeferredLogits):
 
 
 class LazyExpr:
-    """an elementwise expression over a LazyLogits handle that has not been evaluated (`nav_probs = torch.softmax(nav_logits / T, 1)`)"""
+    """an elementwise expression over a deferred-logits handle that has not been evaluated (`nav_probs = torch.softmax(nav_logits / T, 1)`)"""
 
     def __init__(self, root, fn):
         self._root, self._fn = root, fn
@@ -130,7 +136,7 @@ class LazyExpr:
 
     __rmul__ = __mul__
 
-    __torch_function__ = LazyLogits.__torch_function__
+    __torch_function__ = DeferredLogits.__torch_function__
 
     def __getattr__(self, name):
         if name.startswith("__") or name in ("_root", "_fn"):
@@ -157,7 +163,7 @@ _LAZY_FUNCS = {torch.softmax, torch.nn.functional.softmax, torch.log_softmax, to
 
 
 def _force_all(x):
-    if isinstance(x, (LazyLogits, LazyExpr)):
+    if isinstance(x, (DeferredLogits, LazyExpr)):
         return x.force()
     if isinstance(x, (list, tuple)):
         return type(x)(_force_all(v) for v in x)

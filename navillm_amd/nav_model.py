@@ -908,7 +908,7 @@ class NavModel(nn.Module):
             Hs_cls["head"] = (ops.h2d(col, dev), ops.h2d(cand_masks.logical_not(), dev))
             # (an AUTOMATIC episode: the handle forces the step when its numbers are needed; an episode the caller opened with
             # teacher_forced=True promised not to read them: reading raises)
-            handle = LazyLogits(self.episode, Hs_cls, (B, G), dev, BF16) if self._auto_open else DeferredLogits(self.episode, Hs_cls)
+            handle = (LazyLogits if self._auto_open else DeferredLogits)(self.episode, Hs_cls, (B, G), dev, BF16)
             return {"fuse_embeds": fuse.detach().view(B, G, d), "fuse_logits": handle}
         pred = Fn.HeadBF16.apply(Hs_cls, self, "out_head.0")   # [B,100]
 

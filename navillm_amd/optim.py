@@ -149,14 +149,17 @@ class FlatAdamW(torch.optim.Optimizer):
         self.fused_zero_grad = os.environ.get("NAVILLM_ADAMW_ZERO_GRAD", "1") != "0"
         self._zeroed_segs = None
         self._zeroed_at = -1            # FlatStore.grad_writes when step() zeroed them: any gradient write since invalidates the fused form
-        # round 6: the LM group's update runs on a SIDE stream, decoder layer by decoder layer, while the launch stream goes on with the next
-        # episode's scene-encoder / fusion steps (fp32 group: updated on the launch stream); whoever touches an LM parameter or gradient next
-        # waits for the part it needs (FlatStore.wait_params).  In a teacher-forced episode the LM weights are not read again before
-        # finish_episode()'s batched forward, so most of the 18 ms of weight streaming disappear behind latency-bound launches.
-        # NAVILLM_ADAMW_OVERLAP=0 / `optimizer.overlap_update = False`: everything on the launch stream, as before.  Contract: between
-        # step() and the next model call read parameters through model.parameters() / state_dict() (they join the update); a tensor handle
-        # kept from BEFORE the step is ordered only after torch.cuda.synchronize().
-        self.overlap_update = os.environ.get("NAVILLM_ADAMW_OVERLAP", "1") != "0" and self.store.device.type == "cuda"
+        # round 6 (OPT-IN: NAVILLM_ADAMW_OVERLAP=1 / `optimizer.overlap_update = True`): the LM group's update runs on a SIDE stream,
+        # decoder layer by decoder layer, while the launch stream goes on with the next episode's scene-encoder / fusion steps (fp32 group:
+        # updated on the launch stream); whoever touches an LM parameter or gradient next waits for the part it needs
+        # (FlatStore.wait_params).  Built to take the 18 ms of weight streaming off the critical path; MEASURED (same box, ABAB,
+        # gpurun_out/r6_ab_overlap*.json): whole episodes 150.1 -> 150.9 nav-steps/s (+0.5 %), the driver's window 135.2 -> 134.8 (-0.3 %) --
+        # the host runs ahead, so the next episode's ~360 encoder launches are already queued and take ~2 ms, and the rest of the update
+        # lands on the batched forward's GEMMs, which slow down by what the update gains (their event-timed rate 0.534 -> 0.519 of the
+        # MFMA peak).  Not a gain worth a contract on raw tensor handles, hence off by default.  Contract when on: between step() and the
+        # next model call read parameters through model.parameters() / state_dict() (they join the update); a tensor handle kept from
+        # BEFORE the step is ordered only after torch.cuda.synchronize().
+        self.overlap_update = os.environ.get("NAVILLM_ADAMW_OVERLAP", "0") == "1" and self.store.device.type == "cuda"
         self._side = None
 
     # `lr` as an attribute mirrors the single param group (tests / callers that poke it directly)

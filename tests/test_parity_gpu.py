@@ -224,6 +224,10 @@ def test_g12_episode_accumulated_gradients_vs_reference(mode):
             assert m._auto_open and m.auto_stats["opened"] == 1 and m.episode.prefix is not None
         assert maxerr(out["fuse_embeds"], zt["fuse_embeds"]) < 3e-5
         lg, l16, l32 = out["fuse_logits"], T(zt["fuse_logits"]), T(zf[pre + "fuse_logits"])
+        if mode == "auto":
+            from navillm_amd.losses import LazyLogits
+            assert isinstance(lg, LazyLogits)
+            lg = lg.force()                          # this test LOOKS at every step's logits: the handle runs the step and hands out a live tensor
         ulps = bf16_ulps_at_scale(lg, l16)
         worst_ulps = max(worst_ulps, ulps)
         gap, e_hip, e_ref = maxerr(lg, l16), maxerr(lg, l32), maxerr(l16, l32)
