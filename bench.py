@@ -325,6 +325,39 @@ def mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed):
                "episodes_per_s_per_gpu": round((4 * a.batch + a.batch) / dt, 2)}
     model.episode_abort()
     model.zero_grad()
+    # round 6: the SAME meta-steps with nothing but the reference's calls (no begin_episode / finish_episode): automatic episodes -- the
+    # navigation steps run over the cached prefix by themselves (teacher-forced: their forward batched), the sub-task calls take the full path
+    auto = None
+    try:
+        model.auto_episode, model.auto_form = True, "lazy"
+        for rep in range(2):
+            nav_steps = 0
+            per_task = {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t, ep in eps.items():
+                ep.reset()
+                t1 = time.perf_counter()
+                mixed_task_episode(wrapped, crit, ep, STEPS_PER_EPISODE)
+                opt.clip_grad_norm_(40.0); opt.step(); opt.zero_grad()
+                nav_steps += STEPS_PER_EPISODE * a.batch
+                torch.cuda.synchronize()
+                per_task[t] = round((time.perf_counter() - t1) * 1e3, 1)
+            t1 = time.perf_counter()
+            qa_step(wrapped, eps["r2r"], sync="final")
+            opt.clip_grad_norm_(40.0); opt.step(); opt.zero_grad()
+            torch.cuda.synchronize()
+            per_task["scanqa"] = round((time.perf_counter() - t1) * 1e3, 1)
+            dt = time.perf_counter() - t0
+            auto = {"seconds": round(dt, 3), "ms_per_meta_step": per_task, "nav_steps_per_s_per_gpu": round(nav_steps / dt, 2),
+                    "episodes_per_s_per_gpu": round((4 * a.batch + a.batch) / dt, 2),
+                    "what": "no begin_episode / finish_episode in the loop: automatic episodes (NavModel._auto_*)"}
+    except Exception as e:
+        auto = {"error": f"{type(e).__name__}: {e}"}
+        model.episode_abort()
+    model.auto_episode = False
+    model.episode_abort()
+    model.zero_grad()
     for rep in range(2):
         model.flop_log = []
         nav_steps = 0
@@ -354,6 +387,7 @@ def mixed_task_extra(a, cfg, model, wrapped, opt, crit, device, seed):
                        f"algorithmic FLOPs per SURVEY.md §8d incl. lm_head in the LM-loss modes (top level: the whole prompt recomputed at "
                        f"every nav step; `navigation_over_cached_prefix`: the same meta-steps in prefix_reuse mode)"}
         res["navigation_over_cached_prefix"] = pre
+        res["unmodified_rollout_automatic_episodes"] = auto
     model.flop_log = None
     return res
 
