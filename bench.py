@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--no-tf-batch", action="store_true", help="prefix_reuse mode: run every step's LM forward when the step is called (round-3 form) "
                     "instead of batching the teacher-forced episode's forward into finish_episode()")
     ap.add_argument("--no-other-mode", action="store_true", help="do not measure the other training mode (kernel traces of one mode)")
+    ap.add_argument("--explicit-episodes", action="store_true", help="prefix_reuse mode: call begin_episode(..., teacher_forced=...) / finish_episode() around "
+                    "every episode (rounds 3-5) instead of letting the model open and close its episodes itself (round 6: automatic episodes, "
+                    "the default -- the timed loop then contains nothing but the reference's calls)")
     ap.add_argument("--mode", default=os.environ.get("NAVILLM_BENCH_MODE", "prefix_reuse"), choices=["prefix_reuse", "recompute"],
                     help="how the training step treats the prompt's static prefix (instruction + template, ~530 of ~650 tokens): "
                          "prefix_reuse (default) = forward once per episode, K/V reused by every step, one deferred prefix backward "
@@ -175,6 +178,9 @@ MODE_WHAT = {
 }
 
 
+AUTO_WHAT = ("; round 6: none of this is called from the timed loop -- the model opens the episode itself on the first training-mode "
+             "navigation call (NavModel._auto_*), hands out LazyLogits handles, and optimizer.clip_grad_norm_ runs the deferred work "
+             "(bit-identical to the explicit begin_episode / finish_episode form, tests/test_auto_episode_gpu.py)")
 TF_WHAT = ("; round 4: the rollout is imitation learning (teacher forcing: the next action is the teacher's, the next history token the "
            "fusion output -- neither depends on the LM, tasks/agents/mp3d_agent.py:760-761,774-778), so the steps' LM FORWARD is deferred too: "
            "model('navigation') returns fuse_embeds at once and a deferred-logits handle, criterion(handle, targets) * w / B and .backward() "
@@ -874,23 +880,38 @@ def main():
 
     def make_step(mode):
         prefix = mode == "prefix_reuse"
+        explicit = prefix and a.explicit_episodes
+        # round 6: in prefix_reuse mode the loop below contains NOTHING but the reference's calls (nav_step = panorama, navigation,
+        # criterion, backward; then clip + step + zero_grad): the model opens the prefix-reuse episode on the first training-mode
+        # navigation call and `optimizer.clip_grad_norm_` hands its gradients over (NavModel._auto_*; teacher-forced rollout: nothing
+        # reads the LazyLogits handles, so the LM forward of all steps runs as one batch there).  --explicit-episodes: the
+        # begin_episode / finish_episode calls of rounds 3-5 instead (bit-identical results, tests/test_auto_episode_gpu.py)
+        model.auto_episode = prefix and not explicit
+        model.auto_form = "lazy" if TF_BATCH else "step"
+        dp_ctx = wrapped.final_backward if hasattr(wrapped, "final_backward") else contextlib.nullcontext
 
         def one_step(i, end=False):
             """iteration i of the rollout loop (tasks/agents/mp3d_agent.py:660) for the rank's B episodes; every 6th one (or `end`)
             ends the episodes: (prefix mode: the episode's deferred backward,) clip(40) + AdamW + zero_grad (train.py:86-89)"""
             pos = i % STEPS_PER_EPISODE
             last = pos == STEPS_PER_EPISODE - 1 or end
-            if prefix and pos == 0:
+            if explicit and pos == 0:
                 # static prompt prefix: forward once, K/V cached per layer; the rollout is teacher-forced (imitation learning), so the
                 # steps' LM forward is batched into finish_episode() as well (round 4; --no-tf-batch: per-step forward as in round 3)
                 model.begin_episode(ep.prefix_ids(), teacher_forced=TF_BATCH)
             loss, logits = nav_step(wrapped, crit, ep, train=True, last=last, final=last and not prefix)
             if last:
-                if prefix:
-                    ctx = wrapped.final_backward if hasattr(wrapped, "final_backward") else contextlib.nullcontext
-                    with ctx():                               # the LAST backward before the optimizer step: DP exchanges from inside it
+                if explicit:
+                    with dp_ctx():                            # the LAST backward before the optimizer step: DP exchanges from inside it
                         model.finish_episode()
-                opt.clip_grad_norm_(40.0)
+                    opt.clip_grad_norm_(40.0)
+                elif prefix:
+                    # the automatic episode's deferred backward runs inside the clip (it needs .grad first); under data parallelism
+                    # that is the backward the exchange overlaps with (N = 1: a null context)
+                    with dp_ctx():
+                        opt.clip_grad_norm_(40.0)
+                else:
+                    opt.clip_grad_norm_(40.0)
                 opt.step()
                 opt.zero_grad()
                 ep.reset()
@@ -946,6 +967,15 @@ def main():
         return float(tmax.item()), tm, loss
 
     phase("model built")
+    _run_mode = run_mode
+
+    def run_mode(*args, **kw):           # (every other number of this file names its own form: automatic episodes off again afterwards)
+        try:
+            return _run_mode(*args, **kw)
+        finally:
+            model.grad_handover("bench") if getattr(model, "_auto_open", False) else None
+            model.auto_episode = False
+
     if world > 1 and hasattr(wrapped, "exchange_stats"):
         wrapped.profile = True           # HIP events around the exchange of every optimizer step (side stream + the join): `dp.exchange`
     dt, timer, loss = run_mode(a.mode, a.steps, a.warmup, a.prewarm, True)
@@ -1069,7 +1099,12 @@ def main():
                                            "; the short last episode makes this figure conservative, see whole_episodes" if a.steps % STEPS_PER_EPISODE else ""),
                        "training_mode": a.mode,
                        "teacher_forced_forward_batched": bool(TF_BATCH and a.mode == "prefix_reuse"),
-                       "training_mode_what": MODE_WHAT[a.mode] + (TF_WHAT if (TF_BATCH and a.mode == "prefix_reuse") else "")},
+                       "episodes": ("explicit begin_episode / finish_episode calls in the loop (--explicit-episodes)" if a.explicit_episodes else
+                                    "AUTOMATIC: the timed loop holds only the reference's calls -- model('panorama'), model('navigation'), criterion, "
+                                    "backward(), optimizer.clip_grad_norm_ / step / zero_grad; the model opens the prefix-reuse episode itself and the "
+                                    "clip hands its gradients over (INTEGRATION.md section 2's three edits, nothing else)") if a.mode == "prefix_reuse" else None,
+                       "training_mode_what": MODE_WHAT[a.mode] + (TF_WHAT if (TF_BATCH and a.mode == "prefix_reuse") else "") +
+                                             (AUTO_WHAT if (a.mode == "prefix_reuse" and not a.explicit_episodes) else "")},
         }
         if main_stats is not None:
             line["config"]["token_rows_last_episode"] = {"prefix_once": int(main_stats["prefix_rows"]),
