@@ -549,7 +549,7 @@ def unmodified_rollout_extra(a, cfg, model, opt, crit, device, seed):
     from navillm_amd.synthetic import SyntheticEpisodes, reference_train_steps
     out = {"what": "train.py:60-91 + mp3d_agent.py:660-778 verbatim over the synthetic driver, no begin_episode / finish_episode in the loop; "
                    "feedback alternates teacher / sample per meta-step; clip = optimizer.clip_grad_norm_(40.) (INTEGRATION.md edit 3)"}
-    for tag, B, accum, metas in (("B8", a.batch, 1, 4), ("B1x8", 1, 8, 16)):
+    for tag, B, accum, metas in (("B8", a.batch, 1, 8), ("B1x8", 1, 8, 16)):
         epx = SyntheticEpisodes(cfg, B, seed=seed, instr_len=a.instr_len, device=device)
         res = {"batch_per_gpu": B, "gradient_accumulation_step": accum, "meta_steps_timed": metas, "nav_steps_timed": metas * STEPS_PER_EPISODE}
         # (name, automatic episodes?, their form, training stage: "multi" alternates teacher forcing and sampling per meta-step, "pretrain" is
