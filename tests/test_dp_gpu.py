@@ -309,7 +309,19 @@ def _prefix_episode(model, wrapped, seed, steps, dev=DEV, teacher_forced=False):
     ep = SyntheticEpisodes(model.cfg, 3, seed=seed, instr_len=150, device=torch.device(dev))
     model.zero_grad()
     torch.manual_seed(1)
-    if teacher_forced == "window":
+    if teacher_forced == "auto":
+        # round 6: AUTOMATIC episode -- the rollout makes no begin_episode / finish_episode call (synthetic.reference_rollout = the
+        # reference's loop); its deferred work runs when the gradients are handed over, which under the wrapper happens inside
+        # final_backward() so that the per-layer exchange is launched from the deferred backward walk (what bench.py does around the clip)
+        import contextlib
+        from navillm_amd.synthetic import reference_rollout
+        model.auto_episode, model.auto_form = True, "lazy"
+        reference_rollout(wrapped, CrossEntropyLoss(), ep, steps)
+        assert model._auto_open
+        with (wrapped.final_backward() if hasattr(wrapped, "final_backward") else contextlib.nullcontext()):
+            model.grad_handover("test")
+        model.auto_episode = False
+    elif teacher_forced == "window":
         # round 5: an accumulation window of two teacher-forced episodes (begin_episode(..., accumulate=2)); the second finish_episode()
         # runs the whole window inside final_backward()
         ep_b = SyntheticEpisodes(model.cfg, 3, seed=seed + 50, instr_len=110, device=torch.device(dev))
@@ -346,7 +358,7 @@ def _shared_gpu_rank_prefix(rank, world, port, q, steps_by_rank, teacher_forced=
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("teacher_forced", [False, True, "window"])
+@pytest.mark.parametrize("teacher_forced", [False, True, "window", "auto"])
 def test_dp_world2_shared_gpu_prefix_reuse_episode_mean_and_replica_consistency(teacher_forced):
     """the HEADLINE training mode under data parallelism with two real ranks and the real kernels.  Rank 0 runs a
     2-step episode, rank 1 a 3-step one (ranks may run different numbers of nav steps, mp3d_agent.py:661-676: only the final backward
@@ -354,7 +366,8 @@ def test_dp_world2_shared_gpu_prefix_reuse_episode_mean_and_replica_consistency(
     ranks hold bit-identical gradients == the mean of the two single-rank prefix-reuse gradients, nothing is left for the optimizer's
     flush, and after clip + AdamW the replicas are bit-identical.  teacher_forced: the same with the steps' forward deferred and batched
     into finish_episode() (round 4), i.e. the bench's default training step under data parallelism.  "window" (round 5): each rank runs
-    an accumulation window of two teacher-forced episodes; the exchange runs from inside the window's batched backward."""
+    an accumulation window of two teacher-forced episodes; the exchange runs from inside the window's batched backward.  "auto" (round
+    6): the unmodified rollout, automatic episodes, the handover inside final_backward()."""
     import torch.multiprocessing as mp
     from navillm_amd.nav_model import NavModel
     world, steps_by_rank = 2, (2, 3)
