@@ -1010,7 +1010,8 @@ def main():
                 global_tf = TF_BATCH
                 try:
                     globals()["TF_BATCH"] = False
-                    p_dt, _, _ = run_mode(a.mode, w_steps, 0, 0, world > 1)
+                    # (one untimed episode first: the per-step form's K/V-cache layout is allocated on first use since round 6)
+                    p_dt, _, _ = run_mode(a.mode, w_steps, 0, STEPS_PER_EPISODE, world > 1)
                     whole["per_step_forward_nav_steps_per_s"] = round(a.batch * world * w_steps / p_dt, 2)
                     # what a fine-tune sees: the multi-task stage alternates teacher forcing with DAgger sampling meta-step by
                     # meta-step (mp3d_agent.py:509-525: `step % 2 == 0` -> feedback="teacher", else "sample"); a sampled step needs
