@@ -351,8 +351,9 @@ class NavModel(nn.Module):
     # ---- automatic episodes (round 6): the fast path behind the reference's OWN call pattern
     # The rollout of tasks/agents/mp3d_agent.py:660-778 knows nothing of episodes: per step `model('navigation', ...)`, `criterion`,
     # `backward()`; train.py:86-89 then clips through `model.parameters()` and steps.  So the model opens the episode itself on the
-    # first grad-enabled training-mode navigation call (prefix = the static part of each incoming prompt, per-step-forward form: the
-    # logits are real tensors, `torch.softmax(nav_logits / T, 1)` at mp3d_agent.py:732 and sampled / argmax feedback keep working),
+    # first grad-enabled training-mode navigation call (prefix = the static part of each incoming prompt; `fuse_logits` is a
+    # losses.LazyLogits handle on which `torch.softmax(nav_logits / T, 1)` at mp3d_agent.py:732 stays lazy and which runs the pending
+    # steps the moment sampled / argmax feedback reads it -- or, NAVILLM_AUTO_EPISODE=step, a plain tensor with every forward at once),
     # later calls whose prompts start with the same prefixes extend it, and it is closed -- its deferred backward run, every gradient
     # handed to `.grad` -- by whatever comes first: a navigation call with OTHER prompts (the next rollout), `model.parameters()` /
     # `named_parameters()` (torch.nn.utils.clip_grad_norm_, train.py:87; also through the NavDataParallel wrapper),
