@@ -509,11 +509,16 @@ class PrefixEpisode:
         teacher-forced episode whose prefix is still pending -- when a step that cannot be deferred needs the cache"""
         m, cfg, st = self.m, self.m.cfg, self.m.store
         P = self.prefix
-        self._kv_layout()
         B, cap, H, hd, eps, L = self.B, self.cap, cfg.num_heads, cfg.head_dim, cfg.rms_norm_eps, cfg.num_layers
         d, ff = cfg.hidden_size, cfg.intermediate_size
         Mp, Lmax, defer = P["Mp"], P["Lmax"], P["defer"]
         allm = self.mode == "all"
+        # round 6: in the default form the steps' attention reads the prefix's K/V from the episode row buffers in place
+        # (`_step_forward`: one table-step of nv_attn_fwd_episode_bf16), so the K/V-cache layout is neither allocated nor filled here; a
+        # step that does need it (a no-grad step inside the episode, the `steps` forms) copies the rows over then (`_need_prefix_cache`)
+        to_cache = not (allm and defer and os.environ.get("NAVILLM_EPISODE_ATTN_FWD", "episode") != "steps")
+        if to_cache:
+            self._kv_layout()
         ids_d, vix, pos_d, crow_d, cu_d, zero_pos0 = P["ids_dev"], P["vix_dev"], P["pos"], P["crow"], P["cu"], P["pos0"]
         layers = []
         x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_d, vix, None,
@@ -534,7 +539,8 @@ class PrefixEpisode:
                 return self._buf(f"p{i}.{name}", (Mp, width) if width else (Mp,), dt)
             n1, rstd1 = ops.rmsnorm_fwd(x, w1, eps, out=t("n1", d), rstd=t("r1", 0, F32))
             qkv = ops.gemm_qkv_rope(n1, Wqkv, m.rope_cos, m.rope_sin, Lmax, 2 * H * hd, out=t("qkv", 3 * d), pos_i32=pos_d)
-            ops.scatter_rows_bf16_(qkv, crow_d, self.cache[i])
+            if to_cache:
+                ops.scatter_rows_bf16_(qkv, crow_d, self.cache[i])
             if i == L - 1 and os.environ.get("NAVILLM_EPISODE_PRUNE_TOP", "1") != "0":
                 # round 5: the TOP layer's prefix rows feed nothing but their K/V (no head reads a prefix row, and the steps read a layer's
                 # K/V, i.e. its INPUT): attention, o_proj and the MLP of these rows were computed and never read -- the backward has
@@ -553,19 +559,24 @@ class PrefixEpisode:
             x = x2                                     # (dkv_acc needs no zero-fill: the first step SETS the prefix rows)
         P["layers"] = layers
         P["pending"] = False
-        P["cache_valid"] = True
+        P["cache_valid"] = to_cache
 
     def _need_prefix_cache(self):
         """a step that runs NOW (not deferred) reads the prefix's K/V from the per-layer cache: compute the prefix if it is still
         pending, or -- it went through `_forward_lazy` with the in-place attention -- copy its K/V rows into the cache"""
         P = self.prefix
-        self._kv_layout()
         if P.get("pending"):
             self._prefix_forward()
-        elif not P.get("cache_valid", True):
+        self._kv_layout()                      # (marks the cache invalid when it has to be built now)
+        if not P.get("cache_valid", True):
             for i in range(self.m.cfg.num_layers):
                 ops.scatter_rows_bf16_(self._E[i]["qkv"][:P["Mp"]], P["crow"], self.cache[i])
             P["cache_valid"] = True
+
+    def _need_prefix(self):
+        """a deferred step that runs now and reads the prefix's K/V from the episode row buffers in place: only the prefix's forward"""
+        if self.prefix.get("pending"):
+            self._prefix_forward()
 
     def fits(self, ids_list):
         """can this step's prompts run over the cached prefix?  False: at least one prompt was LEFT-TRUNCATED by the tokenizer side
@@ -687,8 +698,12 @@ class PrefixEpisode:
         if win:
             raise RuntimeError("an accumulation window holds teacher-forced TRAINING steps only (a no-grad / sampled step needs the "
                                "prefix's K/V now): open this episode with accumulate=1")
-        self._need_prefix_cache()          # (a step that runs now: the prefix's K/V must be in the cache)
-        if self.mode == "all" and P["defer"] and torch.is_grad_enabled():
+        batched_now = self.mode == "all" and P["defer"] and torch.is_grad_enabled()
+        if batched_now and os.environ.get("NAVILLM_EPISODE_ATTN_FWD", "episode") != "steps":
+            self._need_prefix()            # (a deferred step whose attention reads the episode buffers in place)
+        else:
+            self._need_prefix_cache()      # (a step that runs now over the K/V-cache layout: the prefix's K/V must be there)
+        if batched_now:
             # the LM sees a detached copy; the live tensor keeps this step's scene-encoder / fusion graph alive until finish()
             step["vis_live"] = vis_all
             step["batched"] = True
