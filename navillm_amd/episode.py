@@ -567,7 +567,14 @@ class PrefixEpisode:
         P = self.prefix
         if P.get("pending"):
             self._prefix_forward()
-        self._kv_layout()                      # (marks the cache invalid when it has to be built now)
+        self._fill_prefix_cache(P)
+
+    def _fill_prefix_cache(self, P):
+        """the prefix's post-RoPE K/V rows into the K/V-cache layout, unless they are there already"""
+        had = self.cache is not None
+        self._kv_layout()
+        if not had:
+            P["cache_valid"] = False
         if not P.get("cache_valid", True):
             for i in range(self.m.cfg.num_layers):
                 ops.scatter_rows_bf16_(self._E[i]["qkv"][:P["Mp"]], P["crow"], self.cache[i])
@@ -1256,6 +1263,8 @@ class PrefixEpisode:
                 T_tab, epi_tab, lse_tab = self._step_table(recs, Bk, Mp)
                 assert recs[0]["r0"] == Mp and all(a["r0"] + a["step"]["M"] == b_["r0"] for a, b_ in zip(recs, recs[1:])) and \
                     recs[-1]["r0"] + recs[-1]["step"]["M"] == R, "the steps' blocks must tile rows [Mp, R) of the episode buffers"
+            if epi_tab is None and recs:
+                self._fill_prefix_cache(P)                   # the per-step backward form reads the prefix's K/V from the K/V-cache layout
             for i in reversed(range(L)):
                 Wqkv, Wo, Wgu, Wd, w1, w2, gqkv, go, ggu, gd, gw1, gw2 = self._weights(i)
                 E, E32 = self._E[i], self._E32[i]
