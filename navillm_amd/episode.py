@@ -1022,8 +1022,10 @@ class PrefixEpisode:
             epi_fwd = (os.environ.get("NAVILLM_EPISODE_ATTN_FWD", "episode") != "steps" and f_fits) or bool(P.get("window"))
             if epi_fwd:
                 T, f_tab, f_lse = self._step_table(recs, Bk, Mp)
+            elif pend:
+                self._kv_layout()                      # (the layer loop below scatters the prefix rows as it computes them)
             else:
-                self._kv_layout()
+                self._fill_prefix_cache(P)             # the prefix went through the decoder earlier: its K/V rows into the cache layout
             x = ops.embed_vis(st.p("lang_model.model.embed_tokens.weight"), ids_cat, vix_cat, vis_cat, out=self._E[0]["x"][rows])
             for i in range(L):
                 Wqkv, Wo, Wgu, Wd, w1, w2 = self._weights(i)[:6]
