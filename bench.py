@@ -218,8 +218,10 @@ def roofline_of(timer, dt, steps, mode, model):
             "by_layout_tflops": {n: (round(v["tflops"], 1) if v else None) for n, v in per.items()},
             "all_gemm_flops_per_step": allg["flops_per_launch"] * allg["launches"] / n_sampled,
             "gemm_share_of_step": round(allg["gemm_seconds"] / n_sampled / (dt / steps), 3),
-            "note": "peak = nominal dense bf16 MFMA; with N(0,1) operands the MFMA pipe of this part sustains 1.87-2.0 PFLOP/s "
-                    "(power-limited clock; tools/ubench/mix_rate.hip, DESIGN.md §4); traffic = 2*FETCH_SIZE+WRITE_SIZE per launch from the "
+            "note": "peak = nominal dense bf16 MFMA (2.5 PF).  Sustained ceiling, ONE statement (DESIGN.md §8 item 2): with N(0,1) operands the part "
+                    "clocks to ~1.71 GHz inside this kernel's loop (tools/gemm_clock.py), where the dense bf16 MFMA peak is 1.79 PF; register-only "
+                    "micro-benchmarks on the same data reach 1.85-2.05 PF (tools/ubench/mfma_rate.hip); the fastest GEMM measured on this box in any "
+                    "implementation is a hipBLASLt cell at 1.52 PF (profiles/r05_gemm_vs_blaslt.txt); traffic = 2*FETCH_SIZE+WRITE_SIZE per launch from the "
                     "separate rocprofv3 --pmc passes of THIS training mode committed under profiles/ (`traffic_source`; null when that profile was taken from "
                     "another version of gemm_bf16.hip); it counts the L2s' fabric requests, Infinity-Cache hits included (MI355X_MICROARCH.md "
                     "§HBM), so it is an upper bound of the HBM bytes; algorithmic_bytes_per_launch = operands read once + C written once "
