@@ -12,6 +12,7 @@ Inference extras: `enable_kv_cache()` = prompt-prefix K/V reuse
 Not mirrored (raise NotImplementedError): fp32 LM, OPT LMs.
 """
 import collections
+import contextlib
 import functools
 import itertools
 import os
@@ -420,10 +421,23 @@ class NavModel(nn.Module):
     def grad_handover(self, why="caller"):
         """everything that is still deferred becomes `.grad` NOW: the open accumulation window and the automatic episode.  Called by
         whoever is about to read the gradients (FlatAdamW, `parameters()`, NavDataParallel.parameters())."""
-        if getattr(self, "_window", None) is not None:
-            self._window.flush_window()
-        if getattr(self, "_auto_open", False):
-            self._auto_close(why)
+        w = getattr(self, "_window", None)
+        todo_w = w is not None and w.window_open()
+        todo_a = getattr(self, "_auto_open", False)
+        if not (todo_w or todo_a):
+            return
+        # whoever is about to clip / step is past the optimizer step's LAST backward: under data parallelism the deferred work that runs
+        # now IS that backward, so it runs inside final_backward() and its per-layer exchange is launched from the deferred walk, overlapped
+        # -- an unmodified training loop gets the overlap without knowing the context exists.  (A handover that turns out NOT to be the last
+        # backward -- model.parameters() called for logging -- costs a second exchange at the optimizer, not correctness: the mean over
+        # ranks is linear, and every rank then holds mean(A) + its later local gradients.)
+        dp = getattr(self, "_dp", None)
+        ctx = dp.final_backward if (dp is not None and why in ("optimizer", "parameters") and hasattr(dp, "final_backward")) else contextlib.nullcontext
+        with ctx():
+            if todo_w:
+                w.flush_window()
+            if todo_a:
+                self._auto_close(why)
 
     def flush_accumulation_window(self):
         """hand over the gradients of the open accumulation window (`begin_episode(..., accumulate=n)`) now; a no-op without one.

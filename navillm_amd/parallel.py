@@ -165,7 +165,10 @@ class GradSlices:
         self.rest = [lm[:first_s], lm[last_e:], store.grad["f32"]]   # embeddings | norm+lm_head+heads | fp32 side
 
     def all_slices(self):
-        return self.layer + self.rest
+        """every slice, in the order the overlapped exchange issues them (decoder layers LAST to FIRST, as the backward finishes them, then the
+        rest): a rank that exchanges from inside its last backward and a rank that has nothing deferred and exchanges in the optimizer's
+        flush must issue the SAME sequence of collectives, or equal-sized layer slices would be paired across different layers"""
+        return self.layer[::-1] + self.rest
 
 
 class NavDataParallel(torch.nn.parallel.DistributedDataParallel):

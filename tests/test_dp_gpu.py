@@ -311,15 +311,13 @@ def _prefix_episode(model, wrapped, seed, steps, dev=DEV, teacher_forced=False):
     torch.manual_seed(1)
     if teacher_forced == "auto":
         # round 6: AUTOMATIC episode -- the rollout makes no begin_episode / finish_episode call (synthetic.reference_rollout = the
-        # reference's loop); its deferred work runs when the gradients are handed over, which under the wrapper happens inside
-        # final_backward() so that the per-layer exchange is launched from the deferred backward walk (what bench.py does around the clip)
-        import contextlib
+        # reference's loop); its deferred work runs when the gradients are handed over -- by the optimizer's clip / step, which under the
+        # wrapper runs it inside final_backward() by itself, so that the per-layer exchange is launched from the deferred backward walk
         from navillm_amd.synthetic import reference_rollout
         model.auto_episode, model.auto_form = True, "lazy"
         reference_rollout(wrapped, CrossEntropyLoss(), ep, steps)
         assert model._auto_open
-        with (wrapped.final_backward() if hasattr(wrapped, "final_backward") else contextlib.nullcontext()):
-            model.grad_handover("test")
+        model.grad_handover("optimizer")          # (what FlatAdamW.clip_grad_norm_ / step call first: under a wrapper it runs inside final_backward())
         model.auto_episode = False
     elif teacher_forced == "window":
         # round 5: an accumulation window of two teacher-forced episodes (begin_episode(..., accumulate=2)); the second finish_episode()
