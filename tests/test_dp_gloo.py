@@ -71,6 +71,11 @@ def _worker(rank, world, port, q):
     ddp.train(); ddp.eval(); model.train(); model.eval()
     ddp.state_dict(); model.state_dict()
     ok &= model._dp is ddp and "_dp" not in dict(model.named_children())
+    # the one-shot exchange (the optimizer's flush) issues the slices in the order the overlapped exchange does -- layers last to first, then
+    # the rest -- so that ranks reaching the optimizer step by different paths still pair the same slices (round 6)
+    sl = ddp.slices.all_slices()
+    ok &= [t.data_ptr() for t in sl[:cfg.num_layers]] == [t.data_ptr() for t in reversed(ddp.slices.layer)] and \
+        [t.data_ptr() for t in sl[cfg.num_layers:]] == [t.data_ptr() for t in ddp.slices.rest]
     # the reference's own type check (mp3d_agent.py:661) accepts the wrapper unchanged
     ok &= isinstance(ddp, torch.nn.parallel.DistributedDataParallel) and ddp.module is model
     st = model.store
