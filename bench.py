@@ -808,7 +808,16 @@ def main():
         os.environ["NAVILLM_COMM"] = "torch"
     # N > 1: the CONTROL plane (rendezvous, barriers, the max-over-ranks clock, the 128-byte RCCL id) runs over gloo, so that nothing of it
     # depends on RCCL; the gradients travel through the C-ABI communicator (RCCL over xGMI), picked and verified by `dp_preflight` below
-    device, rank, world = init_distributed_device(backend="gloo", device_index=0 if REHEARSAL else None)
+    control_note = None
+    try:
+        device, rank, world = init_distributed_device(backend="gloo", device_index=0 if REHEARSAL else None)
+    except Exception as e:
+        if REHEARSAL:
+            raise
+        # (a host on which gloo cannot come up: the control plane falls back to ProcessGroupNCCL, as in rounds 1-5)
+        control_note = f"gloo control plane failed ({type(e).__name__}: {e}); using nccl"
+        print(f"[bench] {control_note}", file=sys.stderr, flush=True)
+        device, rank, world = init_distributed_device(backend=None)
     # Host threads for torch's CPU-side glue ops (masks, index lists): a handful.  With the default (all 256 hardware
     # threads) a barrier of the intra-op pool now and then takes 80-100 ms on a tiny tensor (tools/pack_probe.py), longer
     # than a whole forward; and with one process per GPU the ranks must share the host anyway.  (cpu_baseline sets its own.)
@@ -1126,7 +1135,7 @@ def main():
         if world > 1:
             line["dp"] = {"transport": "nv_comm (RCCL, C ABI)" if wrapped.comm is not None else "torch.distributed",
                           "reduce": wrapped.reduce, "algo": wrapped.algo, "calibration": wrapped.calibration,
-                          "rccl_version_per_rank": rccl_versions, "exchange": dp_exchange, "control_plane": dist.get_backend(), "preflight": preflight,
+                          "rccl_version_per_rank": rccl_versions, "exchange": dp_exchange, "control_plane": dist.get_backend(), "control_plane_note": control_note, "preflight": preflight,
                           "what": "gradients averaged once per optimizer step, per-layer slices exchanged from inside the "
                                   "episode's last backward on a side stream"}
         if infer is not None:

@@ -51,6 +51,10 @@ def init_distributed_device(backend=None, device_index=None):
         backend = backend or "gloo"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "gloo" and os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+            # one node: gloo's TCP transport otherwise picks its interface by resolving the machine's hostname, which a container's
+            # may not do; the loopback interface always exists
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = device
